@@ -1,0 +1,10 @@
+"""graph_physics_amd: MI355X-native MeshGraphNet message-passing engine behind the
+Encoder/Processor/Decoder module API of DonsetPG/graph-physics."""
+from .nodetype import NodeType  # noqa: F401
+from .mesh import Graph, collate, cylinder_mesh, cylinder_batch, square_mesh  # noqa: F401
+from .layers import GraphNetBlock, Normalizer, RMSNorm, build_mlp  # noqa: F401
+from .processors import EncodeProcessDecode  # noqa: F401
+from .simulator import Simulator  # noqa: F401
+from .parse_parameters import get_model, get_simulator, cylinder_config  # noqa: F401
+
+__version__ = "0.1.0"

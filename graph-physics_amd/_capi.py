@@ -1,0 +1,162 @@
+"""ctypes binding of the C-ABI library ``csrc/libmgn_hip.so`` (include/mgn_hip.h).
+
+The product path has no CPU fallback: if the library cannot be loaded (or built
+with hipcc when missing), every op raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_REPO = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_CSRC, "libmgn_hip.so")
+SOURCES = [os.path.join(_CSRC, "mgn_kernels.hip")]
+HEADER = os.path.join(_REPO, "include", "mgn_hip.h")
+
+MAX_LAYERS = 8
+MAX_PHASES = 3
+MAX_WGRAD_JOBS = 12
+
+_f32p = C.c_void_p  # raw device pointers travel as integers
+_i32p = C.c_void_p
+
+
+class MlpFwdArgs(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64),
+        ("H", C.c_int), ("NL", C.c_int), ("nphase", C.c_int),
+        ("src", _f32p * MAX_PHASES),
+        ("idx", _i32p * MAX_PHASES),
+        ("kw", C.c_int * MAX_PHASES),
+        ("W", _f32p * MAX_LAYERS),
+        ("b", _f32p * MAX_LAYERS),
+        ("scale", _f32p),
+        ("eps", C.c_float),
+        ("out_w", C.c_int),
+        ("resid", _f32p),
+        ("out", _f32p),
+        ("y_out", _f32p),
+        ("saveH", _f32p * MAX_LAYERS),
+        ("saveU", _f32p),
+        ("saveR", _f32p),
+    ]
+
+
+class MlpBwdArgs(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64),
+        ("H", C.c_int), ("NL", C.c_int),
+        ("dOut", _f32p),
+        ("dOut2", _f32p),
+        ("idx2", _i32p),
+        ("out_w", C.c_int),
+        ("U", _f32p), ("R", _f32p), ("scale", _f32p), ("eps", C.c_float),
+        ("Hs", _f32p * MAX_LAYERS),
+        ("WT", _f32p * MAX_LAYERS),
+        ("dZ", _f32p * MAX_LAYERS),
+        ("n_din", C.c_int),
+        ("WT0", _f32p * MAX_PHASES),
+        ("din_resid", _f32p * MAX_PHASES),
+        ("dIn", _f32p * MAX_PHASES),
+        ("db", _f32p * MAX_LAYERS),
+        ("dscale", _f32p),
+        ("red_ws", C.c_void_p), ("red_ws_bytes", C.c_size_t),
+    ]
+
+
+class WgradJob(C.Structure):
+    _fields_ = [
+        ("A", _f32p), ("B", _f32p), ("dW", _f32p),
+        ("M", C.c_int64),
+        ("lda", C.c_int), ("ldb", C.c_int), ("ldw", C.c_int),
+        ("nja", C.c_int), ("nkb", C.c_int), ("kw", C.c_int),
+    ]
+
+
+#: every symbol include/mgn_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mgn_version": (C.c_int, []),
+    "mgn_last_error": (C.c_char_p, []),
+    "mgn_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "mgn_csr_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_segsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "mgn_mlp_fwd": (C.c_int, [C.POINTER(MlpFwdArgs), C.c_void_p]),
+    "mgn_mlp_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "mgn_mlp_bwd": (C.c_int, [C.POINTER(MlpBwdArgs), C.c_void_p]),
+    "mgn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(WgradJob)]),
+    "mgn_wgrad": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def hipcc_path():
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if p and os.path.exists(p):
+            return p
+    from shutil import which
+
+    return which("hipcc")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > t for s in SOURCES + [HEADER])
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into csrc/libmgn_hip.so (in-tree)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: cannot build csrc/libmgn_hip.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", os.path.join(_REPO, "include"), "-o", LIB_PATH + ".tmp"] + SOURCES
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    if verbose:
+        print("built", LIB_PATH)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded C-ABI library.  Raises RuntimeError if it is missing and cannot be built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if needs_build():
+                try:
+                    build()
+                except Exception as e:  # noqa: BLE001
+                    if not os.path.exists(LIB_PATH):
+                        raise RuntimeError(
+                            f"MI355X engine library {LIB_PATH} is missing and could not be built ({e}); "
+                            "run `python -c 'import __graft_entry__ as g; g.build()'`") from e
+            try:
+                L = C.CDLL(LIB_PATH)
+            except OSError as e:
+                raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().mgn_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

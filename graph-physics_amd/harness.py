@@ -1,0 +1,98 @@
+"""Training-step and rollout loops that reproduce the semantics of the reference's
+LightningModule for the MeshGraphNet path without Lightning (not installed on the
+GPU box):
+
+  * training step  (training/lightning_module.py:270-320): Simulator forward,
+    masked L2 on NORMAL|OUTFLOW nodes (utils/loss.py:37-75, default masks
+    lightning_module.py:48), backward, clip-grad-norm 1.0 (train.py:288),
+    AdamW(lr, betas=(0.9,0.95), weight_decay=1e-4) + cosine warm-up
+    (lightning_module.py:494-511, utils/scheduler.py:51-67);
+  * rollout  (lightning_module.py:375-409): autoregressive feedback of the last
+    prediction, ground truth re-imposed on the non NORMAL/OUTFLOW nodes.
+
+These are what ``bench.py`` times ("training steps/sec", "rollout nodes*steps/sec").
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+from .mesh import Graph
+from .nodetype import NodeType
+from .parse_parameters import get_model, get_simulator
+
+
+def lr_factor(last_epoch: int, warmup: int, max_iters: int, min_lr_factor: float = 0.001) -> float:
+    epoch = last_epoch + 1
+    f = 0.5 * (1 + math.cos(math.pi * epoch / max_iters))
+    if epoch <= warmup:
+        f *= epoch * 1.0 / warmup
+    return max(f, min_lr_factor)
+
+
+def l2_loss(network_output: torch.Tensor, target: torch.Tensor, node_type: torch.Tensor,
+            masks: Sequence[int] = (NodeType.NORMAL, NodeType.OUTFLOW)) -> torch.Tensor:
+    mask = node_type == int(masks[0])
+    for t in masks[1:]:
+        mask = torch.logical_or(mask, node_type == int(t))
+    # mean over the selected rows' elements, without a data-dependent shape (no host sync)
+    w = mask.to(network_output.dtype).unsqueeze(1)
+    err = (network_output - target) ** 2 * w
+    return err.sum() / (w.sum() * network_output.shape[1])
+
+
+def build_mask(node_type: torch.Tensor) -> torch.Tensor:
+    keep = torch.logical_or(node_type == int(NodeType.NORMAL), node_type == int(NodeType.OUTFLOW))
+    return torch.logical_not(keep)
+
+
+class Engine:
+    """Model + simulator + optimiser for one device."""
+
+    def __init__(self, param: Dict[str, Any], device: torch.device, learning_rate: float = 1e-4,
+                 num_steps: int = 1000, warmup: int = 100, grad_clip: float = 1.0):
+        self.param, self.device = param, device
+        self.model = get_model(param)
+        self.sim = get_simulator(param, self.model, device)
+        self.learning_rate, self.num_steps, self.warmup, self.grad_clip = learning_rate, num_steps, warmup, grad_clip
+        self.opt = torch.optim.AdamW(self.sim.parameters(), lr=learning_rate, weight_decay=0.0001, betas=(0.9, 0.95))
+        self.step_count = 0
+        self.grad_sync = None  # set by distributed.DataParallel: callable(params) all-reducing .grad
+
+    def train_step(self, batch: Graph) -> torch.Tensor:
+        self.sim.train()
+        for g in self.opt.param_groups:
+            g["lr"] = self.learning_rate * lr_factor(self.step_count, self.warmup, self.num_steps)
+        node_type = batch.x[:, self.sim.node_type_index]
+        net_out, target, _ = self.sim(batch)
+        loss = l2_loss(net_out, target, node_type)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync(self.sim.parameters())
+        self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.sim.parameters(), self.grad_clip)
+        self.opt.step()
+        self.step_count += 1
+        return loss.detach()
+
+    @torch.no_grad()
+    def predict_step(self, batch: Graph, last_prediction: Optional[torch.Tensor]) -> torch.Tensor:
+        self.sim.eval()
+        batch = batch.clone()
+        i0, i1 = self.sim.output_index_start, self.sim.output_index_end
+        if last_prediction is not None:
+            batch.x[:, i0:i1] = last_prediction
+        mask = build_mask(batch.x[:, self.sim.node_type_index])
+        _, _, pred = self.sim(batch)
+        pred = torch.where(mask.unsqueeze(1), batch.y, pred)
+        return pred
+
+    @torch.no_grad()
+    def rollout(self, frames: Sequence[Graph]) -> List[torch.Tensor]:
+        last, out = None, []
+        for fr in frames:
+            last = self.predict_step(fr, last)
+            out.append(last)
+        return out

@@ -1,0 +1,175 @@
+"""Module mirror of the reference's hot-path layers
+(graphphysics/models/layers.py): same constructor signatures, attribute names and
+``state_dict`` keys, so checkpoints and the Simulator/LightningModule glue carry
+over; ``forward`` runs on the HIP engine (``ops``), never on a torch/CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+# process-global activation switch, like layers.py:132-147
+_USE_SILU_ACTIVATION = False
+
+
+def set_use_silu_activation(use_silu: bool) -> None:
+    global _USE_SILU_ACTIVATION
+    _USE_SILU_ACTIVATION = bool(use_silu)
+
+
+def use_silu_activation() -> bool:
+    return _USE_SILU_ACTIVATION
+
+
+class RMSNorm(nn.Module):
+    """Parameter holder for the trailing normalisation of ``build_mlp``
+    (layers.py:73-129: y = scale * x / (||x||/sqrt(d) + eps), eps OUTSIDE the
+    root).  The arithmetic is fused into the MLP kernel's epilogue."""
+
+    def __init__(self, d: int, p: float = -1.0, eps: float = 1e-8, bias: bool = False):
+        super().__init__()
+        if bias or (0.0 <= p <= 1.0):
+            raise NotImplementedError("partial / biased RMSNorm is not on the MeshGraphNet path")
+        if eps != ops.EPS:
+            raise NotImplementedError("the engine uses the reference default eps=1e-8")
+        self.d, self.p, self.eps, self.bias = d, p, eps, bias
+        self.scale = nn.Parameter(torch.ones(d))
+
+    def forward(self, x):  # never used stand-alone on the path
+        raise RuntimeError("RMSNorm runs fused inside the MLP kernel; call the enclosing MLP")
+
+
+class ReLU(nn.Module):
+    """Placeholder so that Sequential indices match the reference (entries 1,3,5)."""
+
+    def forward(self, x):
+        raise RuntimeError("activation runs fused inside the MLP kernel; call the enclosing MLP")
+
+
+class MLP(nn.Sequential):
+    """``build_mlp`` result: entries 0,2,4,.. nn.Linear, odd entries activation,
+    last entry RMSNorm if ``layer_norm`` (layers.py:198-210).  forward() is one
+    fused HIP kernel (ops.MlpFunction)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        lin = [m for m in self if isinstance(m, nn.Linear)]
+        norm = self[len(self) - 1] if isinstance(self[len(self) - 1], RMSNorm) else None
+        params = []
+        for m in lin:
+            params += [m.weight, m.bias]
+        if norm is not None:
+            params.append(norm.scale)
+        return ops.MlpFunction.apply(x, norm is not None, *params)
+
+
+def build_mlp(in_size: int, hidden_size: int, out_size: int, nb_of_layers: int = 4,
+              layer_norm: bool = True, act: Optional[str] = None) -> nn.Module:
+    """Same signature / assertion as the reference build_mlp (layers.py:163-210)."""
+    assert nb_of_layers >= 2, "The MLP must have at least 2 layers (input and output)."
+    key = act if act is not None else ("silu" if _USE_SILU_ACTIVATION else "relu")
+    if key not in ("relu", "gelu", "silu"):
+        raise NotImplementedError(f"Activation '{key}' not supported. Available: ['relu', 'gelu', 'silu'].")
+    if key != "relu":
+        raise NotImplementedError(f"activation '{key}' is a 'next' row (SURVEY.md N3); the MI355X engine implements ReLU")
+    layers = [nn.Linear(in_size, hidden_size), ReLU()]
+    for _ in range(nb_of_layers - 2):
+        layers.extend([nn.Linear(hidden_size, hidden_size), ReLU()])
+    layers.append(nn.Linear(hidden_size, out_size))
+    if layer_norm:
+        layers.append(RMSNorm(out_size))
+    return MLP(*layers)
+
+
+def _block_params(block: "GraphNetBlock"):
+    out = []
+    for mlp in (block.edge_block, block.node_block):
+        for i in (0, 2, 4, 6):
+            out += [mlp[i].weight, mlp[i].bias]
+        out.append(mlp[7].scale)
+    return out
+
+
+class GraphNetBlock(nn.Module):
+    """One MeshGraphNet round (layers.py:890-1042): gather -> edge MLP ->
+    segment-sum -> node MLP -> residuals, on the HIP engine."""
+
+    def __init__(self, hidden_size: int, nb_of_layers: int = 4, layer_norm: bool = True,
+                 use_rope: bool = False, rope_axes: int = 3, rope_base: float = 10000.0,
+                 use_gated_mlp: bool = False, use_gate: bool = False):
+        super().__init__()
+        if use_rope and rope_axes not in (2, 3):
+            raise ValueError("rope_axes must be 2 or 3 when use_rope=True.")
+        if use_rope or use_gated_mlp or use_gate:
+            raise NotImplementedError("rope / gate / gated-MLP GraphNetBlock variants are 'next' rows (SURVEY.md N3)")
+        if nb_of_layers != 4 or not layer_norm:
+            raise NotImplementedError("the engine implements the reference default block (4 layers, RMSNorm)")
+        self.hidden_size = hidden_size
+        self.use_gated_mlp, self.use_rope, self.use_gate = use_gated_mlp, use_rope, use_gate
+        self.rope_axes, self.rope_base = rope_axes, rope_base
+        self.edge_block = build_mlp(3 * hidden_size, hidden_size, hidden_size, nb_of_layers, layer_norm)
+        self.node_block = build_mlp(2 * hidden_size, hidden_size, hidden_size, nb_of_layers, layer_norm)
+        self.register_buffer("_rope_inv_freq", torch.zeros(0), persistent=False)  # layers.py:977-981
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor, size=None,
+                pos: Optional[torch.Tensor] = None, phi: Optional[torch.Tensor] = None
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+        topo = ops.get_topology(edge_index, x.shape[0])
+        e_sorted = edge_attr[topo.perm_dst.long()]
+        x_new, e_new = ops.ProcessorFunction.apply(x, e_sorted, topo, 1, *_block_params(self))
+        return x_new, e_new[topo.inv_perm]
+
+
+class Normalizer(nn.Module):
+    """Online mean/std normaliser (layers.py:281-408); elementwise boundary code
+    kept in PyTorch-ROCm.  Same buffers / keys."""
+
+    def __init__(self, size: int, max_accumulations: int = 10**5, std_epsilon: float = 1e-8,
+                 name: str = "Normalizer", device: Optional[Union[str, torch.device]] = "cuda"):
+        super().__init__()
+        self.name, self.device = name, device
+        self._max_accumulations = max_accumulations
+        self._std_epsilon = torch.tensor(std_epsilon, dtype=torch.float32, requires_grad=False, device=device)
+        self.register_buffer("_acc_count", torch.tensor(0.0, device=device))
+        self.register_buffer("_num_accumulations", torch.tensor(0.0, device=device))
+        self.register_buffer("_acc_sum", torch.zeros((1, size), dtype=torch.float32, device=device))
+        self.register_buffer("_acc_sum_squared", torch.zeros((1, size), dtype=torch.float32, device=device))
+        self._host_num_acc: Optional[int] = None  # host mirror: avoids a device sync per call
+
+    def forward(self, batched_data: torch.Tensor, accumulate: bool = True) -> torch.Tensor:
+        if accumulate:
+            if self._host_num_acc is None:
+                self._host_num_acc = int(self._num_accumulations.item())
+            if self._host_num_acc < self._max_accumulations:
+                self._accumulate(batched_data.detach())
+                self._host_num_acc += 1
+        return (batched_data - self._mean()) / self._std_with_epsilon()
+
+    def inverse(self, normalized_batch_data: torch.Tensor) -> torch.Tensor:
+        return normalized_batch_data * self._std_with_epsilon() + self._mean()
+
+    def _accumulate(self, batched_data: torch.Tensor):
+        self._acc_sum += torch.sum(batched_data, dim=0, keepdim=True)
+        self._acc_sum_squared += torch.sum(batched_data**2, dim=0, keepdim=True)
+        self._acc_count += batched_data.shape[0]
+        self._num_accumulations += 1
+
+    def _mean(self) -> torch.Tensor:
+        return self._acc_sum / torch.clamp(self._acc_count, min=1.0)
+
+    def _std_with_epsilon(self) -> torch.Tensor:
+        safe = torch.clamp(self._acc_count, min=1.0)
+        var = self._acc_sum_squared / safe - self._mean() ** 2
+        return torch.max(torch.sqrt(torch.clamp(var, min=0.0)), self._std_epsilon.to(var.device))
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._host_num_acc = None
+
+    def get_variable(self):
+        return {"_max_accumulations": self._max_accumulations, "_std_epsilon": self._std_epsilon,
+                "_acc_count": self._acc_count, "_num_accumulations": self._num_accumulations,
+                "_acc_sum": self._acc_sum, "_acc_sum_squared": self._acc_sum_squared, "name": self.name}

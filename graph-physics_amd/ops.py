@@ -1,0 +1,399 @@
+"""Host side of the engine: thin wrappers over the C ABI (include/mgn_hip.h) and
+the ``torch.autograd.Function``s that make ``loss.backward()``, gradient clipping
+and AdamW work unchanged on top of the HIP kernels.
+
+PyTorch is plumbing here: it owns device memory and the stream; every FLOP of the
+message-passing path runs in ``csrc/mgn_kernels.hip``.  There is no CPU path: a
+CPU tensor or a missing library raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _capi
+
+EPS = 1e-8  # RMSNorm epsilon of the reference (layers.py:80)
+SUPPORTED_H = (16, 32, 64, 128)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _require_device(*ts: torch.Tensor):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "graph_physics_amd runs on MI355X only: got a CPU tensor. Move the model and the "
+                "graph to the GPU (there is no CPU fallback).")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def pad16(n: int) -> int:
+    return (n + 15) & ~15
+
+
+# --------------------------------------------------------------------- topology
+class Topology:
+    """dst-sorted (CSR) edge order of one ``edge_index`` plus the src-grouped view
+    the backward scatter needs.  Built on the device by ``mgn_csr_build``; cached
+    per ``edge_index`` tensor by :func:`get_topology` (mesh topology is static
+    along a trajectory)."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+        _require_device(edge_index)
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError("edge_index must have shape [2, E]")
+        dev = edge_index.device
+        ei = edge_index.to(torch.int64).contiguous()
+        E, N = int(ei.shape[1]), int(num_nodes)
+        self.N, self.E, self.device = N, E, dev
+        self.rowptr_dst, self.perm_dst = csr_build(ei[1], N)
+        p = self.perm_dst.long()
+        self.src_s = ei[0][p].to(torch.int32).contiguous()
+        self.dst_s = ei[1][p].to(torch.int32).contiguous()
+        self.rowptr_src, self.perm_src = csr_build(self.src_s.long(), N)
+        self._inv = None
+
+    @property
+    def inv_perm(self) -> torch.Tensor:
+        """position in the sorted order of each original edge id"""
+        if self._inv is None:
+            inv = torch.empty(self.E, dtype=torch.int64, device=self.device)
+            inv[self.perm_dst.long()] = torch.arange(self.E, device=self.device)
+            self._inv = inv
+        return self._inv
+
+
+_topo_cache: dict = {}
+
+
+def get_topology(edge_index: torch.Tensor, num_nodes: int) -> Topology:
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes), str(edge_index.device))
+    hit = _topo_cache.get(key)
+    if hit is not None and hit[0]() is edge_index:
+        return hit[1]
+    import weakref
+
+    topo = Topology(edge_index, num_nodes)
+    if len(_topo_cache) > 64:
+        _topo_cache.clear()
+    try:
+        _topo_cache[key] = (weakref.ref(edge_index), topo)
+    except TypeError:
+        pass
+    return topo
+
+
+def csr_build(key: torch.Tensor, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(rowptr[n+1] int32, perm[E] int32): stable grouping of edge ids by key."""
+    _require_device(key)
+    L = _capi.lib()
+    key = key.to(torch.int64).contiguous()
+    E = key.numel()
+    dev = key.device
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(E, dtype=torch.int32, device=dev)
+    nbytes = L.mgn_csr_workspace_bytes(E, n)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.mgn_csr_build(_ptr(key), E, n, _ptr(rowptr), _ptr(perm), _ptr(ws), ws.numel(), _stream(dev))
+    if rc == 3:
+        raise IndexError(f"edge_index has entries outside [0, {n})")
+    _capi.check(rc, "mgn_csr_build")
+    return rowptr, perm
+
+
+def segsum(src: torch.Tensor, rowptr: torch.Tensor, perm: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = sum of src rows of segment i (sequential in k order)."""
+    _require_device(src)
+    n = rowptr.numel() - 1
+    H = src.shape[1]
+    if out is None:
+        out = torch.empty(n, H, dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        rc = _capi.lib().mgn_segsum(_ptr(src), _ptr(rowptr), _ptr(perm), _ptr(out), n, H, _stream(src.device))
+    _capi.check(rc, "mgn_segsum")
+    return out
+
+
+# ----------------------------------------------------------------- raw launches
+def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], int]],
+            Ws: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]], scale: Optional[torch.Tensor],
+            out_w: int, resid: Optional[torch.Tensor], out: torch.Tensor, y_out: Optional[torch.Tensor] = None,
+            saveH: Optional[Sequence[torch.Tensor]] = None, saveU: Optional[torch.Tensor] = None,
+            saveR: Optional[torch.Tensor] = None):
+    a = _capi.MlpFwdArgs()
+    a.M, a.H, a.NL, a.nphase = M, H, len(Ws), len(phases)
+    for p, (src, idx, kw) in enumerate(phases):
+        a.src[p], a.idx[p], a.kw[p] = _ptr(src), _ptr(idx), kw
+    for l, (W, b) in enumerate(zip(Ws, bs)):
+        a.W[l], a.b[l] = _ptr(W), _ptr(b)
+    a.scale, a.eps, a.out_w = _ptr(scale), EPS, out_w
+    a.resid, a.out, a.y_out = _ptr(resid), _ptr(out), _ptr(y_out)
+    if saveH is not None:
+        for l, h in enumerate(saveH):
+            a.saveH[l] = _ptr(h)
+    a.saveU, a.saveR = _ptr(saveU), _ptr(saveR)
+    dev = out.device
+    with torch.cuda.device(dev):
+        rc = _capi.lib().mgn_mlp_fwd(C.byref(a), _stream(dev))
+    _capi.check(rc, "mgn_mlp_fwd")
+
+
+def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int, U, R, scale,
+            Hs: Sequence[torch.Tensor], WT: Sequence[Optional[torch.Tensor]], dZ: Sequence[Optional[torch.Tensor]],
+            din: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]],
+            db: Sequence[Optional[torch.Tensor]], dscale: Optional[torch.Tensor]):
+    L = _capi.lib()
+    a = _capi.MlpBwdArgs()
+    a.M, a.H, a.NL = M, H, NL
+    a.dOut, a.dOut2, a.idx2, a.out_w = _ptr(dOut), _ptr(dOut2), _ptr(idx2), out_w
+    a.U, a.R, a.scale, a.eps = _ptr(U), _ptr(R), _ptr(scale), EPS
+    for l, h in enumerate(Hs):
+        a.Hs[l] = _ptr(h)
+    for l in range(NL):
+        a.WT[l] = _ptr(WT[l])
+        a.dZ[l] = _ptr(dZ[l])
+        a.db[l] = _ptr(db[l])
+    a.n_din = len(din)
+    for q, (wt0, res, dst) in enumerate(din):
+        a.WT0[q], a.din_resid[q], a.dIn[q] = _ptr(wt0), _ptr(res), _ptr(dst)
+    a.dscale = _ptr(dscale)
+    dev = dOut.device
+    nbytes = L.mgn_mlp_bwd_workspace_bytes(M, H, NL)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    a.red_ws, a.red_ws_bytes = _ptr(ws), ws.numel()
+    with torch.cuda.device(dev):
+        rc = L.mgn_mlp_bwd(C.byref(a), _stream(dev))
+    _capi.check(rc, "mgn_mlp_bwd")
+
+
+def wgrad(jobs: Sequence[Tuple[torch.Tensor, int, int, torch.Tensor, int, int, int, torch.Tensor, int, int]], dev):
+    """jobs: (A, lda, nja, B, ldb, nkb, kw, dW_view_ptr_tensor, dW_offset_elems, ldw); M = A.shape[0]."""
+    L = _capi.lib()
+    for i0 in range(0, len(jobs), _capi.MAX_WGRAD_JOBS):
+        chunk = jobs[i0:i0 + _capi.MAX_WGRAD_JOBS]
+        arr = (_capi.WgradJob * len(chunk))()
+        for j, (A, lda, nja, B, ldb, nkb, kw, dW, off, ldw) in enumerate(chunk):
+            arr[j].A, arr[j].B = _ptr(A), _ptr(B)
+            arr[j].dW = dW.data_ptr() + 4 * off
+            arr[j].M = A.shape[0]
+            arr[j].lda, arr[j].ldb, arr[j].ldw = lda, ldb, ldw
+            arr[j].nja, arr[j].nkb, arr[j].kw = nja, nkb, kw
+        nbytes = L.mgn_wgrad_workspace_bytes(len(chunk), arr)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.mgn_wgrad(len(chunk), arr, _ptr(ws), ws.numel(), _stream(dev))
+        _capi.check(rc, "mgn_wgrad")
+
+
+# ------------------------------------------------------------ generic MLP (R2)
+class MlpFunction(torch.autograd.Function):
+    """build_mlp forward/backward on the engine (encoders, decoder, stand-alone MLPs).
+
+    apply(x, has_norm, W0, b0, ..., W_{NL-1}, b_{NL-1} [, scale]) -> y[M, out]
+    First-layer columns / last-layer rows are zero-padded to multiples of 16 here
+    (plumbing) so that the kernels only see aligned weights.
+    """
+
+    @staticmethod
+    def forward(ctx, x, has_norm, *params):
+        _require_device(x, *params)
+        x = _f32c(x)
+        NL = (len(params) - (1 if has_norm else 0)) // 2
+        Ws = [_f32c(params[2 * l]) for l in range(NL)]
+        bs = [_f32c(params[2 * l + 1]) for l in range(NL)]
+        scale = _f32c(params[2 * NL]) if has_norm else None
+        if NL < 2:
+            raise AssertionError("The MLP must have at least 2 layers (input and output).")
+        M, kin = x.shape
+        H = Ws[0].shape[0]
+        out_w = Ws[-1].shape[0]
+        if H not in SUPPORTED_H or kin > H or out_w > H:
+            raise NotImplementedError(f"MLP widths (in={kin}, hidden={H}, out={out_w}) not supported by the MI355X engine")
+        dev = x.device
+        kp, op = pad16(kin), pad16(out_w)
+        W0 = Ws[0]
+        if kp != kin:
+            W0 = torch.nn.functional.pad(W0, (0, kp - kin))
+        Wl, bl = Ws[-1], bs[-1]
+        if op != out_w:
+            Wl = torch.nn.functional.pad(Wl, (0, 0, 0, op - out_w))
+            bl = torch.nn.functional.pad(bl, (0, op - out_w))
+        Wk = [W0] + Ws[1:-1] + [Wl]
+        bk = bs[:-1] + [bl]
+        need = any(ctx.needs_input_grad)
+        y = torch.empty(M, out_w, dtype=torch.float32, device=dev)
+        saveH = [torch.empty(M, H, dtype=torch.float32, device=dev) for _ in range(NL - 1)] if need else None
+        U = torch.empty(M, H, dtype=torch.float32, device=dev) if (need and has_norm) else None
+        R = torch.empty(M, dtype=torch.float32, device=dev) if (need and has_norm) else None
+        mlp_fwd(M, H, [(x, None, kin)], Wk, bk, scale, out_w, None, y, None, saveH, U, R)
+        ctx.meta = (NL, H, kin, out_w, has_norm)
+        ctx.saved = (x, Wk, scale, saveH, U, R)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        NL, H, kin, out_w, has_norm = ctx.meta
+        x, Wk, scale, saveH, U, R = ctx.saved
+        dy = _f32c(dy)
+        M, dev = x.shape[0], x.device
+        kp, op = pad16(kin), pad16(out_w)
+        widths = [H] * (NL - 1) + [op]
+        dZ = [torch.empty(M, w, dtype=torch.float32, device=dev) for w in widths]
+        db = [torch.empty(w, dtype=torch.float32, device=dev) for w in widths]
+        dscale = torch.empty(H, dtype=torch.float32, device=dev) if has_norm else None
+        WT = [None] + [Wk[l].t().contiguous() for l in range(1, NL)]
+        din = []
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if kin != H:
+                raise NotImplementedError("input gradient of a ragged-width MLP input is not needed by the path")
+            dx = torch.empty(M, H, dtype=torch.float32, device=dev)
+            din = [(Wk[0].t().contiguous(), None, dx)]
+        mlp_bwd(M, H, NL, dy, None, None, out_w, U, R, scale, saveH, WT, dZ, din, db, dscale)
+        ins = [x] + list(saveH)
+        in_w = [kin] + [H] * (NL - 1)
+        dWs = [torch.empty(widths[l], pad16(in_w[l]), dtype=torch.float32, device=dev) for l in range(NL)]
+        jobs = []
+        for l in range(NL):
+            jobs.append((dZ[l], widths[l], widths[l] // 16, ins[l], in_w[l], pad16(in_w[l]) // 16, in_w[l], dWs[l], 0, pad16(in_w[l])))
+        wgrad(jobs, dev)
+        grads = []
+        for l in range(NL):
+            dW, dbl = dWs[l], db[l]
+            if l == 0 and kp != kin:
+                dW = dW[:, :kin]
+            if l == NL - 1 and op != out_w:
+                dW, dbl = dW[:out_w], dbl[:out_w]
+            grads += [dW, dbl]
+        if has_norm:
+            grads.append(dscale)
+        return (dx, None, *grads)
+
+
+# ------------------------------------------------- processor: L GraphNetBlocks (R3-R5)
+PARAMS_PER_BLOCK = 18  # edge W0,b0..W3,b3,scale ; node W0,b0..W3,b3,scale
+
+
+class ProcessorFunction(torch.autograd.Function):
+    """L rounds of gather -> edge MLP -> segment-sum -> node MLP -> residuals.
+
+    apply(x[N,H], e_sorted[E,H], topo, L, *params) -> (x_out, e_out_sorted)
+    ``e`` is in the topology's dst-sorted order.  params: 18 tensors per block in
+    state_dict order (edge_block.{0,2,4,6}.{weight,bias}, edge_block.7.scale,
+    node_block...).
+    """
+
+    @staticmethod
+    def forward(ctx, x, e, topo: Topology, L: int, *params):
+        _require_device(x, e, *params)
+        x, e = _f32c(x), _f32c(e)
+        N, H = x.shape
+        E = e.shape[0]
+        if H not in SUPPORTED_H:
+            raise NotImplementedError(f"hidden_size={H} not supported by the MI355X engine (16/32/64/128)")
+        if N != topo.N or E != topo.E:
+            raise ValueError("x / edge_attr do not match the topology")
+        dev = x.device
+        P = [_f32c(p) for p in params]
+        need = any(ctx.needs_input_grad)
+        f = dict(dtype=torch.float32, device=dev)
+        m = torch.empty(E, H, **f)
+        saved = []
+        for i in range(L):
+            q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
+            We, be, se = [q[0], q[2], q[4], q[6]], [q[1], q[3], q[5], q[7]], q[8]
+            Wn, bn, sn = [q[9], q[11], q[13], q[15]], [q[10], q[12], q[14], q[16]], q[17]
+            e_new = torch.empty(E, H, **f)
+            x_new = torch.empty(N, H, **f)
+            agg = torch.empty(N, H, **f)
+            if need:
+                He = [torch.empty(E, H, **f) for _ in range(3)]
+                Ue, Re = torch.empty(E, H, **f), torch.empty(E, **f)
+                Hn = [torch.empty(N, H, **f) for _ in range(3)]
+                Un, Rn = torch.empty(N, H, **f), torch.empty(N, **f)
+            else:
+                He = Hn = None
+                Ue = Re = Un = Rn = None
+            # R3: m = edge_block(cat[e, x[dst], x[src]]);  e' = e + m     (layers.py:1017-1028,1039)
+            mlp_fwd(E, H, [(e, None, H), (x, topo.dst_s, H), (x, topo.src_s, H)], We, be, se, H, e, e_new, m, He, Ue, Re)
+            # R4: agg = segment-sum of m over dst                          (layers.py:1031-1037)
+            segsum(m, topo.rowptr_dst, None, agg)
+            # R5: x' = x + node_block(cat[x, agg])                         (layers.py:1100-1101,1040)
+            mlp_fwd(N, H, [(x, None, H), (agg, None, H)], Wn, bn, sn, H, x, x_new, None, Hn, Un, Rn)
+            if need:
+                saved.append((x, e, agg, He, Ue, Re, Hn, Un, Rn))
+            x, e = x_new, e_new
+        ctx.topo, ctx.L, ctx.P, ctx.saved_acts = topo, L, P, saved
+        return x, e
+
+    @staticmethod
+    def backward(ctx, dx, de):
+        topo, L, P, saved = ctx.topo, ctx.L, ctx.P, ctx.saved_acts
+        dev = P[0].device
+        N, E = topo.N, topo.E
+        H = P[1].numel()
+        f = dict(dtype=torch.float32, device=dev)
+        dx = _f32c(dx) if dx is not None else torch.zeros(N, H, **f)
+        de = _f32c(de) if de is not None else torch.zeros(E, H, **f)
+        dZn = [torch.empty(N, H, **f) for _ in range(4)]
+        dZe = [torch.empty(E, H, **f) for _ in range(4)]
+        dAgg, Sd, Ss = torch.empty(N, H, **f), torch.empty(N, H, **f), torch.empty(N, H, **f)
+        dx_buf, de_buf = [torch.empty(N, H, **f), torch.empty(N, H, **f)], [torch.empty(E, H, **f), torch.empty(E, H, **f)]
+        grads: List[Optional[torch.Tensor]] = [None] * (PARAMS_PER_BLOCK * L)
+        nb = H // 16
+        for i in reversed(range(L)):
+            q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
+            We, se = [q[0], q[2], q[4], q[6]], q[8]
+            Wn, sn = [q[9], q[11], q[13], q[15]], q[17]
+            x, e, agg, He, Ue, Re, Hn, Un, Rn = saved[i]
+            g = [torch.empty_like(t) for t in q]
+            # transposed weights for the dgrad chains (plumbing copies of 128x128 blocks)
+            WTn = [None] + [Wn[l].t().contiguous() for l in (1, 2, 3)]
+            WTe = [None] + [We[l].t().contiguous() for l in (1, 2, 3)]
+            WT0n_agg = Wn[0][:, H:].t().contiguous()
+            WT0e_e = We[0][:, :H].t().contiguous()
+            Wcat = torch.cat([Wn[0][:, :H].t(), We[0][:, H:2 * H].t(), We[0][:, 2 * H:].t()], dim=1).contiguous()
+            # node MLP chain: dX' -> dZn[3..0], dAgg = W0n[:,H:]^T dZn0
+            mlp_bwd(N, H, 4, dx, None, None, H, Un, Rn, sn, Hn, WTn, dZn, [(WT0n_agg, None, dAgg)],
+                    [g[10], g[12], g[14], g[16]], g[17])
+            # edge MLP chain: dM = dE' + dAgg[dst] -> dZe[3..0], dE = dE' + W0e[:, :H]^T dZe0
+            de_new = de_buf[0] if de.data_ptr() != de_buf[0].data_ptr() else de_buf[1]
+            mlp_bwd(E, H, 4, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
+                    [g[1], g[3], g[5], g[7]], g[8])
+            # scatter of the first-layer pre-activations' grads onto dst / src nodes
+            segsum(dZe[0], topo.rowptr_dst, None, Sd)
+            segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)
+            # dX = dX' + W0n[:, :H]^T dZn0 + W0e[:, H:2H]^T Sd + W0e[:, 2H:]^T Ss
+            dx_new = dx_buf[0] if dx.data_ptr() != dx_buf[0].data_ptr() else dx_buf[1]
+            mlp_fwd(N, H, [(dZn[0], None, H), (Sd, None, H), (Ss, None, H)], [Wcat], [None], None, H, dx, dx_new)
+            # weight gradients: dW = dZ^T X
+            jobs = [
+                (dZn[0], H, nb, x, H, nb, H, g[9], 0, 2 * H),
+                (dZn[0], H, nb, agg, H, nb, H, g[9], H, 2 * H),
+                (dZe[0], H, nb, e, H, nb, H, g[0], 0, 3 * H),
+                (Sd, H, nb, x, H, nb, H, g[0], H, 3 * H),
+                (Ss, H, nb, x, H, nb, H, g[0], 2 * H, 3 * H),
+            ]
+            for l in (1, 2, 3):
+                jobs.append((dZn[l], H, nb, Hn[l - 1], H, nb, H, g[9 + 2 * l], 0, H))
+                jobs.append((dZe[l], H, nb, He[l - 1], H, nb, H, g[2 * l], 0, H))
+            wgrad(jobs, dev)
+            grads[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)] = g
+            dx, de = dx_new, de_new
+        ctx.saved_acts = None
+        return (dx, de, None, None, *grads)

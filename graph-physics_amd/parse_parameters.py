@@ -1,0 +1,66 @@
+"""JSON ``training_config`` surface for the MeshGraphNet path: same keys as the
+reference factories (graphphysics/training/parse_parameters.py:81-190)."""
+from __future__ import annotations
+
+from typing import Any, Dict
+
+import torch
+
+from .layers import set_use_silu_activation
+from .nodetype import NodeType
+from .processors import EncodeProcessDecode
+from .simulator import Simulator
+
+
+def get_model(param: Dict[str, Any], only_processor: bool = False):
+    model = param.get("model", {})
+    model_type = model.get("type", "")
+    node_input_size = param["model"]["node_input_size"] + NodeType.SIZE  # parse_parameters.py:96
+    training = param.get("training", {})
+    set_use_silu_activation(model.get("use_silu_activation", False))
+    if model_type == "epd":
+        return EncodeProcessDecode(
+            message_passing_num=param["model"]["message_passing_num"],
+            node_input_size=node_input_size,
+            edge_input_size=param["model"]["edge_input_size"],
+            output_size=param["model"]["output_size"],
+            hidden_size=param["model"]["hidden_size"],
+            only_processor=only_processor,
+            use_rope_embeddings=model.get("use_rope_embeddings", False),
+            use_gated_attention=model.get("use_gated_attention", False),
+            use_gated_mlp=model.get("use_gated_mlp", False),
+            rope_pos_dimension=model.get("rope_pos_dimension", 3),
+            rope_base=model.get("rope_base", 10000.0),
+            use_temporal_block=training.get("use_temporal_block", False),
+        )
+    if model_type in ("transformer", "transolver"):
+        raise NotImplementedError(f"model type '{model_type}' is outside the MeshGraphNet hot path (SURVEY.md N4)")
+    raise ValueError(f"Model type '{model_type}' not supported.")
+
+
+def get_simulator(param: Dict[str, Any], model, device: torch.device) -> Simulator:
+    return Simulator(
+        node_input_size=param["model"]["node_input_size"] + NodeType.SIZE,
+        edge_input_size=param["model"]["edge_input_size"],
+        output_size=param["model"]["output_size"],
+        feature_index_start=param["index"]["feature_index_start"],
+        feature_index_end=param["index"]["feature_index_end"],
+        output_index_start=param["index"]["output_index_start"],
+        output_index_end=param["index"]["output_index_end"],
+        node_type_index=param["index"]["node_type_index"],
+        model=model,
+        device=device,
+    )
+
+
+def cylinder_config(message_passing_num: int = 15, hidden_size: int = 128) -> Dict[str, Any]:
+    """training_config/cylinder.json with the two benchmark overrides
+    (message_passing_num 5->15, hidden_size 32->128; SURVEY.md TL;DR item 1)."""
+    return {
+        "model": {"type": "epd", "message_passing_num": message_passing_num, "hidden_size": hidden_size,
+                  "node_input_size": 2, "output_size": 2, "edge_input_size": 3,
+                  "use_silu_activation": False, "use_gated_mlp": False},
+        "index": {"feature_index_start": 0, "feature_index_end": 2, "output_index_start": 0,
+                  "output_index_end": 2, "node_type_index": 2},
+        "training": {"use_spatial_mtp": False, "use_temporal_block": False, "enable_vram_optimizations": False},
+    }

@@ -1,0 +1,65 @@
+"""``EncodeProcessDecode`` with the reference's constructor signature, attributes
+and ``state_dict`` keys (graphphysics/models/processors.py:57-215), running on the
+HIP engine: encoders / decoder are fused 4-layer MLP kernels, the processor loop is
+one autograd node (``ops.ProcessorFunction``) that keeps edge latents in the
+dst-sorted order for all rounds."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import GraphNetBlock, _block_params, build_mlp
+
+
+class EncodeProcessDecode(nn.Module):
+    def __init__(self, message_passing_num: int, node_input_size: int, edge_input_size: int, output_size: int,
+                 hidden_size: int = 128, only_processor: bool = False, use_rope_embeddings: bool = False,
+                 use_gated_attention: bool = False, use_gated_mlp: bool = False, rope_pos_dimension: int = 3,
+                 rope_base: float = 10000.0, use_temporal_block: bool = False):
+        super().__init__()
+        self.only_processor = only_processor
+        self.hidden_size = hidden_size
+        self.d = output_size
+        self.use_temporal_block = use_temporal_block
+        self.use_gated_mlp = use_gated_mlp
+        self.use_rope = use_rope_embeddings
+        self.use_gate = use_gated_attention
+        self.rope_axes = rope_pos_dimension
+        self.rope_base = rope_base
+        if self.use_rope and self.rope_axes not in (2, 3):
+            raise ValueError("rope_pos_dimension must be 2 or 3 when use_rope_embeddings=True.")
+        if use_temporal_block:
+            raise NotImplementedError("TemporalAttention tail is a 'next' row (SURVEY.md N3)")
+        self.temporal_block = None
+        if not self.only_processor:
+            self.nodes_encoder = build_mlp(node_input_size, hidden_size, hidden_size)
+            self.edges_encoder = build_mlp(edge_input_size, hidden_size, hidden_size)
+            self.decode_module = build_mlp(hidden_size, hidden_size, output_size, layer_norm=False)
+        self.processor_list = nn.ModuleList(
+            [GraphNetBlock(hidden_size=hidden_size, use_gated_mlp=use_gated_mlp, use_rope=use_rope_embeddings,
+                           rope_axes=rope_pos_dimension, rope_base=rope_base, use_gate=use_gated_attention)
+             for _ in range(message_passing_num)])
+
+    def forward(self, graph) -> torch.Tensor:
+        edge_index = graph.edge_index
+        if self.use_rope and getattr(graph, "pos", None) is None:
+            raise ValueError("Graph data must contain `pos` when use_rope_embeddings=True.")
+        n = graph.x.shape[0]
+        topo = getattr(graph, "mgn_topology", None)
+        if topo is None:
+            topo = ops.get_topology(edge_index, n)
+        perm = topo.perm_dst.long()
+        if self.only_processor:
+            x, e = graph.x, graph.edge_attr[perm]
+        else:
+            x = self.nodes_encoder(graph.x)
+            # encode edges directly in the engine's dst-sorted order (F_e floats per edge to permute)
+            e = self.edges_encoder(graph.edge_attr[perm])
+        params = []
+        for block in self.processor_list:
+            params += _block_params(block)
+        x, _ = ops.ProcessorFunction.apply(x, e, topo, len(self.processor_list), *params)
+        if self.only_processor:
+            return x
+        return self.decode_module(x)

@@ -1,0 +1,143 @@
+/*
+ * mgn_hip.h -- C ABI of the MI355X (gfx950) MeshGraphNet message-passing engine.
+ *
+ * Every entry point takes raw DEVICE pointers, plain sizes and a hipStream_t
+ * (passed as void*), returns 0 on success / non-zero on error (never throws
+ * across the boundary; mgn_last_error() gives the text), allocates nothing and
+ * keeps no state: the caller owns outputs and workspaces.  All launches are
+ * asynchronous on `stream` except mgn_csr_build (one-time topology prep, which
+ * synchronises the stream to report malformed indices).
+ *
+ * All matrices are row-major fp32.  H (latent width) must be 16, 32, 64 or 128.
+ * "T-layout" / "N-layout" in the comments are register layouts, see DESIGN.md.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   mgn_mlp_fwd        build_mlp(...) forward incl. RMSNorm
+ *                        graphphysics/models/layers.py:163-210, :104-129
+ *                      fused with the gathers/concats/residuals of
+ *                        GraphNetBlock.forward / edge_update / update
+ *                        graphphysics/models/layers.py:1015-1028,1039-1040,1044-1060,1074-1102
+ *   mgn_segsum         MessagePassing.propagate(aggr="add") -> scatter-add
+ *                        graphphysics/models/layers.py:926,1031-1037
+ *                        (torch-geometric==2.6.1, requirements.txt:7)
+ *   mgn_mlp_bwd        autograd backward of the above (activation/norm/dgrad chain)
+ *   mgn_wgrad          autograd backward of nn.Linear wrt weight (dW = dZ^T X)
+ *   mgn_csr_build      the dst-sorted edge order that replaces PyG's index-based
+ *                        scatter (no reference counterpart: layout prep)
+ */
+#ifndef MGN_HIP_H
+#define MGN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGN_MAX_LAYERS 8   /* Linear layers per MLP (reference uses 4) */
+#define MGN_MAX_PHASES 3   /* concatenated input blocks of the first layer */
+#define MGN_MAX_WGRAD_JOBS 12
+
+/* ABI version: major*10000 + minor*100 + patch. */
+int mgn_version(void);
+/* Text of the last error on this thread ("" if none). */
+const char* mgn_last_error(void);
+
+/* ------------------------------------------------------------------ CSR build
+ * Stable counting sort of edge ids by key[e] in [0,N).
+ *   rowptr[N+1] : segment offsets;  perm[E] : edge ids grouped by key, ascending
+ *   inside a segment (the order CPU index_add_ sums in).
+ * ws: at least mgn_csr_workspace_bytes(E,N) bytes of device scratch.
+ * Returns 3 if any key is outside [0,N). Synchronises `stream`. */
+size_t mgn_csr_workspace_bytes(int64_t E, int64_t N);
+int mgn_csr_build(const int64_t* key, int64_t E, int64_t N, int32_t* rowptr, int32_t* perm,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- segment sum
+ * out[i,:] = sum_{k=rowptr[i]}^{rowptr[i+1]-1} src[perm ? perm[k] : k, :]
+ * summed sequentially in k order (deterministic, atomics-free).  H in {16,32,64,128}. */
+int mgn_segsum(const float* src, const int32_t* rowptr, const int32_t* perm, float* out,
+               int64_t N, int H, void* stream);
+
+/* ------------------------------------------------------------ fused MLP forward
+ * For each row m in [0,M):
+ *   in  = cat_p src[p][ idx[p] ? idx[p][m] : m , 0:kw[p] ]      (p < nphase)
+ *   z   = W[NL-1] act(... act(W[0] in + b[0]) ...) + b[NL-1]     (act = ReLU)
+ *   y   = scale ? scale * z / (||z||_2/sqrt(H) + eps) : z        (RMSNorm, layers.py:104-129)
+ *   out = (resid ? resid[m] : 0) + y ;   y_out = y (optional)
+ * W[0] is [Hout, ktot] with ktot = sum_p pad16(kw[p]) and phase p occupying columns
+ * [sum_{q<p} pad16(kw[q]), +kw[p]) (zero padded); W[l>0] is [Hout, H].  The last
+ * layer's W/b are padded to pad16(out_w) rows.  All weight pointers 16-byte aligned.
+ * Optional saves for backward: saveH[l] = activation feeding layer l+1 ([M,H]),
+ * saveU = z / (rms+eps) ([M,H]), saveR = rms ([M]).  Any of them may be NULL.
+ */
+typedef struct {
+  int64_t M;
+  int H, NL, nphase;
+  const float* src[MGN_MAX_PHASES];
+  const int32_t* idx[MGN_MAX_PHASES];
+  int kw[MGN_MAX_PHASES];
+  const float* W[MGN_MAX_LAYERS];
+  const float* b[MGN_MAX_LAYERS];   /* NULL = no bias */
+  const float* scale;               /* NULL = no RMSNorm */
+  float eps;
+  int out_w;                        /* width of the last layer (== H when scale != NULL) */
+  const float* resid;               /* [M,out_w] or NULL */
+  float* out;                       /* [M,out_w] */
+  float* y_out;                     /* [M,out_w] or NULL */
+  float* saveH[MGN_MAX_LAYERS];
+  float* saveU;
+  float* saveR;
+} mgn_mlp_fwd_args;
+int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream);
+
+/* ----------------------------------------------------- fused MLP backward chain
+ * Given dY = dOut[m] (+ dOut2[idx2[m]]) = gradient wrt y above, computes
+ *   dZ[NL-1] (through the RMSNorm), dZ[l-1] = (WT[l] dZ[l]) * (H_l > 0)   (l = NL-1..1)
+ *   dIn[q]   = (din_resid[q] ? din_resid[q] : 0) + WT0[q] dZ[0]          (q < n_din)
+ * and the column sums db[l] = sum_m dZ[l][m,:], dscale = sum_m dY*U.
+ * WT[l] = W[l]^T, [H, pad16(out width of layer l)] row-major (l >= 1; WT[0] unused);
+ * WT0[q] = (column slab q of W[0])^T, [H(in), H(out)] row-major.
+ * dZ[l] are [M, pad16(width)] outputs that feed mgn_wgrad.
+ * red_ws: device scratch of mgn_mlp_bwd_workspace_bytes(M,H,NL) bytes.
+ */
+typedef struct {
+  int64_t M;
+  int H, NL;
+  const float* dOut;                /* [M,out_w] */
+  const float* dOut2;               /* [*,H] gathered by idx2, or NULL */
+  const int32_t* idx2;
+  int out_w;
+  const float* U; const float* R; const float* scale; float eps;   /* scale NULL = no norm */
+  const float* Hs[MGN_MAX_LAYERS];  /* Hs[l-1] = saved input of layer l (l>=1) */
+  const float* WT[MGN_MAX_LAYERS];
+  float* dZ[MGN_MAX_LAYERS];
+  int n_din;
+  const float* WT0[MGN_MAX_PHASES];
+  const float* din_resid[MGN_MAX_PHASES];
+  float* dIn[MGN_MAX_PHASES];
+  float* db[MGN_MAX_LAYERS];        /* [pad16(width)] or NULL */
+  float* dscale;                    /* [H] or NULL */
+  void* red_ws; size_t red_ws_bytes;
+} mgn_mlp_bwd_args;
+size_t mgn_mlp_bwd_workspace_bytes(int64_t M, int H, int NL);
+int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream);
+
+/* ------------------------------------------------------------------ weight grads
+ * For each job: dW[j, k] = sum_m A[m, j] * B[m, k],  j < 16*nja, k < 16*nkb
+ * (B columns >= kw read as zero).  A is [M,lda], B is [M,ldb], dW is [16*nja, ldw].
+ * ws: device scratch of mgn_wgrad_workspace_bytes(njobs, jobs) bytes. */
+typedef struct {
+  const float* A; const float* B; float* dW;
+  int64_t M;
+  int lda, ldb, ldw;
+  int nja, nkb, kw;
+} mgn_wgrad_job;
+size_t mgn_wgrad_workspace_bytes(int njobs, const mgn_wgrad_job* jobs);
+int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGN_HIP_H */

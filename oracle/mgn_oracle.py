@@ -1,0 +1,295 @@
+"""CPU oracle for the MeshGraphNet message-passing path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain ``torch`` CPU ops (no PyG, no Lightning), the
+algorithm of the reference's hot path so that the HIP engine can be checked
+against it anywhere (the reference source never travels to the GPU box).
+
+Who may import this: ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` -- as the checker / timed baseline only.
+The product package (``graph-physics_amd/``) must never import it.
+
+Parity status: the reference's own tests hold NO numeric golden vectors for
+this path (shape / "grad exists" assertions only), so the
+oracle is pinned against outputs of the reference itself, imported in the build
+container by ``tests/golden/make_golden.py`` (PyG's ``MessagePassing.propagate``
+-- un-vendored ``torch-geometric==2.6.1``, ``requirements.txt:7`` -- restated
+there as ``zeros(N,H).index_add_(0, edge_index[1], msg)``).  The committed
+fixtures under ``tests/golden/*.npz`` carry the reference's outputs; the test
+``tests/test_oracle_golden.py`` checks this file against them bit-for-bit.
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+NODE_TYPE_SIZE = 9  # graphphysics/utils/nodetype.py:12  (NodeType.SIZE)
+NODE_NORMAL = 0  # nodetype.py:5
+NODE_OUTFLOW = 5  # nodetype.py:10
+
+
+# --------------------------------------------------------------------------- R1
+def rms_norm(x: torch.Tensor, scale: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """graphphysics/models/layers.py:104-129 (default p=-1, no bias).
+
+    y = scale * x / (||x||_2 / sqrt(d) + eps)  -- eps is added to the RMS, not
+    inside the square root.
+    """
+    d = x.shape[-1]
+    norm_x = x.norm(2, dim=-1, keepdim=True)  # layers.py:116
+    rms_x = norm_x / math.sqrt(d)  # layers.py:123
+    x_normed = x / (rms_x + eps)  # layers.py:124
+    return scale * x_normed  # layers.py:129
+
+
+# --------------------------------------------------------------------------- R2
+def mlp(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str, act: str = "relu") -> torch.Tensor:
+    """build_mlp(nb_of_layers=4) forward, graphphysics/models/layers.py:163-210.
+
+    Sequential entries 0,2,4,6 are nn.Linear (y = x W^T + b, W[out,in]); 1,3,5
+    are the activation (ReLU unless the global SiLU flag is set,
+    layers.py:150-160); entry 7 is RMSNorm when present (``layer_norm=True``).
+    ``p`` is a state_dict; ``prefix`` e.g. "processor_list.0.edge_block.".
+    """
+    f = torch.relu if act == "relu" else torch.nn.functional.silu
+    h = x
+    for i in (0, 2, 4, 6):
+        h = torch.nn.functional.linear(h, p[f"{prefix}{i}.weight"], p[f"{prefix}{i}.bias"])
+        if i != 6:
+            h = f(h)
+    key = f"{prefix}7.scale"
+    if key in p:
+        h = rms_norm(h, p[key])
+    return h
+
+
+# ------------------------------------------------------------------- R3, R4, R5
+def graph_net_block(
+    x: torch.Tensor,
+    e: torch.Tensor,
+    edge_index: torch.Tensor,
+    p: Dict[str, torch.Tensor],
+    prefix: str,
+    act: str = "relu",
+    return_intermediates: bool = False,
+):
+    """GraphNetBlock.forward, graphphysics/models/layers.py:989-1042.
+
+    row, col = edge_index; x_i = x[col] (target), x_j = x[row] (source)
+    (layers.py:1016-1018).  Message m = edge_block(cat[e, x_i, x_j])
+    (layers.py:1058-1059).  Aggregation is PyG ``aggr="add"``,
+    ``flow="source_to_target"`` (layers.py:926): agg[i] = sum_{k: col[k]=i} m[k],
+    summed in edge-id order on CPU (``index_add_``).  Node update
+    node_block(cat[x, agg]) (layers.py:1100-1101); residuals layers.py:1039-1040
+    -- note the aggregated message is the PRE-residual MLP output.
+    """
+    row, col = edge_index[0], edge_index[1]
+    x_i = x[col]
+    x_j = x[row]
+    m = mlp(torch.cat([e, x_i, x_j], dim=-1), p, prefix + "edge_block.", act)
+    agg = torch.zeros(x.shape[0], m.shape[1], dtype=m.dtype).index_add_(0, col, m)
+    upd = mlp(torch.cat([x, agg], dim=-1), p, prefix + "node_block.", act)
+    e_new = e + m
+    x_new = x + upd
+    if return_intermediates:
+        return x_new, e_new, {"m": m, "agg": agg, "upd": upd}
+    return x_new, e_new
+
+
+# --------------------------------------------------------------------------- R6
+def epd_forward(
+    x_in: torch.Tensor,
+    edge_attr_in: torch.Tensor,
+    edge_index: torch.Tensor,
+    p: Dict[str, torch.Tensor],
+    message_passing_num: int,
+    only_processor: bool = False,
+    act: str = "relu",
+    per_round: Optional[List[torch.Tensor]] = None,
+) -> torch.Tensor:
+    """EncodeProcessDecode.forward, graphphysics/models/processors.py:162-215
+    (rope / gate / temporal block off -- the defaults of every shipped JSON)."""
+    if only_processor:
+        x, e = x_in, edge_attr_in  # processors.py:176-177
+    else:
+        x = mlp(x_in, p, "nodes_encoder.", act)  # processors.py:179
+        e = mlp(edge_attr_in, p, "edges_encoder.", act)  # processors.py:180
+    for i in range(message_passing_num):  # processors.py:193-202
+        x, e = graph_net_block(x, e, edge_index, p, f"processor_list.{i}.", act)
+        if per_round is not None:
+            per_round.append(x)
+    if only_processor:
+        return x  # processors.py:211-212
+    return mlp(x, p, "decode_module.", act)  # processors.py:214 (no RMSNorm: :141-146)
+
+
+# --------------------------------------------------------------------------- R7
+class NormalizerState:
+    """Running-sum normaliser, graphphysics/models/layers.py:281-391."""
+
+    def __init__(self, size: int, max_accumulations: float = 10**5, std_epsilon: float = 1e-8):
+        self.max_accumulations = max_accumulations  # layers.py:311
+        self.std_epsilon = torch.tensor(std_epsilon, dtype=torch.float32)  # layers.py:312
+        self.acc_count = torch.tensor(0.0)  # layers.py:315
+        self.num_accumulations = torch.tensor(0.0)  # layers.py:316
+        self.acc_sum = torch.zeros(1, size)  # layers.py:317
+        self.acc_sum_squared = torch.zeros(1, size)  # layers.py:323
+
+    def mean(self):  # layers.py:378-382
+        return self.acc_sum / torch.max(self.acc_count, torch.tensor(1.0))
+
+    def std(self):  # layers.py:384-391
+        safe = torch.max(self.acc_count, torch.tensor(1.0))
+        var = self.acc_sum_squared / safe - self.mean() ** 2
+        return torch.max(torch.sqrt(torch.clamp(var, min=0.0)), self.std_epsilon)
+
+    def __call__(self, data: torch.Tensor, accumulate: bool = True) -> torch.Tensor:  # layers.py:331-349
+        if accumulate and self.num_accumulations < self.max_accumulations:
+            d = data.detach()  # layers.py:363-376
+            self.acc_sum += d.sum(dim=0, keepdim=True)
+            self.acc_sum_squared += (d**2).sum(dim=0, keepdim=True)
+            self.acc_count += d.shape[0]
+            self.num_accumulations += 1
+        return (data - self.mean()) / self.std()
+
+    def inverse(self, data: torch.Tensor) -> torch.Tensor:  # layers.py:351-361
+        return data * self.std() + self.mean()
+
+    def load(self, sd: Dict[str, torch.Tensor], prefix: str):
+        self.acc_count = sd[prefix + "_acc_count"].clone()
+        self.num_accumulations = sd[prefix + "_num_accumulations"].clone()
+        self.acc_sum = sd[prefix + "_acc_sum"].clone()
+        self.acc_sum_squared = sd[prefix + "_acc_sum_squared"].clone()
+
+
+class SimulatorOracle:
+    """Simulator.forward, graphphysics/models/simulator.py:145-217."""
+
+    def __init__(self, index: Dict[str, int], node_input_size: int, edge_input_size: int, output_size: int):
+        self.ix = index
+        self.out_norm = NormalizerState(output_size)  # simulator.py:65-67
+        self.node_norm = NormalizerState(node_input_size)  # simulator.py:68-70
+        self.edge_norm = NormalizerState(edge_input_size) if edge_input_size > 0 else None  # :71-75
+
+    def build_input(self, x, y, edge_attr, training: bool):
+        ix = self.ix
+        pre_target = x[:, ix["output_index_start"] : ix["output_index_end"]]  # simulator.py:91
+        target = None
+        if y is not None:
+            target = self.out_norm(y - pre_target, training)  # simulator.py:106-110
+        node_type = x[:, ix["node_type_index"]]
+        one_hot = torch.nn.functional.one_hot(torch.squeeze(node_type.long()), NODE_TYPE_SIZE)  # :122-125
+        feats = x[:, ix["feature_index_start"] : ix["feature_index_end"]]
+        node_features = torch.cat([feats, one_hot], dim=1)  # simulator.py:139-140
+        xn = self.node_norm(node_features, training)  # simulator.py:162
+        en = self.edge_norm(edge_attr, training) if self.edge_norm is not None else edge_attr  # :164-167
+        return xn, en, target
+
+    def build_outputs(self, x, net_out):  # simulator.py:178-191
+        ix = self.ix
+        return x[:, ix["output_index_start"] : ix["output_index_end"]] + self.out_norm.inverse(net_out)
+
+
+# --------------------------------------------------------------------------- R8
+def l2_loss(net_out: torch.Tensor, target: torch.Tensor, node_type: torch.Tensor,
+            masks: Sequence[int] = (NODE_NORMAL, NODE_OUTFLOW)) -> torch.Tensor:
+    """L2Loss.forward, graphphysics/utils/loss.py:37-75 with the default masks of
+    lightning_module.py:48: mean over the selected ROWS' elements."""
+    mask = torch.zeros_like(node_type, dtype=torch.bool)
+    for t in masks:
+        mask |= node_type == t
+    return torch.mean(((net_out - target) ** 2)[mask])
+
+
+def lr_factor(step: int, warmup: int, max_iters: int, min_lr_factor: float = 0.001) -> float:
+    """CosineWarmupScheduler.get_lr_factor, graphphysics/utils/scheduler.py:51-67.
+    ``step`` is last_epoch (starts at 0 after construction)."""
+    epoch = step + 1
+    f = 0.5 * (1 + math.cos(math.pi * epoch / max_iters))
+    if epoch <= warmup:
+        f *= epoch * 1.0 / warmup
+    return max(f, min_lr_factor)
+
+
+def train_steps(
+    params: Dict[str, torch.Tensor],
+    sim: SimulatorOracle,
+    batches: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]],
+    message_passing_num: int,
+    lr: float,
+    warmup: int,
+    num_steps: int,
+):
+    """Reference training semantics: LightningModule.training_step
+    (training/lightning_module.py:270-320) + configure_optimizers (:494-511) +
+    Trainer(gradient_clip_val=1.0) (train.py:288).
+
+    ``params`` are leaf tensors (requires_grad) updated in place.  Returns the
+    list of (loss, grad_norm_before_clip) per step.
+    """
+    names = list(params.keys())
+    leaves = [params[k] for k in names]
+    opt = torch.optim.AdamW(leaves, lr=lr, weight_decay=0.0001, betas=(0.9, 0.95))
+    log = []
+    for step, (x, y, edge_attr, edge_index) in enumerate(batches):
+        for g in opt.param_groups:  # LR for THIS step = base_lr * factor(last_epoch=step)
+            g["lr"] = lr * lr_factor(step, warmup, num_steps)
+        xn, en, target = sim.build_input(x, y, edge_attr, training=True)
+        out = epd_forward(xn, en, edge_index, params, message_passing_num)
+        loss = l2_loss(out, target, x[:, sim.ix["node_type_index"]])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(leaves, 1.0)
+        opt.step()
+        log.append((float(loss.detach()), float(gn)))
+    return log
+
+
+# --------------------------------------------------------------------------- R9
+def rollout(
+    params: Dict[str, torch.Tensor],
+    sim: SimulatorOracle,
+    frames_x: Sequence[torch.Tensor],
+    frames_y: Sequence[torch.Tensor],
+    edge_attr: torch.Tensor,
+    edge_index: torch.Tensor,
+    message_passing_num: int,
+) -> List[torch.Tensor]:
+    """Autoregressive rollout, LightningModule._make_prediction
+    (training/lightning_module.py:375-409) with build_mask (:27-35): nodes that
+    are NOT NORMAL/OUTFLOW get the ground truth re-imposed."""
+    ix = sim.ix
+    last = None
+    preds = []
+    with torch.no_grad():
+        for x, y in zip(frames_x, frames_y):
+            x = x.clone()
+            if last is not None:
+                x[:, ix["output_index_start"] : ix["output_index_end"]] = last  # :379-382
+            node_type = x[:, ix["node_type_index"]]
+            mask = ~((node_type == NODE_NORMAL) | (node_type == NODE_OUTFLOW))  # :27-35
+            xn, en, _ = sim.build_input(x, y, edge_attr, training=False)
+            net = epd_forward(xn, en, edge_index, params, message_passing_num)
+            pred = sim.build_outputs(x, net)  # simulator.py:213-217
+            pred[mask] = y[mask]  # lightning_module.py:398
+            last = pred
+            preds.append(pred.clone())
+    return preds
+
+
+# ------------------------------------------------------------- CSR (integer work)
+def csr_by_key(key: torch.Tensor, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stable sort of edge ids by ``key`` (dst for aggregation).  Returns
+    (rowptr[n+1] int32, perm[E] int32) with perm ascending in edge id inside each
+    segment -- the order CPU ``index_add_`` sums in (layers.py:1031 via PyG
+    scatter).  Bit-exact target for ``mgn_csr_build``."""
+    key = key.to(torch.int64)
+    perm = torch.argsort(key, stable=True)
+    counts = torch.bincount(key, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    return rowptr.to(torch.int32), perm.to(torch.int32)

@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Mint golden vectors from the REFERENCE implementation (build container only).
+
+Run:  python tests/golden/make_golden.py            (needs /root/reference)
+
+The reference (graphphysics/models/{layers,processors,simulator}.py,
+utils/{loss,scheduler}.py) is imported unmodified from /root/reference.  Its two
+missing third-party imports are satisfied by throw-away stand-ins written to a
+temp dir (never committed):
+  * loguru          -> no-op logger;
+  * torch_geometric -> ``Data`` attribute bag, and ``MessagePassing`` whose
+    ``propagate`` restates PyG 2.6.1's aggr="add", flow="source_to_target":
+    message(**kw) -> zeros(N,H).index_add_(0, edge_index[1], msg) -> update(...)
+    (torch-geometric==2.6.1 is pinned in the reference's requirements.txt:7 and is
+    not installed in this image).
+Only plain arrays leave this script: inputs come from tests/golden/recipe.py,
+outputs are written to tests/golden/*.npz.  While minting, every oracle function
+is checked bit-for-bit against the reference output it restates.
+"""
+import os
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+
+def install_standins():
+    d = tempfile.mkdtemp(prefix="gp_standins_")
+    os.makedirs(os.path.join(d, "loguru"))
+    with open(os.path.join(d, "loguru", "__init__.py"), "w") as f:
+        f.write(textwrap.dedent("""
+            class _L:
+                def __getattr__(self, n):
+                    return lambda *a, **k: None
+            logger = _L()
+        """))
+    for sub in ("", "nn", "data"):
+        os.makedirs(os.path.join(d, "torch_geometric", sub), exist_ok=True)
+    with open(os.path.join(d, "torch_geometric", "__init__.py"), "w") as f:
+        f.write("")
+    with open(os.path.join(d, "torch_geometric", "data", "__init__.py"), "w") as f:
+        f.write(textwrap.dedent("""
+            class Data:
+                def __init__(self, **kw):
+                    for k, v in kw.items():
+                        setattr(self, k, v)
+                def __getattr__(self, n):
+                    if n.startswith("__"):
+                        raise AttributeError(n)
+                    return None
+            Batch = Data
+        """))
+    with open(os.path.join(d, "torch_geometric", "nn", "__init__.py"), "w") as f:
+        f.write(textwrap.dedent("""
+            import torch
+            class MessagePassing(torch.nn.Module):
+                def __init__(self, aggr="add", flow="source_to_target"):
+                    super().__init__()
+                    assert aggr == "add" and flow == "source_to_target"
+                def propagate(self, edge_index, size=None, **kw):
+                    import inspect
+                    mk = {k: kw[k] for k in inspect.signature(self.message).parameters if k in kw}
+                    msg = self.message(**mk)
+                    n = size[1]
+                    agg = torch.zeros(n, msg.shape[1], dtype=msg.dtype).index_add_(0, edge_index[1], msg)
+                    uk = {k: kw[k] for k in inspect.signature(self.update).parameters if k in kw}
+                    return self.update(agg, **uk)
+            class TransformerConv(torch.nn.Module):
+                pass
+        """))
+    sys.path.insert(0, d)
+    sys.path.insert(1, REF)
+    os.environ["GRAPH_PHYSICS_ASSUME_NO_DGL"] = "1"
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference checkout not present: goldens can only be minted in the build container")
+    install_standins()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    from graphphysics.models.layers import GraphNetBlock as RefBlock  # noqa: E402
+    from graphphysics.models.processors import EncodeProcessDecode as RefEPD  # noqa: E402
+    from graphphysics.models.simulator import Simulator as RefSim  # noqa: E402
+    from graphphysics.utils.loss import L2Loss as RefL2  # noqa: E402
+    from graphphysics.utils.nodetype import NodeType as RefNT  # noqa: E402
+    from graphphysics.utils.scheduler import CosineWarmupScheduler as RefSched  # noqa: E402
+    from torch_geometric.data import Data  # stand-in
+
+    import recipe as R
+    from oracle import mgn_oracle as O
+
+    def save(name, **arrs):
+        out = {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"wrote {name}.npz  ({os.path.getsize(path) / 1024:.0f} kB)")
+
+    def exact(a, b, what):
+        d = (a - b).abs().max().item() if a.numel() else 0.0
+        assert d == 0.0, f"oracle is not bit-exact vs reference for {what}: max|diff|={d}"
+
+    # ------------------------------------------------------------------ (i) one block
+    for tag, H, N, seed in (("block_h128", 128, 24, 11), ("block_h16", 16, 12, 12)):
+        pos, ei, _ = R.delaunay_graph(N, seed)
+        E = ei.shape[1]
+        shapes = R.epd_param_shapes(1, H, 1, 1, 1, only_processor=True)
+        params = R.make_params(shapes, seed)
+        blk = RefBlock(hidden_size=H)
+        blk.load_state_dict({k[len("processor_list.0."):]: v for k, v in params.items()})
+        x = R.randn((N, H), seed + 1).requires_grad_(True)
+        e = R.randn((E, H), seed + 2).requires_grad_(True)
+        cx, ce = R.randn((N, H), seed + 3), R.randn((E, H), seed + 4)
+        x2, e2 = blk(x, ei, e)
+        loss = (x2 * cx).sum() + (e2 * ce).sum()
+        loss.backward()
+        # oracle check (forward + intermediates)
+        ox, oe, inter = O.graph_net_block(x.detach(), e.detach(), ei, params, "processor_list.0.", return_intermediates=True)
+        exact(ox, x2.detach(), tag + " x'")
+        exact(oe, e2.detach(), tag + " e'")
+        g = {("g_" + k): p.grad for k, p in blk.state_dict(keep_vars=True).items()}
+        small = {}
+        for k, v in g.items():
+            if v.dim() == 2:  # weights: keep 8 rows + norm (fixture size)
+                small[k + "__rows8"] = v[:8]
+                small[k + "__norm"] = v.norm()
+            else:
+                small[k] = v
+        save(tag, edge_index=ei, x_out=x2, e_out=e2, m=inter["m"], agg=inter["agg"], dx=x.grad, de=e.grad, **small)
+
+    # ----------------------------------------------------------- (ii) EPD L=2 / L=15
+    for tag, L, N, seed in (("epd_l2", 2, 256, 21), ("epd_l15", 15, 256, 22)):
+        H, F_n, F_e, Oo = 128, 11, 3, 2
+        pos, ei, ea = R.delaunay_graph(N, seed)
+        params = R.make_params(R.epd_param_shapes(L, H, F_n, F_e, Oo), seed)
+        net = RefEPD(message_passing_num=L, node_input_size=F_n, edge_input_size=F_e, output_size=Oo, hidden_size=H)
+        net.load_state_dict(params)
+        x_in = R.randn((N, F_n), seed + 1)
+        e_in = R.randn((ea.shape[0], F_e), seed + 2)
+        cot = R.randn((N, Oo), seed + 3)
+        out = net(Data(x=x_in, edge_attr=e_in, edge_index=ei))
+        (out * cot).sum().backward()
+        per = []
+        oo = O.epd_forward(x_in, e_in, ei, params, L, per_round=per)
+        exact(oo, out.detach(), tag + " output")
+        gn = {("gnorm_" + k): p.grad.norm() for k, p in net.state_dict(keep_vars=True).items()}
+        gb = {("g_" + k): p.grad for k, p in net.state_dict(keep_vars=True).items() if p.dim() == 1 and ("processor_list.0." in k or "encoder" in k or "decode" in k)}
+        save(tag, edge_index=ei, out=out, x_round_norm=torch.stack([p.norm() for p in per]),
+             x_round_row0=torch.stack([p[0] for p in per]), **gn, **gb)
+
+    # ------------------------------------------------------------- (v) edge cases
+    H, L, N, E, seed = 128, 3, 40, 150, 31
+    ei = R.random_graph(N, E, seed)
+    params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), seed)
+    net = RefEPD(message_passing_num=L, node_input_size=11, edge_input_size=3, output_size=2, hidden_size=H)
+    net.load_state_dict(params)
+    x_in, e_in = R.randn((N, 11), seed + 1), R.randn((E, 3), seed + 2)
+    out = net(Data(x=x_in, edge_attr=e_in, edge_index=ei))
+    exact(O.epd_forward(x_in, e_in, ei, params, L), out.detach(), "random-graph EPD")
+    save("epd_random_graph", edge_index=ei, out=out)
+    # only_processor=True (processors.py:176-177,211-212)
+    params = R.make_params(R.epd_param_shapes(2, H, 1, 1, 1, only_processor=True), seed + 5)
+    net = RefEPD(message_passing_num=2, node_input_size=H, edge_input_size=H, output_size=H, hidden_size=H, only_processor=True)
+    net.load_state_dict(params)
+    xh, eh = R.randn((N, H), seed + 6), R.randn((E, H), seed + 7)
+    out = net(Data(x=xh, edge_attr=eh, edge_index=ei))
+    exact(O.epd_forward(xh, eh, ei, params, 2, only_processor=True), out.detach(), "only_processor EPD")
+    save("epd_only_processor", edge_index=ei, out=out)
+
+    # ---------------------------------------------------- (iii) R8: two training steps
+    H, L, N, seed = 128, 3, 96, 41
+    lr, warmup, num_steps = 1e-3, 4, 100
+    pos, ei, ea, xs, ys = R.trajectory(N, 3, seed)
+    params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), seed)
+    net = RefEPD(message_passing_num=L, node_input_size=11, edge_input_size=3, output_size=2, hidden_size=H)
+    net.load_state_dict(params)
+    sim = RefSim(node_input_size=11, edge_input_size=3, output_size=2, model=net, device=torch.device("cpu"), **R.CYL_INDEX)
+    sim.train()
+    # LightningModule.configure_optimizers (lightning_module.py:494-511)
+    opt = torch.optim.AdamW(sim.parameters(), lr=lr, weight_decay=0.0001, betas=(0.9, 0.95))
+    sch = RefSched(opt, warmup=warmup, max_iters=num_steps)
+    loss_fn = RefL2()
+    logs = []
+    for t in range(2):
+        batch = Data(x=xs[t], y=ys[t], pos=pos, edge_attr=ea, edge_index=ei)
+        node_type = batch.x[:, sim.node_type_index]  # lightning_module.py:275
+        net_out, target, _ = sim(batch)  # :276
+        loss = loss_fn(target=target, network_output=net_out, node_type=node_type,
+                       masks=[RefNT.NORMAL, RefNT.OUTFLOW])  # :305-312, default masks :48
+        opt.zero_grad()
+        loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_(sim.parameters(), 1.0)  # Trainer(gradient_clip_val=1.0) train.py:288
+        opt.step()
+        sch.step()
+        logs.append((loss.item(), gnorm.item(), opt.param_groups[0]["lr"]))
+    sd = net.state_dict()
+    # oracle restatement of the same two steps
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    osim = O.SimulatorOracle(R.CYL_INDEX, 11, 3, 2)
+    olog = O.train_steps(op, osim, [(xs[t], ys[t], ea, ei) for t in range(2)], L, lr, warmup, num_steps)
+    # gradients are NOT bit-reproducible on CPU (the backward of x[col] is a threaded
+    # index_put_(accumulate=True)), so the training goldens carry a tolerance.
+    for (l0, g0, _), (l1, g1) in zip(logs, olog):
+        assert abs(l0 - l1) <= 1e-5 * abs(l0) and abs(g0 - g1) <= 1e-5 * abs(g0), f"oracle train step differs: {(l0, g0)} vs {(l1, g1)}"
+    for k in sd:
+        assert torch.allclose(op[k].detach(), sd[k], rtol=1e-5, atol=2e-6), "post-step weights " + k
+    save("train_2steps", edge_index=ei, loss=np.array([l[0] for l in logs]), grad_norm=np.array([l[1] for l in logs]),
+         lr_after=np.array([l[2] for l in logs]),
+         param_sum=np.array([sd[k].double().sum().item() for k in sd]),
+         param_sqsum=np.array([(sd[k].double() ** 2).sum().item() for k in sd]),
+         w_last=sd["decode_module.6.weight"], b_first=sd["nodes_encoder.0.bias"],
+         node_norm_sum=sim._node_normalizer._acc_sum, out_norm_sumsq=sim._output_normalizer._acc_sum_squared)
+
+    # ------------------------------------------------------------ (iv) R9: rollout
+    H, L, N, seed, T = 128, 3, 96, 51, 5
+    pos, ei, ea, xs, ys = R.trajectory(N, T, seed)
+    params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), seed)
+    net = RefEPD(message_passing_num=L, node_input_size=11, edge_input_size=3, output_size=2, hidden_size=H)
+    net.load_state_dict(params)
+    sim = RefSim(node_input_size=11, edge_input_size=3, output_size=2, model=net, device=torch.device("cpu"), **R.CYL_INDEX)
+    # fixed normaliser buffers: accumulate the first frame once, then freeze (eval)
+    sim.train()
+    with torch.no_grad():
+        sim._build_input_graph(Data(x=xs[0], y=ys[0], pos=pos, edge_attr=ea, edge_index=ei), True)
+    sim.eval()
+    norm_sd = {k: v.clone() for k, v in sim.state_dict().items() if "_normalizer" in k}
+    last = None
+    preds = []
+    for t in range(T):  # LightningModule._make_prediction, lightning_module.py:375-409
+        batch = Data(x=xs[t].clone(), y=ys[t], pos=pos, edge_attr=ea, edge_index=ei)
+        if last is not None:
+            batch.x[:, sim.output_index_start: sim.output_index_end] = last.detach()
+        nt = batch.x[:, 2]
+        mask = torch.logical_not(torch.logical_or(nt == RefNT.NORMAL, nt == RefNT.OUTFLOW))  # build_mask :27-35
+        with torch.no_grad():
+            _, _, pred = sim(batch)
+        pred[mask] = batch.y[mask]
+        last = pred
+        preds.append(pred.clone())
+    osim = O.SimulatorOracle(R.CYL_INDEX, 11, 3, 2)
+    osim.out_norm.load(norm_sd, "_output_normalizer.")
+    osim.node_norm.load(norm_sd, "_node_normalizer.")
+    osim.edge_norm.load(norm_sd, "_edge_normalizer.")
+    opred = O.rollout(params, osim, xs, ys, ea, ei, L)
+    for t in range(T):
+        exact(opred[t], preds[t], f"rollout step {t}")
+    save("rollout_5steps", edge_index=ei, pred1=preds[0], pred2=preds[1], pred5=preds[4],
+         **{("norm." + k): v for k, v in norm_sd.items()})
+    print("all oracle functions bit-exact vs the reference on the minted cases")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""CPU: host-side mirror of the reference interface -- constructor signatures,
+state_dict keys, error conventions, JSON factory, harness formulas -- and the rule
+that the product path fails loudly instead of falling back to the CPU."""
+import pytest
+import torch
+
+import recipe as R
+import graph_physics_amd as gp
+from graph_physics_amd import harness
+from oracle import mgn_oracle as O
+
+
+def test_state_dict_keys_match_reference_layout():
+    net = gp.EncodeProcessDecode(15, 11, 3, 2, hidden_size=128)
+    sd = net.state_dict()
+    want = R.epd_param_shapes(15, 128, 11, 3, 2)
+    assert list(sd.keys()) == list(want.keys())
+    for k, s in want.items():
+        assert tuple(sd[k].shape) == s
+    assert sum(v.numel() for v in sd.values()) == 2873730
+    assert sd["processor_list.0.edge_block.0.weight"].shape == (128, 384)
+    assert sd["processor_list.0.node_block.0.weight"].shape == (128, 256)
+    assert "decode_module.7.scale" not in sd
+    assert isinstance(net.processor_list, torch.nn.ModuleList) and net.hidden_size == 128 and net.d == 2
+    for attr in ("nodes_encoder", "edges_encoder", "decode_module"):
+        assert isinstance(getattr(net, attr), torch.nn.Module)
+    net.load_state_dict(R.make_params(want, 0))
+
+
+def test_only_processor_has_no_encoders():
+    net = gp.EncodeProcessDecode(2, 16, 16, 16, hidden_size=16, only_processor=True)
+    assert not hasattr(net, "nodes_encoder")
+    assert len(net.processor_list) == 2
+
+
+def test_error_conventions():
+    with pytest.raises(AssertionError):
+        gp.build_mlp(4, 8, 4, nb_of_layers=1)  # layers.py:188
+    with pytest.raises(ValueError):
+        gp.GraphNetBlock(16, use_rope=True, rope_axes=5)  # layers.py:965
+    with pytest.raises(ValueError):
+        gp.EncodeProcessDecode(1, 2, 2, 2, use_rope_embeddings=True, rope_pos_dimension=4)  # processors.py:113
+    with pytest.raises(ValueError, match="Model type 'foo' not supported."):
+        gp.get_model({"model": {"type": "foo", "node_input_size": 2}})  # parse_parameters.py:162
+    with pytest.raises(NotImplementedError):
+        gp.GraphNetBlock(16, use_gate=True)  # N3 row: not silently mis-computed
+
+
+def test_json_factory():
+    cfg = gp.cylinder_config()
+    net = gp.get_model(cfg)
+    assert net.nodes_encoder[0].in_features == 2 + 9  # NodeType.SIZE added, parse_parameters.py:96
+    assert len(net.processor_list) == 15 and net.hidden_size == 128
+    cfg["model"].update(message_passing_num=5, hidden_size=32)  # the shipped cylinder.json values
+    assert gp.get_model(cfg).hidden_size == 32
+
+
+def test_cpu_tensors_fail_loudly():
+    net = gp.EncodeProcessDecode(1, 11, 3, 2, hidden_size=16)
+    _, ei, ea = R.delaunay_graph(12, 0)
+    g = gp.Graph(x=torch.randn(12, 11), edge_attr=ea, edge_index=ei)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(g)
+    blk = gp.GraphNetBlock(16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        blk(torch.randn(12, 16), ei, torch.randn(ei.shape[1], 16))
+
+
+def test_product_never_imports_oracle():
+    import os
+    import re
+
+    root = os.path.dirname(gp.__path__[0]) + "/graph-physics_amd"
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+    bench = open(os.path.join(os.path.dirname(root), "bench.py")).read() if os.path.exists(os.path.join(os.path.dirname(root), "bench.py")) else ""
+    for line in bench.splitlines():
+        if re.match(r"\s*(from|import)\s+oracle", line):
+            assert "cpu_baseline" in bench
+
+
+def test_harness_formulas_match_oracle():
+    for step in (0, 1, 3, 4, 50, 99, 150):
+        assert harness.lr_factor(step, 4, 100) == O.lr_factor(step, 4, 100)
+    torch.manual_seed(0)
+    out, tgt = torch.randn(50, 2), torch.randn(50, 2)
+    nt = torch.randint(0, 7, (50,)).float()
+    assert torch.allclose(harness.l2_loss(out, tgt, nt), O.l2_loss(out, tgt, nt), rtol=1e-6)
+    m = harness.build_mask(nt)
+    assert torch.equal(m, ~((nt == 0) | (nt == 5)))
+
+
+def test_normalizer_matches_oracle_state():
+    n = gp.Normalizer(3, device="cpu")
+    o = O.NormalizerState(3)
+    torch.manual_seed(1)
+    for _ in range(3):
+        d = torch.randn(20, 3) * 2 + 1
+        assert torch.allclose(n(d, True), o(d, True), rtol=1e-6, atol=1e-7)
+    d = torch.randn(5, 3)
+    assert torch.allclose(n.inverse(n(d, False)), d, atol=1e-6)  # reference test_layers.py:92-100
+    assert set(n.state_dict().keys()) == {"_acc_count", "_num_accumulations", "_acc_sum", "_acc_sum_squared"}
+
+
+def test_mesh_contract():
+    g = gp.cylinder_mesh(300, seed=3)
+    ei = g.edge_index
+    key = ei[0] * 300 + ei[1]
+    assert torch.all(key[1:] > key[:-1])  # coalesced: sorted by (src,dst), no duplicates
+    assert torch.all(ei[0] != ei[1])
+    rev = set(map(tuple, ei.t().tolist()))
+    assert all((b, a) in rev for a, b in rev)  # symmetric closure
+    assert g.edge_attr.shape == (ei.shape[1], 3) and g.x.shape == (300, 4)
+    b = gp.collate([g, gp.cylinder_mesh(200, seed=4)])
+    assert b.x.shape[0] == 500 and int(b.edge_index.max()) < 500 and int(b.edge_index[:, ei.shape[1]:].min()) >= 300

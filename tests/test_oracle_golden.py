@@ -1,0 +1,110 @@
+"""CPU: the oracle (oracle/mgn_oracle.py) against the golden vectors minted from the
+reference (tests/golden/make_golden.py).  Forward results are bit-exact; gradients
+carry a tolerance because CPU index_put_(accumulate) is order-nondeterministic."""
+import numpy as np
+import torch
+
+import recipe as R
+from conftest import load_golden, rel_err
+from oracle import mgn_oracle as O
+
+
+def _block_case(tag, H, N, seed):
+    g = load_golden(tag)
+    _, ei, _ = R.delaunay_graph(N, seed)
+    assert torch.equal(ei, g["edge_index"])
+    params = R.make_params(R.epd_param_shapes(1, H, 1, 1, 1, only_processor=True), seed)
+    x = R.randn((N, H), seed + 1)
+    e = R.randn((ei.shape[1], H), seed + 2)
+    return g, ei, params, x, e
+
+
+def test_block_forward_bit_exact():
+    for tag, H, N, seed in (("block_h128", 128, 24, 11), ("block_h16", 16, 12, 12)):
+        g, ei, params, x, e = _block_case(tag, H, N, seed)
+        x2, e2, inter = O.graph_net_block(x, e, ei, params, "processor_list.0.", return_intermediates=True)
+        assert torch.equal(x2, g["x_out"]) and torch.equal(e2, g["e_out"])
+        assert torch.equal(inter["m"], g["m"]) and torch.equal(inter["agg"], g["agg"])
+
+
+def test_block_backward():
+    tag, H, N, seed = "block_h128", 128, 24, 11
+    g, ei, params, x, e = _block_case(tag, H, N, seed)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    x.requires_grad_(True), e.requires_grad_(True)
+    x2, e2 = O.graph_net_block(x, e, ei, p, "processor_list.0.")
+    ((x2 * R.randn((N, H), seed + 3)).sum() + (e2 * R.randn((ei.shape[1], H), seed + 4)).sum()).backward()
+    assert rel_err(x.grad, g["dx"]) < 1e-5 and rel_err(e.grad, g["de"]) < 1e-5
+    for k, v in p.items():
+        kk = "g_" + k[len("processor_list.0."):]
+        if v.dim() == 2:
+            assert rel_err(v.grad[:8], g[kk + "__rows8"]) < 1e-5
+            assert abs(float(v.grad.norm()) - float(g[kk + "__norm"])) < 1e-5 * float(g[kk + "__norm"])
+        else:
+            assert rel_err(v.grad, g[kk]) < 1e-5
+
+
+def test_epd_forward_bit_exact():
+    for tag, L, N, seed in (("epd_l2", 2, 256, 21), ("epd_l15", 15, 256, 22)):
+        g = load_golden(tag)
+        _, ei, ea = R.delaunay_graph(N, seed)
+        params = R.make_params(R.epd_param_shapes(L, 128, 11, 3, 2), seed)
+        per = []
+        out = O.epd_forward(R.randn((N, 11), seed + 1), R.randn((ea.shape[0], 3), seed + 2), ei, params, L, per_round=per)
+        assert torch.equal(out, g["out"])
+        assert torch.equal(torch.stack([p[0] for p in per]), g["x_round_row0"])
+
+
+def test_edge_cases_bit_exact():
+    H, L, N, E, seed = 128, 3, 40, 150, 31
+    ei = R.random_graph(N, E, seed)
+    g = load_golden("epd_random_graph")
+    assert torch.equal(ei, g["edge_index"])
+    params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), seed)
+    out = O.epd_forward(R.randn((N, 11), seed + 1), R.randn((E, 3), seed + 2), ei, params, L)
+    assert torch.equal(out, g["out"])
+    g = load_golden("epd_only_processor")
+    params = R.make_params(R.epd_param_shapes(2, H, 1, 1, 1, only_processor=True), seed + 5)
+    out = O.epd_forward(R.randn((N, H), seed + 6), R.randn((E, H), seed + 7), ei, params, 2, only_processor=True)
+    assert torch.equal(out, g["out"])
+
+
+def test_train_steps():
+    H, L, N, seed = 128, 3, 96, 41
+    g = load_golden("train_2steps")
+    pos, ei, ea, xs, ys = R.trajectory(N, 3, seed)
+    p = {k: v.clone().requires_grad_(True) for k, v in R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), seed).items()}
+    sim = O.SimulatorOracle(R.CYL_INDEX, 11, 3, 2)
+    log = O.train_steps(p, sim, [(xs[t], ys[t], ea, ei) for t in range(2)], L, 1e-3, 4, 100)
+    for t in range(2):
+        assert abs(log[t][0] - float(g["loss"][t])) < 1e-5 * float(g["loss"][t])
+        assert abs(log[t][1] - float(g["grad_norm"][t])) < 1e-5 * float(g["grad_norm"][t])
+    assert torch.allclose(p["decode_module.6.weight"].detach(), g["w_last"], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(p["nodes_encoder.0.bias"].detach(), g["b_first"], rtol=1e-5, atol=2e-6)
+    sums = np.array([p[k].detach().double().sum().item() for k in p])
+    assert np.allclose(sums, g["param_sum"].numpy(), rtol=1e-6, atol=1e-4)
+    assert torch.equal(sim.node_norm.acc_sum, g["node_norm_sum"])
+    # learning-rate schedule (scheduler.py:51-67): lr_after[t] is the LR set for step t+1
+    for t in range(2):
+        assert abs(1e-3 * O.lr_factor(t + 1, 4, 100) - float(g["lr_after"][t])) < 1e-12
+
+
+def test_rollout_bit_exact():
+    H, L, N, seed, T = 128, 3, 96, 51, 5
+    g = load_golden("rollout_5steps")
+    pos, ei, ea, xs, ys = R.trajectory(N, T, seed)
+    params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), seed)
+    sim = O.SimulatorOracle(R.CYL_INDEX, 11, 3, 2)
+    nsd = {k[len("norm."):]: v for k, v in g.items() if k.startswith("norm.")}
+    sim.out_norm.load(nsd, "_output_normalizer.")
+    sim.node_norm.load(nsd, "_node_normalizer.")
+    sim.edge_norm.load(nsd, "_edge_normalizer.")
+    preds = O.rollout(params, sim, xs, ys, ea, ei, L)
+    assert torch.equal(preds[0], g["pred1"]) and torch.equal(preds[1], g["pred2"]) and torch.equal(preds[4], g["pred5"])
+
+
+def test_csr_oracle():
+    key = torch.tensor([2, 0, 2, 1, 0, 2, 4])
+    rowptr, perm = O.csr_by_key(key, 5)
+    assert rowptr.tolist() == [0, 2, 3, 6, 6, 7]
+    assert perm.tolist() == [1, 4, 3, 0, 2, 5, 6]
