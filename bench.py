@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MeshGraphNet (CylinderFlow, 15 rounds, latent 128) training
+steps/s on MI355X through the HIP engine, plus rollout node*steps/s.
+
+  python bench.py --gpus N --steps K --warmup W        (driver: torch.distributed.run for N>1)
+
+One "step" = one optimiser step (forward + masked L2 + backward + clip 1.0 + AdamW)
+on one batch of 16 synthetic CylinderFlow meshes (BASELINE.json configs[1]; data
+already resident in HBM).  For N>1 every rank steps its own batch of 16 and the
+gradients are all-reduced over RCCL each step (weak scaling; value = N*K/T).
+
+The JSON line also carries
+  roofline      MFMA roofline of the dominant kernel (edge-MLP forward, fp32 MFMA),
+                timed live with HIP events on the launch stream,
+  roofline_scatter   HBM roofline of the segment-sum (scatter-add) kernel,
+  cpu_baseline  the torch-CPU oracle timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+PEAK_MFMA_F32 = 157.3  # TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md chip table)
+PEAK_HBM = 8000.0  # GB/s spec (same table; ~6300 achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="meshes per GPU batch (configs[1] = 16)")
+    ap.add_argument("--nodes", type=int, default=1885)
+    ap.add_argument("--rounds", type=int, default=15)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--rollout-steps", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def time_kernel(fn, iters=20, warm=3):
+    """average launch duration (ms) measured with HIP events on the current stream"""
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def kernel_rooflines(gp, ops, batch, model, dev):
+    """Live per-kernel timings on the bench workload (same tensors' shapes)."""
+    from graph_physics_amd.layers import _block_params
+
+    topo = batch.mgn_topology
+    N, E, H = topo.N, topo.E, model.hidden_size
+    f = dict(dtype=torch.float32, device=dev)
+    x, e = torch.randn(N, H, **f), torch.randn(E, H, **f)
+    q = [p.detach() for p in _block_params(model.processor_list[0])]
+    We, be, se = [q[0], q[2], q[4], q[6]], [q[1], q[3], q[5], q[7]], q[8]
+    m, e_new, agg = torch.empty(E, H, **f), torch.empty(E, H, **f), torch.empty(N, H, **f)
+    He = [torch.empty(E, H, **f) for _ in range(3)]
+    Ue, Re = torch.empty(E, H, **f), torch.empty(E, **f)
+
+    def edge_fwd():
+        ops.mlp_fwd(E, H, [(e, None, H), (x, topo.dst_s, H), (x, topo.src_s, H)], We, be, se, H, e, e_new, m, He, Ue, Re)
+
+    def seg():
+        ops.segsum(m, topo.rowptr_dst, None, agg)
+
+    t_edge = time_kernel(edge_fwd)
+    t_seg = time_kernel(seg, iters=50)
+    flops = 12.0 * E * H * H  # 2*E*H*(3H) + 3 * 2*E*H*H   
+    ach = flops / (t_edge * 1e-3) / 1e12
+    seg_bytes = 4.0 * E * H + 4.0 * N * H + 4.0 * (N + 1)  # read m, write agg, read rowptr
+    ach_seg = seg_bytes / (t_seg * 1e-3) / 1e9
+    roof = {"kernel": "k_mlp_fwd<8,MT> (edge MLP: gather + 4 Linear + RMSNorm + residual)", "bound": "mfma",
+            "achieved": round(ach, 2), "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4),
+            "traffic": None, "launch_ms": round(t_edge, 4), "flops_per_launch": flops}
+    roof_seg = {"kernel": "k_segsum<8> (CSR segment-sum of edge messages)", "bound": "hbm", "achieved": round(ach_seg, 1),
+                "peak": PEAK_HBM, "unit": "GB/s", "frac": round(ach_seg / PEAK_HBM, 4), "traffic": None,
+                "launch_ms": round(t_seg, 5), "bytes_per_launch": seg_bytes}
+    return roof, roof_seg
+
+
+def cpu_baseline(args, gp):
+    """The torch-CPU oracle (bit-exact restatement of the reference, oracle/mgn_oracle.py)
+    timed on the host cores: training steps on the same synthetic batch."""
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    import recipe as R
+    from oracle import mgn_oracle as O
+
+    torch.manual_seed(0)
+    params = R.make_params(R.epd_param_shapes(args.rounds, args.hidden, 11, 3, 2), 0)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ix = gp.cylinder_config()["index"]
+    one = gp.cylinder_mesh(args.nodes, 0)
+    sim = O.SimulatorOracle(ix, 11, 3, 2)
+    O.train_steps(p, sim, [(one.x, one.y, one.edge_attr, one.edge_index)], args.rounds, 1e-4, 10, 100)  # warm-up
+    nb = min(args.batch, 16)
+    big = gp.cylinder_batch(nb, args.nodes, 0)
+    n_steps = 2
+    t0 = time.perf_counter()
+    O.train_steps(p, sim, [(big.x, big.y, big.edge_attr, big.edge_index)] * n_steps, args.rounds, 1e-4, 10, 100)
+    dt = (time.perf_counter() - t0) / n_steps
+    return {"value": round(1.0 / dt * (nb / args.batch), 5), "unit": "steps/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{n_steps} training steps of the oracle on a batch of {nb} meshes "
+            f"(N={big.x.shape[0]}, E={big.edge_index.shape[1]}), {dt:.2f} s/step, after one batch-1 warm-up step"}
+
+
+def main():
+    args = parse()
+    import graph_physics_amd as gp
+    from graph_physics_amd import distributed as D
+    from graph_physics_amd import harness, ops
+
+    rank, world, local = D.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = gp.cylinder_config(args.rounds, args.hidden)
+    torch.manual_seed(0)
+    eng = harness.Engine(cfg, dev, learning_rate=1e-4, num_steps=10000, warmup=100)
+    if world > 1:
+        D.broadcast_parameters(eng.sim)
+        eng.grad_sync = D.GradAllReduce()
+    batch = gp.cylinder_batch(args.batch, args.nodes, seed0=rank * args.batch).to(dev)
+    batch.mgn_topology = ops.Topology(batch.edge_index, batch.x.shape[0])
+    N, E = batch.x.shape[0], batch.edge_index.shape[1]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train_step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    steps_per_s = world * args.steps / dt
+
+    # rollout (second half of the metric): one mesh batch advanced autoregressively
+    frames = [batch] * args.rollout_steps
+    eng.rollout(frames[:3])
+    barrier()
+    t0 = time.perf_counter()
+    eng.rollout(frames)
+    barrier()
+    dt_r = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt_r], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt_r = float(t.item())
+    rollout_nps = world * N * args.rollout_steps / dt_r
+
+    if rank == 0:
+        out = {
+            "metric": "training steps/sec, CylinderFlow 15-round MGN (batch 16 meshes per step)",
+            "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CylinderFlow-like Delaunay meshes, {args.batch} x {args.nodes} nodes per GPU batch "
+                       f"(N={N}, E={E}), {args.rounds} MP rounds, latent {args.hidden}, fp32, random-init weights; "
+                       "BASELINE.json configs[1]", "global_batch_meshes": args.batch * world,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "rollout_node_steps_per_s": round(rollout_nps, 1),
+            "rollout_ms_per_step": round(1e3 * dt_r / args.rollout_steps, 3),
+        }
+        if not args.no_kernel_timing:
+            roof, roof_seg = kernel_rooflines(gp, ops, batch, eng.model, dev)
+            out["roofline"], out["roofline_scatter"] = roof, roof_seg
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, gp)
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,11 +15,24 @@
 // with 16-byte loads and needs no LDS staging for operands.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "mgn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// Every hot access is forced into the GLOBAL address space: a pointer that went through
+// a select loses its provenance and becomes a FLAT access, and one flat load among
+// global loads makes hipcc fall back to s_waitcnt vmcnt(0) -- a full stall per step.
+typedef __attribute__((address_space(1))) const f32x4 g_cf32x4;
+typedef __attribute__((address_space(1))) f32x4 g_f32x4;
+typedef __attribute__((address_space(1))) const float g_cfloat;
+typedef __attribute__((address_space(1))) float g_float;
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(g_cf32x4*)p; }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *(g_f32x4*)p = v; }
+__device__ __forceinline__ float ld1(const float* p) { return *(g_cfloat*)p; }
+__device__ __forceinline__ void st1(float* p, float v) { *(g_float*)p = v; }
 
 // --------------------------------------------------------------------------
 // Z^T[16*ib.., tile] += W[16*ib + c, 16*kb + 4g + r] * in[kb][r]   (T-layout chain)
@@ -39,8 +52,7 @@ __device__ __forceinline__ void gemm_tl(f32x4 (&acc)[MT][HB], const f32x4 (&in)[
           f32x4 w[IP];
 #pragma unroll
           for (int q = 0; q < IP; ++q)
-            w[q] = (ib + q < nib) ? *(const f32x4*)(wl + (size_t)(16 * (ib + q)) * ldw + 16 * kb)
-                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+            w[q] = (ib + q < nib) ? ld4(wl + (size_t)(16 * (ib + q)) * ldw + 16 * kb) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -54,19 +66,66 @@ __device__ __forceinline__ void gemm_tl(f32x4 (&acc)[MT][HB], const f32x4 (&in)[
   }
 }
 
-template <int HB, int MT>
+// Guard-free variant for full H x H blocks -- the hot one.  Straight-line code with
+//  * kb-outer order: input block kb is dead once every output block consumed it, so
+//    (NEXT) the rows of the NEXT tensor (next gathered phase, or the saved activation
+//    the backward chain masks with) are loaded into in[.][kb] while the MFMAs of the
+//    remaining blocks run -- a prefetch that costs no extra registers;
+//  * a 3-deep ring of weight fragments loaded PD=2 steps ahead (L2 latency ~ 2 steps).
+// Consecutive MFMAs hit 2*MT different accumulators (dependent latency 40 cyc > issue 32).
+template <int HB, int MT, bool NEXT>
+__device__ __forceinline__ void gemm_full(f32x4 (&acc)[MT][HB], f32x4 (&in)[MT][HB],
+                                          const float* __restrict__ W, int ldw, int c, int g,
+                                          const float* const (&nxt)[MT]) {
+  constexpr int IP = (HB >= 2) ? 2 : 1;
+  constexpr int NI = HB / IP;
+  constexpr int NS = HB * NI;
+  constexpr int PD = 2;
+  const float* wl = W + (size_t)c * ldw + 4 * g;
+  f32x4 w[PD + 1][IP];
+#pragma unroll
+  for (int s = 0; s < PD && s < NS; ++s)
+#pragma unroll
+    for (int q = 0; q < IP; ++q)
+      w[s % (PD + 1)][q] = ld4(wl + (size_t)(16 * ((s % NI) * IP + q)) * ldw + 16 * (s / NI));
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int kb = s / NI, ibp = s % NI;
+    if (s + PD < NS) {
+      const int s2 = s + PD;
+#pragma unroll
+      for (int q = 0; q < IP; ++q)
+        w[s2 % (PD + 1)][q] = ld4(wl + (size_t)(16 * ((s2 % NI) * IP + q)) * ldw + 16 * (s2 / NI));
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the hand-placed pipeline: no hoisting of later loads
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int q = 0; q < IP; ++q)
+          acc[t][ibp * IP + q] = MFMA16(w[s % (PD + 1)][q][r], in[t][kb][r], acc[t][ibp * IP + q]);
+    if (NEXT && ibp == NI - 1) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) in[t][kb] = ld4(nxt[t] + 16 * kb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int HB, int MT, bool RAGGED = true>
 __device__ __forceinline__ void load_tl(f32x4 (&v)[MT][HB], const float* __restrict__ src,
                                         const int32_t* __restrict__ idx, int kw, const long (&mm)[MT],
                                         int g, int& nkb) {
   constexpr int H = 16 * HB;
-  if (kw == H) {
+  if (!RAGGED || kw == H) {
     nkb = HB;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const long row = idx ? (long)idx[mm[t]] : mm[t];
       const float* p = src + row * H + 4 * g;
 #pragma unroll
-      for (int kb = 0; kb < HB; ++kb) v[t][kb] = *(const f32x4*)(p + 16 * kb);
+      for (int kb = 0; kb < HB; ++kb) v[t][kb] = ld4(p + 16 * kb);
     }
   } else {  // ragged width: scalar guarded loads, zero padded to a multiple of 16
     nkb = (kw + 15) >> 4;
@@ -81,7 +140,7 @@ __device__ __forceinline__ void load_tl(f32x4 (&v)[MT][HB], const float* __restr
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int k = 16 * kb + 4 * g + r;
-            if (k < kw) x[r] = p[k];
+            if (k < kw) x[r] = ld1(p + k);
           }
         }
         v[t][kb] = x;
@@ -90,17 +149,17 @@ __device__ __forceinline__ void load_tl(f32x4 (&v)[MT][HB], const float* __restr
   }
 }
 
-template <int HB, int MT>
+template <int HB, int MT, bool RAGGED = true>
 __device__ __forceinline__ void store_tl(float* __restrict__ dst, const f32x4 (&v)[MT][HB], int w,
                                          const long (&mm)[MT], const bool (&valid)[MT], int g) {
   constexpr int H = 16 * HB;
-  if (w == H) {
+  if (!RAGGED || w == H) {
 #pragma unroll
     for (int t = 0; t < MT; ++t)
       if (valid[t]) {
         float* p = dst + mm[t] * H + 4 * g;
 #pragma unroll
-        for (int kb = 0; kb < HB; ++kb) *(f32x4*)(p + 16 * kb) = v[t][kb];
+        for (int kb = 0; kb < HB; ++kb) st4(p + 16 * kb, v[t][kb]);
       }
   } else {
     const int nb = (w + 15) >> 4;
@@ -114,7 +173,7 @@ __device__ __forceinline__ void store_tl(float* __restrict__ dst, const f32x4 (&
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int k = 16 * kb + 4 * g + r;
-              if (k < w) p[k] = v[t][kb][r];
+              if (k < w) st1(p + k, v[t][kb][r]);
             }
           }
       }
@@ -126,7 +185,7 @@ __device__ __forceinline__ void init_bias(f32x4 (&acc)[MT][HB], const float* __r
 #pragma unroll
   for (int ib = 0; ib < HB; ++ib) {
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (b != nullptr && ib < nib) bv = *(const f32x4*)(b + 16 * ib + 4 * g);
+    if (b != nullptr && ib < nib) bv = ld4(b + 16 * ib + 4 * g);
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t][ib] = bv;
   }
@@ -148,7 +207,7 @@ __device__ __forceinline__ float colsum16(float v) {
 }
 
 // ========================================================================= forward
-template <int HB, int MT>
+template <int HB, int MT, bool RAGGED>
 __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_mlp_fwd_args a) {
   constexpr int H = 16 * HB;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -166,38 +225,74 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_ml
   const int nib_last = (a.out_w + 15) >> 4;
 
   f32x4 in[MT][HB], acc[MT][HB];
-  // ---- layer 0: phases of the concatenated input, gathered straight into MFMA operands
-  {
-    const int nib0 = (a.NL == 1) ? nib_last : HB;
-    int ktot = 0;
-    for (int p = 0; p < a.nphase; ++p) ktot += (a.kw[p] + 15) & ~15;
-    init_bias<HB, MT>(acc, a.b[0], nib0, g);
-    int koff = 0;
-    for (int p = 0; p < a.nphase; ++p) {
-      int nkb;
-      load_tl<HB, MT>(in, a.src[p], a.idx[p], a.kw[p], mm, g, nkb);
+  const float* dummy[MT];  // any readable address: target of the redundant "next" loads
+#pragma unroll
+  for (int t = 0; t < MT; ++t) dummy[t] = a.W[0] + 4 * g;
+  const int nib0 = (a.NL == 1) ? nib_last : HB;
+  int ktot = 0;
+  bool full0 = (nib0 == HB);
+  for (int p = 0; p < a.nphase; ++p) {
+    ktot += (a.kw[p] + 15) & ~15;
+    full0 = full0 && (a.kw[p] == H);
+  }
+  init_bias<HB, MT>(acc, a.b[0], nib0, g);
+  int nkb;
+  load_tl<HB, MT, RAGGED>(in, a.src[0], a.idx[0], a.kw[0], mm, g, nkb);  // first phase: blocking
+  int l = 0, p = 0, koff = 0;
+  bool layer_open = full0;  // acc is collecting layer 0's phases through the pipelined path
+  if (RAGGED && !full0) {  // ragged layer 0 (encoders: 11 / 3 input features): guarded generic path
+    for (int pp = 0; pp < a.nphase; ++pp) {
+      if (pp > 0) load_tl<HB, MT, RAGGED>(in, a.src[pp], a.idx[pp], a.kw[pp], mm, g, nkb);
       gemm_tl<HB, MT>(acc, in, a.W[0] + koff, ktot, nib0, nkb, c, g);
       koff += 16 * nkb;
     }
+    l = 1;
   }
-  // ---- layers 1..NL-1: the accumulator IS the next B operand
-  for (int l = 1; l < a.NL; ++l) {
+  // One pipelined GEMM call site serves every phase of layer 0 and every later layer.
+  while (l < a.NL) {
+    const float* Wp;
+    int ldw;
+    const float* nx[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int t = 0; t < MT; ++t) nx[t] = dummy[t];
+    if (layer_open) {  // layer 0, phase p; prefetch the gathered rows of phase p+1
+      Wp = a.W[0] + koff;
+      ldw = ktot;
+      if (p + 1 < a.nphase) {
+        const float* sp = a.src[p + 1];
+        const int32_t* ip = a.idx[p + 1];
 #pragma unroll
-      for (int ib = 0; ib < HB; ++ib)
+        for (int t = 0; t < MT; ++t) nx[t] = sp + (ip ? (long)ip[mm[t]] : mm[t]) * H + 4 * g;
+      }
+    } else {  // layer l >= 1: the accumulator IS the next B operand
 #pragma unroll
-        for (int r = 0; r < 4; ++r) in[t][ib][r] = fmaxf(acc[t][ib][r], 0.f);
-    if (a.saveH[l - 1] != nullptr) store_tl<HB, MT>(a.saveH[l - 1], in, H, mm, valid, g);
-    const int nib = (l == a.NL - 1) ? nib_last : HB;
-    init_bias<HB, MT>(acc, a.b[l], nib, g);
-    gemm_tl<HB, MT>(acc, in, a.W[l], H, nib, HB, c, g);
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) in[t][ib][r] = fmaxf(acc[t][ib][r], 0.f);
+      if (a.saveH[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.saveH[l - 1], in, H, mm, valid, g);
+      const int nib = (l == a.NL - 1) ? nib_last : HB;
+      init_bias<HB, MT>(acc, a.b[l], nib, g);
+      if (RAGGED && nib != HB) {  // ragged last layer (decoder: 2 / 3 outputs)
+        gemm_tl<HB, MT>(acc, in, a.W[l], H, nib, HB, c, g);
+        ++l;
+        continue;
+      }
+      Wp = a.W[l];
+      ldw = H;
+    }
+    gemm_full<HB, MT, true>(acc, in, Wp, ldw, c, g, nx);
+    if (layer_open && p + 1 < a.nphase) {
+      ++p;
+      koff += H;
+    } else {
+      layer_open = false;
+      ++l;
+    }
   }
   // ---- epilogue: RMSNorm (reference epsilon placement), residual, stores
   if (a.scale != nullptr) {
-    f32x4 sc[HB];
-#pragma unroll
-    for (int ib = 0; ib < HB; ++ib) sc[ib] = *(const f32x4*)(a.scale + 16 * ib + 4 * g);
     const float sqrt_d = sqrtf((float)H);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -213,22 +308,22 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_ml
       for (int ib = 0; ib < HB; ++ib)
 #pragma unroll
         for (int r = 0; r < 4; ++r) in[t][ib][r] = acc[t][ib][r] / den;  // u = z / (rms + eps)
-      if (a.saveR != nullptr && valid[t] && g == 0) a.saveR[mm[t]] = rms;
+      if (a.saveR != nullptr && valid[t] && g == 0) st1(a.saveR + mm[t], rms);
 #pragma unroll
-      for (int ib = 0; ib < HB; ++ib) acc[t][ib] = sc[ib] * in[t][ib];
+      for (int ib = 0; ib < HB; ++ib) acc[t][ib] = ld4(a.scale + 16 * ib + 4 * g) * in[t][ib];
     }
-    if (a.saveU != nullptr) store_tl<HB, MT>(a.saveU, in, H, mm, valid, g);
+    if (a.saveU != nullptr) store_tl<HB, MT, RAGGED>(a.saveU, in, H, mm, valid, g);
   }
-  if (a.y_out != nullptr) store_tl<HB, MT>(a.y_out, acc, a.out_w, mm, valid, g);
+  if (a.y_out != nullptr) store_tl<HB, MT, RAGGED>(a.y_out, acc, a.out_w, mm, valid, g);
   if (a.resid != nullptr) {
     int nkb;
-    load_tl<HB, MT>(in, a.resid, nullptr, a.out_w, mm, g, nkb);
+    load_tl<HB, MT, RAGGED>(in, a.resid, nullptr, a.out_w, mm, g, nkb);
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int ib = 0; ib < HB; ++ib) acc[t][ib] = in[t][ib] + acc[t][ib];
   }
-  store_tl<HB, MT>(a.out, acc, a.out_w, mm, valid, g);
+  store_tl<HB, MT, RAGGED>(a.out, acc, a.out_w, mm, valid, g);
 }
 
 // ======================================================================== backward
@@ -247,7 +342,7 @@ __device__ __forceinline__ void colsum_to_lds(float* lds_w, const f32x4 (&v)[MT]
   }
 }
 
-template <int HB, int MT>
+template <int HB, int MT, bool RAGGED>
 __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_mlp_bwd_args a) {
   constexpr int H = 16 * HB;
   __shared__ float lds[4 * (MGN_MAX_LAYERS + 1) * H];
@@ -271,9 +366,9 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
     const int nkb_last = (a.out_w + 15) >> 4;
     f32x4 dz[MT][HB], acc[MT][HB];
     int nkb;
-    load_tl<HB, MT>(dz, a.dOut, nullptr, a.out_w, mm, g, nkb);
+    load_tl<HB, MT, RAGGED>(dz, a.dOut, nullptr, a.out_w, mm, g, nkb);
     if (a.dOut2 != nullptr) {
-      load_tl<HB, MT>(acc, a.dOut2, a.idx2, H, mm, g, nkb);
+      load_tl<HB, MT, RAGGED>(acc, a.dOut2, a.idx2, H, mm, g, nkb);
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -289,8 +384,8 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
     if (a.scale != nullptr) {
       f32x4 sc[HB];
 #pragma unroll
-      for (int ib = 0; ib < HB; ++ib) sc[ib] = *(const f32x4*)(a.scale + 16 * ib + 4 * g);
-      load_tl<HB, MT>(acc, a.U, nullptr, H, mm, g, nkb);  // acc <- u
+      for (int ib = 0; ib < HB; ++ib) sc[ib] = ld4(a.scale + 16 * ib + 4 * g);
+      load_tl<HB, MT, RAGGED>(acc, a.U, nullptr, H, mm, g, nkb);  // acc <- u
       f32x4 du[MT][HB];
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
@@ -304,7 +399,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
           dz[t][ib] = gg;
         }
         dot = rowsum4(dot);
-        const float rms = a.R[mm[t]];
+        const float rms = ld1(a.R + mm[t]);
         const float inv = 1.0f / (rms + a.eps);
         const float k2 = (rms > 0.f) ? dot / ((float)H * rms) : 0.f;
 #pragma unroll
@@ -312,40 +407,79 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
       }
       if (a.dscale != nullptr) colsum_to_lds<HB, MT>(lds_w + a.NL * H, du, c, g);
     }
-    if (a.dZ[a.NL - 1] != nullptr) store_tl<HB, MT>(a.dZ[a.NL - 1], dz, 16 * nkb_last, mm, valid, g);
+    if (a.dZ[a.NL - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.dZ[a.NL - 1], dz, 16 * nkb_last, mm, valid, g);
     if (a.db[a.NL - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (a.NL - 1) * H, dz, c, g);
-    // ---- dgrad chain with ReLU masks from the saved activations
-    for (int l = a.NL - 1; l >= 1; --l) {
+    // ---- dgrad chain with ReLU masks from the saved activations, then the requested
+    //      first-layer input gradients: ONE pipelined GEMM call site for all of them.
+    int l = a.NL - 1;
+    if (RAGGED && l >= 1 && nkb_last != HB) {  // ragged last layer (decoder): guarded generic path
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int nk = (l == a.NL - 1) ? nkb_last : HB;
-      gemm_tl<HB, MT>(acc, dz, a.WT[l], 16 * nk, HB, nk, c, g);
-      load_tl<HB, MT>(dz, a.Hs[l - 1], nullptr, H, mm, g, nkb);  // dz <- h_l (post-ReLU)
+      gemm_tl<HB, MT>(acc, dz, a.WT[l], 16 * nkb_last, HB, nkb_last, c, g);
+      load_tl<HB, MT, RAGGED>(dz, a.Hs[l - 1], nullptr, H, mm, g, nkb);
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int ib = 0; ib < HB; ++ib)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            dz[t][ib][r] = (valid[t] && dz[t][ib][r] > 0.f) ? acc[t][ib][r] : 0.f;
-      if (a.dZ[l - 1] != nullptr) store_tl<HB, MT>(a.dZ[l - 1], dz, H, mm, valid, g);
+          for (int r = 0; r < 4; ++r) dz[t][ib][r] = (valid[t] && dz[t][ib][r] > 0.f) ? acc[t][ib][r] : 0.f;
+      if (a.dZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.dZ[l - 1], dz, H, mm, valid, g);
       if (a.db[l - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
+      --l;
     }
-    // ---- gradients wrt the requested first-layer input blocks
-    for (int q = 0; q < a.n_din; ++q) {
-      if (a.din_resid[q] != nullptr) {
-        load_tl<HB, MT>(acc, a.din_resid[q], nullptr, H, mm, g, nkb);
-      } else {
+    const bool din_full = (a.NL > 1) || (nkb_last == HB);
+    int q = 0;
+    for (;;) {
+      const bool chain = (l >= 1);
+      if (!chain && q >= a.n_din) break;
+      const float* Wp;
+      const float* nx[MT];
+      if (chain) {
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
           for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Wp = a.WT[l];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) nx[t] = a.Hs[l - 1] + mm[t] * H + 4 * g;  // dz <- h_l on the way out
+      } else {
+        if (a.din_resid[q] != nullptr) {
+          load_tl<HB, MT, RAGGED>(acc, a.din_resid[q], nullptr, H, mm, g, nkb);
+        } else {
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (RAGGED && !din_full) {  // NL == 1 with a ragged output: generic
+          gemm_tl<HB, MT>(acc, dz, a.WT0[q], 16 * nkb_last, HB, nkb_last, c, g);
+          store_tl<HB, MT, RAGGED>(a.dIn[q], acc, H, mm, valid, g);
+          ++q;
+          continue;
+        }
+        Wp = a.WT0[q];
+        // the "next" loads re-read dZ[0] (just stored by this wave): dz keeps its value
+        const float* base = (a.dZ[0] != nullptr) ? a.dZ[0] : a.WT0[q];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) nx[t] = base + ((a.dZ[0] != nullptr) ? mm[t] * H : 0) + 4 * g;
       }
-      const int nk0 = (a.NL == 1) ? nkb_last : HB;
-      gemm_tl<HB, MT>(acc, dz, a.WT0[q], 16 * nk0, HB, nk0, c, g);
-      store_tl<HB, MT>(a.dIn[q], acc, H, mm, valid, g);
+      gemm_full<HB, MT, true>(acc, dz, Wp, H, c, g, nx);
+      if (chain) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz[t][ib][r] = (valid[t] && dz[t][ib][r] > 0.f) ? acc[t][ib][r] : 0.f;
+        if (a.dZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.dZ[l - 1], dz, H, mm, valid, g);
+        if (a.db[l - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
+        --l;
+      } else {
+        store_tl<HB, MT, RAGGED>(a.dIn[q], acc, H, mm, valid, g);
+        ++q;
+      }
     }
   }
   __syncthreads();
@@ -359,22 +493,329 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
 struct ColredOuts {
   float* o[MGN_MAX_LAYERS + 1];
 };
-__global__ void k_colred(const float* __restrict__ ws, int nblocks, int nslot, int H, const ColredOuts outs) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nslot * H) return;
-  float* o = outs.o[i / H];
-  if (o == nullptr) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+__global__ void __launch_bounds__(1024) k_colred(const float* __restrict__ ws, int nblocks, int nslot, int H, const ColredOuts outs) {
+  __shared__ float red[32][33];
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int rl = threadIdx.x >> 5;  // 0..31
   const size_t st = (size_t)nslot * H;
-  int b = 0;
-  for (; b + 4 <= nblocks; b += 4) {
-    s0 += ws[(size_t)b * st + i];
-    s1 += ws[(size_t)(b + 1) * st + i];
-    s2 += ws[(size_t)(b + 2) * st + i];
-    s3 += ws[(size_t)(b + 3) * st + i];
+  float s = 0.f;
+  if (col < nslot * H)
+    for (int b = rl; b < nblocks; b += 32) s += ws[(size_t)b * st + col];
+  red[rl][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rl == 0 && col < nslot * H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
+    float* o = outs.o[col / H];
+    if (o != nullptr) o[col % H] = t;
   }
-  for (; b < nblocks; ++b) s0 += ws[(size_t)b * st + i];
-  o[i % H] = (s0 + s1) + (s2 + s3);
+}
+
+// ======================================================== LDS-weight kernels (H = 128)
+// Probe result (tools/gemm_probe.hip): with every wave streaming its own weight
+// fragments from L2 the per-CU vector-memory path saturates and the fp32 MFMA pipe
+// idles half of the time.  Here the 4 waves of a workgroup share ONE copy of the weights
+// in LDS.  A 128x128 block is streamed as two K-halves of 32 KB (columns 0..63 / 64..127),
+// double buffered (2 x 32 KB), filled by LDS-DMA (global_load_lds_dwordx4, no VGPRs) one
+// half-GEMM ahead and read with ds_read_b128; 64 KB per workgroup lets TWO independent
+// workgroups share a CU, so one's barriers / stores / prologue hide under the other's MFMAs
+// (8 lock-stepped waves of a single workgroup measured 54 % MFMA-busy).
+// Image of a half: row j at byte 256*j; 16-byte chunk ch (0..15) of the row is stored at
+// chunk position ch ^ (j & 15) -- the swizzle goes on the DMA's per-lane SOURCE address (the
+// LDS destination of a DMA is lane-linear), and makes the rows a b128 lane group reads hit
+// different 4-bank groups (SQ_LDS_BANK_CONFLICT = 0).  One barrier per half-GEMM.
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
+#define WBUF_BYTES 32768
+
+// half hk (0/1) of the 128 x 128 block W (leading dimension ldw) -> 32 KB LDS buffer.
+// Instruction q = 8*wv+i fills rows 4q..4q+3 (1 KB, lane-linear): lane -> row 4q + lane/16,
+// chunk position lane%16 holding global chunk (lane%16) ^ (row%16).  With row%16 =
+// 4*(i%4) + lane/16 the per-lane part of the address takes only 4 values, so each DMA is
+// (wave-uniform SGPR base) + (one of 4 precomputed 32-bit lane offsets): no 64-bit VALU,
+// nothing to spill, and the 8 DMAs issue back to back.
+__device__ __forceinline__ void dma_weights(const float* __restrict__ Wk, int ldw, int hk, lds_char* buf, int wv, int lane) {
+  const int lg = lane >> 4, bg = (lane & 15) ^ lg;
+  int vo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vo[j] = lg * ldw + 4 * (bg ^ (4 * j));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = 8 * wv + i;
+    const float* su = Wk + (size_t)(4 * q) * ldw + 64 * hk;  // wave-uniform
+    __builtin_amdgcn_global_load_lds((g_cfloat*)(su + vo[i & 3]), buf + q * 1024, 16, 0, 0);
+  }
+}
+
+// acc += W[:, 64*hk .. 64*hk+63](LDS) * in[4*hk .. 4*hk+3]; the consumed input blocks are
+// refilled from nxt (prefetch of the next tensor, see gemm_full).
+template <int MT, int HK>
+__device__ __forceinline__ void gemm_lds_half(f32x4 (&acc)[MT][8], f32x4 (&in)[MT][8], lds_char* wbuf,
+                                              const int (&off)[4], const float* const (&nxt)[MT]) {
+  constexpr int NI = 4, NS = 16;
+  f32x4 w[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) w[0][q] = *(lds_cf32x4*)(wbuf + off[0] + q * 4096);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int kbh = s / NI, ibp = s % NI;
+    if (s + 1 < NS) {
+      const int s2 = s + 1, kb2 = s2 / NI, ib2 = (s2 % NI) * 2;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) w[s2 & 1][q] = *(lds_cf32x4*)(wbuf + off[kb2] + (ib2 + q) * 4096);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          acc[t][ibp * 2 + q] = MFMA16(w[s & 1][q][r], in[t][4 * HK + kbh][r], acc[t][ibp * 2 + q]);
+    if (ibp == NI - 1) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) in[t][4 * HK + kbh] = ld4(nxt[t] + 16 * (4 * HK + kbh));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int MT>
+__global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a) {
+  constexpr int HB = 8, H = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* wl = (lds_char*)smem;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const long row0 = ((long)blockIdx.x * 4 + wv) * (16 * MT);
+  long mm[MT];
+  bool valid[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const long m = row0 + 16 * t + c;
+    valid[t] = m < a.M;
+    mm[t] = valid[t] ? m : a.M - 1;  // waves past M still take part in the DMA / barriers
+  }
+  int off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) off[j] = c * 256 + (((4 * j + g) ^ c) & 15) * 16;
+
+  const int G = a.nphase + a.NL - 1;  // GEMMs: the phases of layer 0, then layers 1..NL-1
+  const int ktot = H * a.nphase;
+  auto wsrc = [&](int k, const float*& Wk, int& ldw) {
+    if (k < a.nphase) {
+      Wk = a.W[0] + H * k;
+      ldw = ktot;
+    } else {
+      Wk = a.W[k - a.nphase + 1];
+      ldw = H;
+    }
+  };
+  auto dma_half = [&](int j) {  // half j&1 of GEMM j>>1 -> buffer j&1
+    const float* Wk;
+    int ldw;
+    wsrc(j >> 1, Wk, ldw);
+    dma_weights(Wk, ldw, j & 1, wl + (j & 1) * WBUF_BYTES, wv, lane);
+  };
+  dma_half(0);
+  dma_half(1);
+  f32x4 in[MT][HB], acc[MT][HB];
+  const float* dummy[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) dummy[t] = a.W[0] + 4 * g;
+  init_bias<HB, MT>(acc, a.b[0], HB, g);
+  int nkb;
+  load_tl<HB, MT, false>(in, a.src[0], a.idx[0], H, mm, g, nkb);
+
+  for (int k = 0; k < G; ++k) {
+    const float* nx[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) nx[t] = dummy[t];
+    if (k < a.nphase) {
+      if (k + 1 < a.nphase) {  // prefetch the gathered rows of the next phase
+        const float* sp = a.src[k + 1];
+        const int32_t* ip = a.idx[k + 1];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) nx[t] = sp + (ip ? (long)ip[mm[t]] : mm[t]) * H + 4 * g;
+      }
+    } else {  // layer l >= 1: operand = ReLU(previous accumulator)
+      const int l = k - a.nphase + 1;
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) in[t][ib][r] = fmaxf(acc[t][ib][r], 0.f);
+      if (a.saveH[l - 1] != nullptr) store_tl<HB, MT, false>(a.saveH[l - 1], in, H, mm, valid, g);
+      init_bias<HB, MT>(acc, a.b[l], HB, g);
+    }
+    // barrier: this half's weights landed (DMA issued one half ago) and every wave is done
+    // reading the other buffer, which the next DMA may now overwrite
+    __syncthreads();
+    if (k >= 1) dma_half(2 * k + 1);
+    gemm_lds_half<MT, 0>(acc, in, wl, off, nx);
+    __syncthreads();
+    if (k + 1 < G) dma_half(2 * k + 2);
+    gemm_lds_half<MT, 1>(acc, in, wl + WBUF_BYTES, off, nx);
+  }
+  // ---- epilogue: RMSNorm (reference epsilon placement), residual, stores
+  if (a.scale != nullptr) {
+    const float sqrt_d = sqrtf((float)H);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      float ss = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss = fmaf(acc[t][ib][r], acc[t][ib][r], ss);
+      ss = rowsum4(ss);
+      const float rms = sqrtf(ss) / sqrt_d;
+      const float den = rms + a.eps;
+#pragma unroll
+      for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) in[t][ib][r] = acc[t][ib][r] / den;
+      if (a.saveR != nullptr && valid[t] && g == 0) st1(a.saveR + mm[t], rms);
+#pragma unroll
+      for (int ib = 0; ib < HB; ++ib) acc[t][ib] = ld4(a.scale + 16 * ib + 4 * g) * in[t][ib];
+    }
+    if (a.saveU != nullptr) store_tl<HB, MT, false>(a.saveU, in, H, mm, valid, g);
+  }
+  if (a.y_out != nullptr) store_tl<HB, MT, false>(a.y_out, acc, H, mm, valid, g);
+  if (a.resid != nullptr) {
+    load_tl<HB, MT, false>(in, a.resid, nullptr, H, mm, g, nkb);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int ib = 0; ib < HB; ++ib) acc[t][ib] = in[t][ib] + acc[t][ib];
+  }
+  store_tl<HB, MT, false>(a.out, acc, H, mm, valid, g);
+}
+
+template <int MT>
+__global__ void __launch_bounds__(256, 2) k_mlp_bwd_lds(const mgn_mlp_bwd_args a) {
+  constexpr int HB = 8, H = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* wl = (lds_char*)smem;
+  float* lds = (float*)(smem + 2 * WBUF_BYTES);  // [4 waves][nslot][H] column-sum partials
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const long row0 = ((long)blockIdx.x * 4 + wv) * (16 * MT);
+  const int nslot = a.NL + 1;
+  float* lds_w = lds + wv * nslot * H;
+  for (int i = lane; i < nslot * H; i += 64) lds_w[i] = 0.f;
+  long mm[MT];
+  bool valid[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const long m = row0 + 16 * t + c;
+    valid[t] = m < a.M;
+    mm[t] = valid[t] ? m : a.M - 1;
+  }
+  int off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) off[j] = c * 256 + (((4 * j + g) ^ c) & 15) * 16;
+  const int G = (a.NL - 1) + a.n_din;  // chain GEMMs (WT[NL-1]..WT[1]) then the input-grad GEMMs
+  auto wsrc = [&](int k) -> const float* { return (k < a.NL - 1) ? a.WT[a.NL - 1 - k] : a.WT0[k - (a.NL - 1)]; };
+  auto dma_half = [&](int j) { dma_weights(wsrc(j >> 1), H, j & 1, wl + (j & 1) * WBUF_BYTES, wv, lane); };
+  if (G > 0) {
+    dma_half(0);
+    dma_half(1);
+  }
+
+  f32x4 dz[MT][HB], acc[MT][HB];
+  int nkb;
+  load_tl<HB, MT, false>(dz, a.dOut, nullptr, H, mm, g, nkb);
+  if (a.dOut2 != nullptr) {
+    load_tl<HB, MT, false>(acc, a.dOut2, a.idx2, H, mm, g, nkb);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int ib = 0; ib < HB; ++ib) dz[t][ib] += acc[t][ib];
+  }
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+    if (!valid[t]) {
+#pragma unroll
+      for (int ib = 0; ib < HB; ++ib) dz[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  if (a.scale != nullptr) {  // RMSNorm backward (see k_mlp_bwd)
+    load_tl<HB, MT, false>(acc, a.U, nullptr, H, mm, g, nkb);
+    f32x4 du[MT][HB];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      float dot = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < HB; ++ib) {
+        du[t][ib] = dz[t][ib] * acc[t][ib];
+        const f32x4 gg = ld4(a.scale + 16 * ib + 4 * g) * dz[t][ib];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dot = fmaf(gg[r], acc[t][ib][r], dot);
+        dz[t][ib] = gg;
+      }
+      dot = rowsum4(dot);
+      const float rms = ld1(a.R + mm[t]);
+      const float inv = 1.0f / (rms + a.eps);
+      const float k2 = (rms > 0.f) ? dot / ((float)H * rms) : 0.f;
+#pragma unroll
+      for (int ib = 0; ib < HB; ++ib) dz[t][ib] = dz[t][ib] * inv - acc[t][ib] * k2;
+    }
+    if (a.dscale != nullptr) colsum_to_lds<HB, MT>(lds_w + a.NL * H, du, c, g);
+  }
+  if (a.dZ[a.NL - 1] != nullptr) store_tl<HB, MT, false>(a.dZ[a.NL - 1], dz, H, mm, valid, g);
+  if (a.db[a.NL - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (a.NL - 1) * H, dz, c, g);
+
+  for (int k = 0; k < G; ++k) {
+    const bool chain = k < a.NL - 1;
+    const int l = a.NL - 1 - k;  // chain: layer whose W^T is applied
+    const int q = k - (a.NL - 1);
+    const float* nx[MT];
+    if (chain) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < MT; ++t) nx[t] = a.Hs[l - 1] + mm[t] * H + 4 * g;  // dz <- h_l on the way out
+    } else {
+      if (a.din_resid[q] != nullptr) {
+        load_tl<HB, MT, false>(acc, a.din_resid[q], nullptr, H, mm, g, nkb);
+      } else {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const float* base = (a.dZ[0] != nullptr) ? a.dZ[0] : a.WT0[q];  // re-read dZ[0]: dz keeps its value
+#pragma unroll
+      for (int t = 0; t < MT; ++t) nx[t] = base + ((a.dZ[0] != nullptr) ? mm[t] * H : 0) + 4 * g;
+    }
+    __syncthreads();
+    if (k >= 1) dma_half(2 * k + 1);
+    gemm_lds_half<MT, 0>(acc, dz, wl, off, nx);
+    __syncthreads();
+    if (k + 1 < G) dma_half(2 * k + 2);
+    gemm_lds_half<MT, 1>(acc, dz, wl + WBUF_BYTES, off, nx);
+    if (chain) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dz[t][ib][r] = (valid[t] && dz[t][ib][r] > 0.f) ? acc[t][ib][r] : 0.f;
+      if (a.dZ[l - 1] != nullptr) store_tl<HB, MT, false>(a.dZ[l - 1], dz, H, mm, valid, g);
+      if (a.db[l - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
+    } else {
+      store_tl<HB, MT, false>(a.dIn[q], acc, H, mm, valid, g);
+    }
+  }
+  __syncthreads();
+  float* ws = (float*)a.red_ws + (size_t)blockIdx.x * nslot * H;
+  for (int i = threadIdx.x; i < nslot * H; i += 256)
+    ws[i] = ((lds[i] + lds[nslot * H + i]) + lds[2 * nslot * H + i]) + lds[3 * nslot * H + i];
 }
 
 // ===================================================================== weight grads
@@ -407,9 +848,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WgradLaunch L) {
     for (int jb = 0; jb < HB; ++jb) acc[kk][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int kb0 = wv * KPW;
-  if (kb0 < J.nkb) {
-    for (long tile = t0; tile < t1; ++tile) {
-      float av[HB][4], bv[KPW][4];
+  if (kb0 < J.nkb && t0 < t1) {
+    // operands of one 16-row tile in N-layout; tile t+1 is loaded while tile t multiplies
+    float av[2][HB][4], bv[2][KPW][4];
+    auto load_tile = [&](long tile, float (&a)[HB][4], float (&b)[KPW][4]) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long row = tile * 16 + 4 * g + r;
@@ -417,20 +859,36 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WgradLaunch L) {
         const float* ap = J.A + (ok ? row : 0) * J.lda + c;
         const float* bp = J.B + (ok ? row : 0) * J.ldb + c;
 #pragma unroll
-        for (int jb = 0; jb < HB; ++jb) av[jb][r] = (ok && jb < J.nja) ? ap[16 * jb] : 0.f;
+        for (int jb = 0; jb < HB; ++jb) a[jb][r] = (ok && jb < J.nja) ? ld1(ap + 16 * jb) : 0.f;
 #pragma unroll
         for (int kk = 0; kk < KPW; ++kk) {
           const int col = 16 * (kb0 + kk) + c;
-          bv[kk][r] = (ok && col < J.kw) ? bp[16 * (kb0 + kk)] : 0.f;
+          b[kk][r] = (ok && col < J.kw) ? ld1(bp + 16 * (kb0 + kk)) : 0.f;
         }
       }
+    };
+    auto mac_tile = [&](const float (&a)[HB][4], const float (&b)[KPW][4]) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int kk = 0; kk < KPW; ++kk)
 #pragma unroll
-          for (int jb = 0; jb < HB; ++jb)
-            if (jb < J.nja) acc[kk][jb] = MFMA16(av[jb][r], bv[kk][r], acc[kk][jb]);
+          for (int jb = 0; jb < HB; ++jb) acc[kk][jb] = MFMA16(a[jb][r], b[kk][r], acc[kk][jb]);
+    };
+    load_tile(t0, av[0], bv[0]);
+    long tile = t0;
+    for (; tile + 2 <= t1 - 1; tile += 2) {  // two tiles per trip keeps buffer indices static
+      load_tile(tile + 1, av[1], bv[1]);
+      mac_tile(av[0], bv[0]);
+      load_tile(tile + 2, av[0], bv[0]);
+      mac_tile(av[1], bv[1]);
+    }
+    if (tile + 1 <= t1 - 1) {
+      load_tile(tile + 1, av[1], bv[1]);
+      mac_tile(av[0], bv[0]);
+      mac_tile(av[1], bv[1]);
+    } else {
+      mac_tile(av[0], bv[0]);
     }
   }
   // D layout: lane (c,g), reg q -> dW[16*jb + 4g + q][16*kb + c]
@@ -490,7 +948,7 @@ __global__ void __launch_bounds__(256) k_segsum(const float* __restrict__ src, c
       const int kk = k + u;
       if (kk < end) {
         const long row = perm ? (long)perm[kk] : (long)kk;
-        v[u] = *(const f32x4*)(base + row * H);
+        v[u] = ld4(base + row * H);
       } else {
         v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -499,7 +957,7 @@ __global__ void __launch_bounds__(256) k_segsum(const float* __restrict__ src, c
     for (int u = 0; u < 8; ++u)
       if (k + u < end) s += v[u];
   }
-  *(f32x4*)(out + node * H + 4 * l) = s;
+  st4(out + node * H + 4 * l, s);
 }
 
 // ======================================================================= CSR build
@@ -616,29 +1074,99 @@ static int pick_mt(int64_t M) {
   return 1;
 }
 
-template <int HB>
-static void launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
-  const int mt = pick_mt(a.M);
-  const unsigned grid = (unsigned)((a.M + 64 * mt - 1) / (64 * mt));
-  if (mt == 2)
-    hipLaunchKernelGGL((k_mlp_fwd<HB, 2>), dim3(grid), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((k_mlp_fwd<HB, 1>), dim3(grid), dim3(256), 0, s, a);
+struct MlpPlan {
+  bool lds;       // LDS-weight kernel (H = 128, full widths)
+  int mt;         // 16-row tiles per wave
+  unsigned grid;  // workgroups
+  size_t smem;    // dynamic LDS bytes
+};
+
+static bool fwd_ragged(const mgn_mlp_fwd_args& a) {
+  bool r = (a.out_w != a.H);
+  for (int p = 0; p < a.nphase; ++p) r = r || (a.kw[p] != a.H);
+  return r;
 }
 
-static unsigned bwd_grid(int64_t M) {
-  const int mt = pick_mt(M);
-  return (unsigned)((M + 64 * mt - 1) / (64 * mt));
+static MlpPlan plan_mlp(int64_t M, int H, int NL, bool ragged, bool bwd) {
+  MlpPlan p;
+  p.lds = (H == 128) && !ragged && NL >= 2 && NL <= 6;
+  if (getenv("MGN_NO_LDS") != nullptr) p.lds = false;
+  p.mt = (M >= (int64_t)64 * 2048) ? 2 : 1;
+  // measured on MI355X (tools/kbench.py, E = 180k): with LDS-shared weights the forward is
+  // faster at 16 rows per wave (172 VGPRs, no spills: 352 vs 368 us), the backward chain at 32
+  if (p.lds && !bwd) p.mt = 1;
+  if (const char* e = getenv("MGN_MT")) p.mt = (atoi(e) == 2) ? 2 : 1;
+  const int rows = 64 * p.mt;
+  p.grid = (unsigned)((M + rows - 1) / rows);
+  p.smem = p.lds ? (size_t)2 * WBUF_BYTES + (bwd ? (size_t)4 * (NL + 1) * H * sizeof(float) : 0) : 0;
+  return p;
+}
+
+template <typename K>
+static int set_smem(K kern, size_t bytes) {
+  static thread_local const void* done[16];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == (const void*)kern) return 0;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WBUF_BYTES + 4 * 7 * 128 * 4)) != hipSuccess) return 1;
+  (void)bytes;
+  if (ndone < 16) done[ndone++] = (const void*)kern;
+  return 0;
 }
 
 template <int HB>
-static void launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
-  const int mt = pick_mt(a.M);
-  const unsigned grid = bwd_grid(a.M);
-  if (mt == 2)
-    hipLaunchKernelGGL((k_mlp_bwd<HB, 2>), dim3(grid), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((k_mlp_bwd<HB, 1>), dim3(grid), dim3(256), 0, s, a);
+static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
+  const bool ragged = fwd_ragged(a);
+  const MlpPlan p = plan_mlp(a.M, a.H, a.NL, ragged, false);
+  if (p.lds) {
+    if (p.mt == 2) {
+      if (set_smem(k_mlp_fwd_lds<2>, p.smem)) return 1;
+      hipLaunchKernelGGL((k_mlp_fwd_lds<2>), dim3(p.grid), dim3(256), p.smem, s, a);
+    } else {
+      if (set_smem(k_mlp_fwd_lds<1>, p.smem)) return 1;
+      hipLaunchKernelGGL((k_mlp_fwd_lds<1>), dim3(p.grid), dim3(256), p.smem, s, a);
+    }
+    return 0;
+  }
+  if (ragged) {  // encoders / decoder: guarded generic first / last layer
+    if (p.mt == 2)
+      hipLaunchKernelGGL((k_mlp_fwd<HB, 2, true>), dim3(p.grid), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_mlp_fwd<HB, 1, true>), dim3(p.grid), dim3(256), 0, s, a);
+  } else {
+    if (p.mt == 2)
+      hipLaunchKernelGGL((k_mlp_fwd<HB, 2, false>), dim3(p.grid), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_mlp_fwd<HB, 1, false>), dim3(p.grid), dim3(256), 0, s, a);
+  }
+  return 0;
+}
+
+template <int HB>
+static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
+  const MlpPlan p = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H, true);
+  if (p.lds) {
+    if (p.mt == 2) {
+      if (set_smem(k_mlp_bwd_lds<2>, p.smem)) return 1;
+      hipLaunchKernelGGL((k_mlp_bwd_lds<2>), dim3(p.grid), dim3(256), p.smem, s, a);
+    } else {
+      if (set_smem(k_mlp_bwd_lds<1>, p.smem)) return 1;
+      hipLaunchKernelGGL((k_mlp_bwd_lds<1>), dim3(p.grid), dim3(256), p.smem, s, a);
+    }
+    return 0;
+  }
+  if (a.out_w != a.H) {
+    if (p.mt == 2)
+      hipLaunchKernelGGL((k_mlp_bwd<HB, 2, true>), dim3(p.grid), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_mlp_bwd<HB, 1, true>), dim3(p.grid), dim3(256), 0, s, a);
+  } else {
+    if (p.mt == 2)
+      hipLaunchKernelGGL((k_mlp_bwd<HB, 2, false>), dim3(p.grid), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_mlp_bwd<HB, 1, false>), dim3(p.grid), dim3(256), 0, s, a);
+  }
+  return 0;
 }
 
 extern "C" {
@@ -713,18 +1241,21 @@ int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream) {
   if (a.scale != nullptr && a.out_w != a.H) return fail(1, "mgn_mlp_fwd: RMSNorm needs out_w == H");
   if (a.M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  int rc;
   switch (a.H) {
-    case 128: launch_fwd<8>(a, s); break;
-    case 64: launch_fwd<4>(a, s); break;
-    case 32: launch_fwd<2>(a, s); break;
-    default: launch_fwd<1>(a, s); break;
+    case 128: rc = launch_fwd<8>(a, s); break;
+    case 64: rc = launch_fwd<4>(a, s); break;
+    case 32: rc = launch_fwd<2>(a, s); break;
+    default: rc = launch_fwd<1>(a, s); break;
   }
+  if (rc) return fail(2, "mgn_mlp_fwd: cannot reserve LDS");
   return check_launch("mgn_mlp_fwd");
 }
 
 
 size_t mgn_mlp_bwd_workspace_bytes(int64_t M, int H, int NL) {
-  return (size_t)(bwd_grid(M) + 1) * (NL + 1) * H * sizeof(float);
+  // sized for the kernel with the most workgroups (64 rows each)
+  return (size_t)((M + 63) / 64 + 1) * (NL + 1) * H * sizeof(float);
 }
 
 
@@ -732,18 +1263,21 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   const mgn_mlp_bwd_args& a = *args;
   if (int rc = check_mlp_common(a.H, a.NL, a.out_w, "mgn_mlp_bwd")) return rc;
   if (a.n_din < 0 || a.n_din > MGN_MAX_PHASES) return fail(1, "mgn_mlp_bwd: n_din out of range");
+  if (a.n_din > 1 && a.dZ[0] == nullptr) return fail(1, "mgn_mlp_bwd: n_din > 1 needs dZ[0]");
   if (a.M == 0) return 0;
   if (a.red_ws_bytes < mgn_mlp_bwd_workspace_bytes(a.M, a.H, a.NL)) return fail(1, "mgn_mlp_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
+  int lrc;
   switch (a.H) {
-    case 128: launch_bwd<8>(a, s); break;
-    case 64: launch_bwd<4>(a, s); break;
-    case 32: launch_bwd<2>(a, s); break;
-    default: launch_bwd<1>(a, s); break;
+    case 128: lrc = launch_bwd<8>(a, s); break;
+    case 64: lrc = launch_bwd<4>(a, s); break;
+    case 32: lrc = launch_bwd<2>(a, s); break;
+    default: lrc = launch_bwd<1>(a, s); break;
   }
+  if (lrc) return fail(2, "mgn_mlp_bwd: cannot reserve LDS");
   if (int rc = check_launch("mgn_mlp_bwd")) return rc;
   // column reductions: db[l], dscale
-  const unsigned grid = bwd_grid(a.M);
+  const unsigned grid = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H, true).grid;
   const int nslot = a.NL + 1;
   ColredOuts outs;
   bool any = false;
@@ -756,7 +1290,7 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   any |= outs.o[a.NL] != nullptr;
   if (!any) return 0;
   const int n = nslot * a.H;
-  hipLaunchKernelGGL(k_colred, dim3((n + 127) / 128), dim3(128), 0, s, (const float*)a.red_ws, (int)grid, nslot, a.H, outs);
+  hipLaunchKernelGGL(k_colred, dim3((n + 31) / 32), dim3(1024), 0, s, (const float*)a.red_ws, (int)grid, nslot, a.H, outs);
   return check_launch("mgn_mlp_bwd/colred");
 }
 
