@@ -907,6 +907,94 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WgradLaunch L) {
   }
 }
 
+// LDS-staged variant for full 128 x 128 jobs (lda = ldb = 128): the workgroup streams
+// 32-row tiles of A (= dZ) and B (= X) through LDS by DMA, double buffered; every element is
+// fetched from L2/HBM once per workgroup instead of once per wave.  Tile image: row r at
+// byte 512*r, 16-byte chunk p of the row holds global chunk p ^ (4*(r&1)): rows m and m+1
+// then sit 16 banks apart, so the N-layout ds_read_b32 (16 lanes x 4 rows) is conflict-free.
+#define WG_TILE_ROWS 32
+#define WG_TILE_BYTES (WG_TILE_ROWS * 512)
+
+__device__ __forceinline__ void dma_rows(const float* __restrict__ X, long row0, long M, lds_char* buf, int wv, int lane) {
+  // 32 rows x 512 B = 16 instructions of 1 KB (2 rows each); 4 per wave
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = 4 * wv + i;
+    const int r = 2 * q + (lane >> 5);
+    long row = row0 + r;
+    row = row < M ? row : M - 1;  // tail rows are masked at the MFMA
+    const int gch = (lane & 31) ^ (4 * (r & 1));
+    __builtin_amdgcn_global_load_lds((g_cfloat*)(X + row * 128 + 4 * gch), buf + q * 1024, 16, 0, 0);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* sm = (lds_char*)smem;  // [2 buffers][A tile | B tile]
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  int j = 0;
+  while (j + 1 < L.njobs && (int)blockIdx.x >= L.wg0[j + 1]) ++j;
+  const mgn_wgrad_job J = L.job[j];
+  const int nwg = L.wg0[j + 1] - L.wg0[j];
+  const int wg = blockIdx.x - L.wg0[j];
+  const long ntiles = (J.M + WG_TILE_ROWS - 1) / WG_TILE_ROWS;
+  const long t0 = ntiles * wg / nwg, t1 = ntiles * (wg + 1) / nwg;
+
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) acc[kk][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // lane (c,g) reads feature 16*b + c of row (4*quad + g): swizzled by the row parity
+  const int kb0 = 2 * wv;
+  if (t0 < t1) {
+    dma_rows(J.A, t0 * WG_TILE_ROWS, J.M, sm, wv, lane);
+    dma_rows(J.B, t0 * WG_TILE_ROWS, J.M, sm + WG_TILE_BYTES, wv, lane);
+  }
+  for (long tile = t0; tile < t1; ++tile) {
+    const int buf = (int)((tile - t0) & 1);
+    __syncthreads();  // tile landed; the other buffer is free again
+    if (tile + 1 < t1) {
+      lds_char* nb = sm + (buf ^ 1) * 2 * WG_TILE_BYTES;
+      dma_rows(J.A, (tile + 1) * WG_TILE_ROWS, J.M, nb, wv, lane);
+      dma_rows(J.B, (tile + 1) * WG_TILE_ROWS, J.M, nb + WG_TILE_BYTES, wv, lane);
+    }
+    lds_char* ta = sm + buf * 2 * WG_TILE_BYTES;
+    lds_char* tb = ta + WG_TILE_BYTES;
+    const bool tail = (tile + 1) * WG_TILE_ROWS > J.M;
+#pragma unroll
+    for (int quad = 0; quad < WG_TILE_ROWS / 4; ++quad) {
+      const int r = 4 * quad + g;
+      const int rb = r * 512 + ((r & 1) ? 64 : 0);  // XOR 16 floats on odd rows == toggle byte bit 6
+      float av[8], bv[2];
+#pragma unroll
+      for (int jb = 0; jb < 8; ++jb)
+        av[jb] = *(__attribute__((address_space(3))) const float*)(ta + ((r * 512 + 64 * jb + 4 * c) ^ ((r & 1) << 6)));
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        bv[kk] = *(__attribute__((address_space(3))) const float*)(tb + ((r * 512 + 64 * (kb0 + kk) + 4 * c) ^ ((r & 1) << 6)));
+      (void)rb;
+      if (tail && tile * WG_TILE_ROWS + r >= J.M) {
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) av[jb] = 0.f;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) acc[kk][jb] = MFMA16(av[jb], bv[kk], acc[kk][jb]);
+    }
+  }
+  float* P = L.partial + (size_t)blockIdx.x * (128 * 128);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[(16 * jb + 4 * g + q) * 128 + 16 * (kb0 + kk) + c] = acc[kk][jb][q];
+}
+
 __global__ void k_wgrad_red(const WgradLaunch L) {
   const int H = L.H;
   int j = blockIdx.y;
@@ -1294,15 +1382,18 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   return check_launch("mgn_mlp_bwd/colred");
 }
 
-static int wgrad_plan(int njobs, const mgn_wgrad_job* jobs, int* wg0) {
-  // ~1024 workgroups in total, shared out in proportion to the rows of each job
+static int wgrad_plan(int njobs, const mgn_wgrad_job* jobs, int* wg0, bool lds) {
+  // a fixed budget of workgroups shared out in proportion to the rows of each job:
+  // 512 for the LDS kernel (2 resident per CU), ~1024 for the generic one
+  const int rows = lds ? WG_TILE_ROWS : 16;
+  const int budget = lds ? 512 : 1024;
   int64_t tot = 0;
-  for (int j = 0; j < njobs; ++j) tot += (jobs[j].M + 15) / 16;
+  for (int j = 0; j < njobs; ++j) tot += (jobs[j].M + rows - 1) / rows;
   int acc = 0;
   for (int j = 0; j < njobs; ++j) {
-    const int64_t tiles = (jobs[j].M + 15) / 16;
-    int64_t n = tot > 0 ? (tiles * 1024 + tot - 1) / tot : 1;
-    const int64_t cap = (tiles + 7) / 8;  // at least 8 tiles (128 rows) per workgroup
+    const int64_t tiles = (jobs[j].M + rows - 1) / rows;
+    int64_t n = tot > 0 ? (tiles * budget + tot - 1) / tot : 1;
+    const int64_t cap = (tiles + 3) / 4;  // at least 4 tiles per workgroup
     if (n > cap) n = cap;
     if (n < 1) n = 1;
     wg0[j] = acc;
@@ -1314,37 +1405,60 @@ static int wgrad_plan(int njobs, const mgn_wgrad_job* jobs, int* wg0) {
 
 size_t mgn_wgrad_workspace_bytes(int njobs, const mgn_wgrad_job* jobs) {
   if (njobs < 1 || njobs > MGN_MAX_WGRAD_JOBS) return 0;
-  int wg0[MGN_MAX_WGRAD_JOBS + 1];
-  const int total = wgrad_plan(njobs, jobs, wg0);
-  return (size_t)total * 128 * 128 * sizeof(float);
+  // upper bound over the two launches (LDS-staged + generic)
+  return (size_t)(512 + 1024 + 2 * MGN_MAX_WGRAD_JOBS) * 128 * 128 * sizeof(float);
+}
+
+static bool wgrad_job_full(const mgn_wgrad_job& j) {
+  return j.nja == 8 && j.nkb == 8 && j.lda == 128 && j.ldb == 128 && j.kw == 128 && j.M >= 1 && getenv("MGN_NO_LDS") == nullptr;
 }
 
 int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, void* stream) {
   if (njobs < 1 || njobs > MGN_MAX_WGRAD_JOBS) return fail(1, "mgn_wgrad: njobs out of range");
-  WgradLaunch L;
-  L.njobs = njobs;
-  int maxb = 1;
-  for (int j = 0; j < njobs; ++j) {
-    L.job[j] = jobs[j];
-    if (jobs[j].nja < 1 || jobs[j].nkb < 1 || jobs[j].nja > 8 || jobs[j].nkb > 8) return fail(1, "mgn_wgrad: block counts out of range");
-    if (jobs[j].nja > maxb) maxb = jobs[j].nja;
-    if (jobs[j].nkb > maxb) maxb = jobs[j].nkb;
-  }
-  const int HB = maxb <= 1 ? 1 : maxb <= 2 ? 2 : maxb <= 4 ? 4 : 8;
-  L.H = 16 * HB;
-  const int total = wgrad_plan(njobs, jobs, L.wg0);
-  if (ws_bytes < (size_t)total * L.H * L.H * sizeof(float)) return fail(1, "mgn_wgrad: workspace too small");
-  L.partial = (float*)ws;
   hipStream_t s = (hipStream_t)stream;
-  switch (HB) {
-    case 8: hipLaunchKernelGGL(k_wgrad<8>, dim3(total), dim3(256), 0, s, L); break;
-    case 4: hipLaunchKernelGGL(k_wgrad<4>, dim3(total), dim3(256), 0, s, L); break;
-    case 2: hipLaunchKernelGGL(k_wgrad<2>, dim3(total), dim3(256), 0, s, L); break;
-    default: hipLaunchKernelGGL(k_wgrad<1>, dim3(total), dim3(256), 0, s, L); break;
+  // two launches at most: full 128x128 jobs on the LDS-staged kernel, the others generic
+  size_t ws_off = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    WgradLaunch L;
+    L.njobs = 0;
+    int maxb = 1;
+    for (int j = 0; j < njobs; ++j) {
+      if (jobs[j].nja < 1 || jobs[j].nkb < 1 || jobs[j].nja > 8 || jobs[j].nkb > 8) return fail(1, "mgn_wgrad: block counts out of range");
+      if (wgrad_job_full(jobs[j]) != (pass == 0)) continue;
+      L.job[L.njobs++] = jobs[j];
+      if (jobs[j].nja > maxb) maxb = jobs[j].nja;
+      if (jobs[j].nkb > maxb) maxb = jobs[j].nkb;
+    }
+    if (L.njobs == 0) continue;
+    const int HB = maxb <= 1 ? 1 : maxb <= 2 ? 2 : maxb <= 4 ? 4 : 8;
+    L.H = 16 * HB;
+    const int total = wgrad_plan(L.njobs, L.job, L.wg0, pass == 0);
+    const size_t need = (size_t)total * L.H * L.H * sizeof(float);
+    if (ws_bytes < ws_off + need) return fail(1, "mgn_wgrad: workspace too small");
+    L.partial = (float*)((char*)ws + ws_off);
+    ws_off += need;
+    if (pass == 0) {
+      const size_t smem = 4 * WG_TILE_BYTES;
+      static thread_local bool attr_done = false;
+      if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)k_wgrad_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+          return fail(2, "mgn_wgrad: cannot reserve LDS");
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(k_wgrad_lds, dim3(total), dim3(256), smem, s, L);
+    } else {
+      switch (HB) {
+        case 8: hipLaunchKernelGGL(k_wgrad<8>, dim3(total), dim3(256), 0, s, L); break;
+        case 4: hipLaunchKernelGGL(k_wgrad<4>, dim3(total), dim3(256), 0, s, L); break;
+        case 2: hipLaunchKernelGGL(k_wgrad<2>, dim3(total), dim3(256), 0, s, L); break;
+        default: hipLaunchKernelGGL(k_wgrad<1>, dim3(total), dim3(256), 0, s, L); break;
+      }
+    }
+    if (int rc = check_launch("mgn_wgrad")) return rc;
+    hipLaunchKernelGGL(k_wgrad_red, dim3((L.H * L.H + 255) / 256, L.njobs), dim3(256), 0, s, L);
+    if (int rc = check_launch("mgn_wgrad/reduce")) return rc;
   }
-  if (int rc = check_launch("mgn_wgrad")) return rc;
-  hipLaunchKernelGGL(k_wgrad_red, dim3((L.H * L.H + 255) / 256, njobs), dim3(256), 0, s, L);
-  return check_launch("mgn_wgrad/reduce");
+  return 0;
 }
 
 }  // extern "C"
