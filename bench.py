@@ -84,7 +84,7 @@ def kernel_rooflines(gp, ops, batch, model, dev):
     ach = flops / (t_edge * 1e-3) / 1e12
     seg_bytes = 4.0 * E * H + 4.0 * N * H + 4.0 * (N + 1)  # read m, write agg, read rowptr
     ach_seg = seg_bytes / (t_seg * 1e-3) / 1e9
-    roof = {"kernel": "k_mlp_fwd<8,MT> (edge MLP: gather + 4 Linear + RMSNorm + residual)", "bound": "mfma",
+    roof = {"kernel": "k_mlp_fwd_lds<1> (edge MLP: gather + 4 Linear + RMSNorm + residual, training-mode saves)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4),
             "traffic": None, "launch_ms": round(t_edge, 4), "flops_per_launch": flops}
     roof_seg = {"kernel": "k_segsum<8> (CSR segment-sum of edge messages)", "bound": "hbm", "achieved": round(ach_seg, 1),
@@ -95,7 +95,8 @@ def kernel_rooflines(gp, ops, batch, model, dev):
 
 def cpu_baseline(args, gp):
     """The torch-CPU oracle (bit-exact restatement of the reference, oracle/mgn_oracle.py)
-    timed on the host cores: training steps on the same synthetic batch."""
+    timed on the host cores.  Thread count: the fastest of a short sweep on the batch-1 mesh
+    (more threads is not faster for these small GEMMs); then one full batch timed at it."""
     sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
     import recipe as R
     from oracle import mgn_oracle as O
@@ -106,16 +107,30 @@ def cpu_baseline(args, gp):
     ix = gp.cylinder_config()["index"]
     one = gp.cylinder_mesh(args.nodes, 0)
     sim = O.SimulatorOracle(ix, 11, 3, 2)
-    O.train_steps(p, sim, [(one.x, one.y, one.edge_attr, one.edge_index)], args.rounds, 1e-4, 10, 100)  # warm-up
+    b1 = [(one.x, one.y, one.edge_attr, one.edge_index)]
+
+    def steps(batches):
+        t0 = time.perf_counter()
+        O.train_steps(p, sim, batches, args.rounds, 1e-4, 10, 100)
+        return (time.perf_counter() - t0) / len(batches)
+
+    ncpu = os.cpu_count() or 1
+    best_t, best_n = None, None
+    for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+        torch.set_num_threads(n)
+        steps(b1)  # warm-up at this thread count
+        t = steps(b1 * 2)
+        if best_t is None or t < best_t:
+            best_t, best_n = t, n
+    torch.set_num_threads(best_n)
     nb = min(args.batch, 16)
     big = gp.cylinder_batch(nb, args.nodes, 0)
-    n_steps = 2
-    t0 = time.perf_counter()
-    O.train_steps(p, sim, [(big.x, big.y, big.edge_attr, big.edge_index)] * n_steps, args.rounds, 1e-4, 10, 100)
-    dt = (time.perf_counter() - t0) / n_steps
-    return {"value": round(1.0 / dt * (nb / args.batch), 5), "unit": "steps/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{n_steps} training steps of the oracle on a batch of {nb} meshes "
-            f"(N={big.x.shape[0]}, E={big.edge_index.shape[1]}), {dt:.2f} s/step, after one batch-1 warm-up step"}
+    dt = steps([(big.x, big.y, big.edge_attr, big.edge_index)])
+    return {"value": round(1.0 / dt * (nb / args.batch), 5), "unit": "steps/s", "cores": best_n,
+            "kind": "port", "batch1_steps_per_s": round(1.0 / best_t, 3), "host_cpus": ncpu,
+            "sample": f"1 training step of the oracle on the batch of {nb} meshes (N={big.x.shape[0]}, "
+            f"E={big.edge_index.shape[1]}): {dt:.2f} s at {best_n} threads (fastest of a sweep over "
+            f"8..{ncpu} threads on the batch-1 mesh: {best_t:.3f} s/step)"}
 
 
 def main():

@@ -33,8 +33,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
 class GradAllReduce:
     """callable(params): average ``.grad`` over the group through one flat buffer."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, average: bool = True):
         self.group = group
+        self.average = average  # False: sum (partitioned mesh, the loss is already global)
         self._flat: Optional[torch.Tensor] = None
 
     def __call__(self, params: Iterable[torch.nn.Parameter]):
@@ -47,7 +48,8 @@ class GradAllReduce:
         torch._foreach_copy_(list(torch.split(self._flat, [p.grad.numel() for p in ps])),
                              [p.grad.reshape(-1) for p in ps])
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
-        self._flat.div_(dist.get_world_size(self.group))
+        if self.average:
+            self._flat.div_(dist.get_world_size(self.group))
         off = 0
         for p in ps:
             k = p.grad.numel()
@@ -61,3 +63,93 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+
+
+# ----------------------------------------------------------------------------------
+# Partitioned large-mesh path: one-hop halo exchange of ghost-node latents per round.
+# ----------------------------------------------------------------------------------
+class HaloExchange(torch.autograd.Function):
+    """ghost rows <- owners' rows (forward); ghost-row gradients summed back into the
+    owners' rows (backward).  One ``all_to_all_single`` each way -- a neighbour exchange
+    of ~O(sqrt(N/P)) rows per peer, latency-bound over xGMI."""
+
+    @staticmethod
+    def forward(ctx, x_own, plan, group):
+        ctx.plan, ctx.group, ctx.n_own = plan, group, x_own.shape[0]
+        idx = plan.send_idx.to(x_own.device)
+        ctx.idx = idx
+        send = x_own.detach().index_select(0, idx).contiguous()
+        recv = torch.empty(plan.n_ghost, x_own.shape[1], dtype=x_own.dtype, device=x_own.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=plan.recv_counts, input_split_sizes=plan.send_counts, group=group)
+        return recv
+
+    @staticmethod
+    def backward(ctx, d_ghost):
+        plan = ctx.plan
+        d_ghost = d_ghost.contiguous()
+        back = torch.empty(ctx.idx.numel(), d_ghost.shape[1], dtype=d_ghost.dtype, device=d_ghost.device)
+        dist.all_to_all_single(back, d_ghost, output_split_sizes=plan.send_counts, input_split_sizes=plan.recv_counts, group=ctx.group)
+        d_own = torch.zeros(ctx.n_own, d_ghost.shape[1], dtype=d_ghost.dtype, device=d_ghost.device)
+        d_own.index_add_(0, ctx.idx, back)
+        return d_own, None, None
+
+
+class HipBackend:
+    """Compute backend of the partitioned model: the HIP engine (default, GPU only)."""
+
+    def prepare(self, edge_index, n_local):
+        from . import ops
+        return ops.Topology(edge_index, n_local)
+
+    def mlp(self, module, x):
+        return module(x)
+
+    def order_edges(self, edge_attr, ctx):
+        return edge_attr[ctx.perm_dst.long()]
+
+    def block(self, block, x, e, ctx):
+        from . import ops
+        from .layers import _block_params
+        return ops.ProcessorFunction.apply(x, e, ctx, 1, *_block_params(block))
+
+
+class PartitionedEPD(torch.nn.Module):
+    """EncodeProcessDecode over a node-partitioned mesh.  Each rank holds its owned nodes,
+    the ghost sources of its edges, and the edges whose destination it owns; results on the
+    owned nodes equal the un-partitioned forward / backward (the parity oracle of section 8e).
+
+    forward(x_in_own[n_own,F_n], edge_attr_loc[E_loc,F_e]) -> out_own[n_own,O]
+    """
+
+    def __init__(self, model, plan, group=None, backend=None):
+        super().__init__()
+        self.model, self.plan, self.group = model, plan, group
+        self.backend = backend if backend is not None else HipBackend()
+        self._ctx = None
+
+    def forward(self, x_in_own: torch.Tensor, edge_attr_loc: torch.Tensor) -> torch.Tensor:
+        plan, be, m = self.plan, self.backend, self.model
+        dev = x_in_own.device
+        if self._ctx is None:
+            self._ctx = be.prepare(plan.edge_index.to(dev), plan.n_own + plan.n_ghost)
+        x_own = be.mlp(m.nodes_encoder, x_in_own)
+        e = be.mlp(m.edges_encoder, be.order_edges(edge_attr_loc, self._ctx))
+        for blk in m.processor_list:
+            x_gh = HaloExchange.apply(x_own, plan, self.group)
+            x_full = torch.cat([x_own, x_gh], dim=0)
+            x_full, e = be.block(blk, x_full, e, self._ctx)
+            x_own = x_full[: plan.n_own]
+        return be.mlp(m.decode_module, x_own)
+
+
+def partitioned_loss(net_out_own, target_own, node_type_own, group=None):
+    """Masked L2 over ALL ranks' NORMAL|OUTFLOW nodes (same value on every rank); its local
+    gradient, SUMMED over ranks (GradAllReduce(average=False)), is the global gradient."""
+    from .nodetype import NodeType
+    mask = (node_type_own == int(NodeType.NORMAL)) | (node_type_own == int(NodeType.OUTFLOW))
+    w = mask.to(net_out_own.dtype).unsqueeze(1)
+    num = ((net_out_own - target_own) ** 2 * w).sum()
+    cnt = (w.sum() * net_out_own.shape[1]).detach()
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(cnt, group=group)
+    return num / cnt

@@ -1,0 +1,165 @@
+"""CPU, world_size 2, gloo: the N>1 paths.
+  * data-parallel replicas: one flat gradient all-reduce per step (bench.py --gpus N);
+  * node-partitioned mesh with one-hop halo exchange: forward AND gradients equal the
+    un-partitioned oracle (the parity oracle of the partitioned path).
+No GPU here, so the partitioned model runs on an injected oracle compute backend -- the
+halo / partition / collective logic under test is the product's own."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import recipe as R
+from oracle import mgn_oracle as O
+
+
+class OracleBackend:
+    """tests-only compute backend: blocks / MLPs evaluated by the CPU oracle"""
+
+    def prepare(self, edge_index, n_local):
+        return edge_index
+
+    @staticmethod
+    def _sd(module):
+        return {k: v for k, v in module.named_parameters()}
+
+    def mlp(self, module, x):
+        return O.mlp(x, self._sd(module), "")
+
+    def order_edges(self, edge_attr, ctx):
+        return edge_attr
+
+    def block(self, block, x, e, ctx):
+        return O.graph_net_block(x, e, ctx, self._sd(block), "")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker_partition(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import graph_physics_amd as gp
+    from graph_physics_amd import distributed as D
+    from graph_physics_amd import partition as P
+
+    L, H, N, seed = 3, 32, 120, 5
+    pos, ei, ea = R.delaunay_graph(N, seed)
+    params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), seed)
+    x_in, e_in = R.randn((N, 11), 1), R.randn((ei.shape[1], 3), 2)
+    tgt = R.randn((N, 2), 3)
+    nt = torch.from_numpy((np.arange(N) % 3 == 0).astype(np.float32) * 5)  # OUTFLOW / NORMAL mix
+    part = P.rcb_partition(pos.numpy(), world)
+    plan = P.build_rank_plan(ei, part, rank, world)
+    net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H)
+    net.load_state_dict(params)
+    pm = D.PartitionedEPD(net, plan, backend=OracleBackend())
+    out = pm(x_in[plan.owned], e_in[plan.edge_ids])
+    loss = D.partitioned_loss(out, tgt[plan.owned], nt[plan.owned])
+    loss.backward()
+    D.GradAllReduce(average=False)(net.parameters())
+    grads = {k: v.grad.numpy().copy() for k, v in net.named_parameters()}  # by value: the worker exits first
+    q.put((rank, plan.owned.numpy().copy(), out.detach().numpy().copy(), float(loss.detach()), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partitioned_forward_backward_equals_unpartitioned():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_partition, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # un-partitioned oracle
+    L, H, N, seed = 3, 32, 120, 5
+    pos, ei, ea = R.delaunay_graph(N, seed)
+    params = {k: v.clone().requires_grad_(True) for k, v in R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), seed).items()}
+    x_in, e_in = R.randn((N, 11), 1), R.randn((ei.shape[1], 3), 2)
+    tgt = R.randn((N, 2), 3)
+    nt = torch.from_numpy((np.arange(N) % 3 == 0).astype(np.float32) * 5)
+    ref = O.epd_forward(x_in, e_in, ei, params, L)
+    ref_loss = O.l2_loss(ref, tgt, nt)
+    ref_loss.backward()
+    full = torch.zeros_like(ref)
+    total = 0.0
+    for rank, owned, out, loss, grads in res:
+        full[torch.from_numpy(owned)] = torch.from_numpy(out)
+        total += loss  # each rank holds its share of the global masked mean
+        for k, g in grads.items():
+            assert torch.allclose(torch.from_numpy(g), params[k].grad, rtol=2e-4, atol=1e-6), (rank, k)
+    assert abs(total - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
+    assert torch.allclose(full, ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_rcb_partition_and_plan():
+    from graph_physics_amd import partition as P
+
+    pos, ei, _ = R.delaunay_graph(1000, 9)
+    for k in (2, 3, 8):
+        part = P.rcb_partition(pos.numpy(), k)
+        sizes = np.bincount(part, minlength=k)
+        assert sizes.max() - sizes.min() <= 1
+        assert P.edge_cut(ei, part) < 0.25
+        plans = [P.build_rank_plan(ei, part, r, k) for r in range(k)]
+        assert sum(p.edge_ids.numel() for p in plans) == ei.shape[1]  # every edge lives on exactly one rank
+        assert sum(p.n_own for p in plans) == 1000
+        for p in plans:
+            assert int(p.edge_index[1].max()) < p.n_own  # destinations are owned
+            assert sum(p.recv_counts) == p.n_ghost and sum(p.send_counts) == p.send_idx.numel()
+            for qq in range(k):  # what I send to q is what q expects from me, in the same order
+                if qq == p.rank:
+                    continue
+                a = sum(p.send_counts[:qq])
+                mine = p.owned[p.send_idx[a:a + p.send_counts[qq]]]
+                b = sum(plans[qq].recv_counts[:p.rank])
+                theirs = plans[qq].ghost[b:b + plans[qq].recv_counts[p.rank]]
+                assert torch.equal(mine, theirs)
+
+
+def _worker_dp(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from graph_physics_amd import distributed as D
+
+    torch.manual_seed(rank)
+    lin = torch.nn.Linear(5, 3)
+    D.broadcast_parameters(lin)
+    w0 = lin.weight.detach().clone()
+    x = torch.full((4, 5), float(rank + 1))
+    lin(x).sum().backward()
+    D.GradAllReduce()(lin.parameters())
+    q.put((rank, w0.numpy().copy(), lin.weight.grad.numpy().copy(), lin.bias.grad.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_grad_allreduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_dp, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1])  # broadcast: same start weights
+    # grad wrt W of sum(lin(x)) = column sums of x: rank r gives 4*(r+1); average = 6
+    assert np.allclose(res[0][2], 6.0) and np.array_equal(res[0][2], res[1][2])
+    assert np.allclose(res[0][3], 4.0)
