@@ -525,34 +525,137 @@ __global__ void __launch_bounds__(1024) k_colred(const float* __restrict__ ws, i
 // chunk position ch ^ (j & 15) -- the swizzle goes on the DMA's per-lane SOURCE address (the
 // LDS destination of a DMA is lane-linear), and makes the rows a b128 lane group reads hit
 // different 4-bank groups (SQ_LDS_BANK_CONFLICT = 0).  One barrier per half-GEMM.
+#ifdef MGN_TIMELINE
+// debug build only (tools/): s_memtime stamps of wave 0 of a few workgroups
+__device__ unsigned long long g_timeline[8][512];
+__device__ int g_tlpos[8];
+#define TL_STAMP(tag)                                                                                  \
+  do {                                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 8) {                                                          \
+      int p_ = g_tlpos[blockIdx.x];                                                                    \
+      if (p_ < 512) {                                                                                  \
+        g_timeline[blockIdx.x][p_] = (__builtin_readcyclecounter() << 8) | (unsigned long long)(tag);  \
+        g_tlpos[blockIdx.x] = p_ + 1;                                                                  \
+      }                                                                                                \
+    }                                                                                                  \
+  } while (0)
+extern "C" int mgn_debug_timeline(unsigned long long* out, int* pos) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 8 * 512) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(pos, HIP_SYMBOL(g_tlpos), sizeof(int) * 8) != hipSuccess) return 1;
+  int z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tlpos), z, sizeof(z)) != hipSuccess;
+}
+#else
+#define TL_STAMP(tag) ((void)0)
+#endif
+#ifdef MGN_EXP_NOSYNC
+#define MGN_SYNC() ((void)0)
+#else
+#define MGN_SYNC() __syncthreads()
+#endif
+// arr[i] for a small kernel-argument pointer array WITHOUT a dynamic (SMEM) load: every
+// element is read with a constant index (hoisted to SGPRs once) and picked by a select
+// chain.  A scalar load inside the GEMM loop is poison: SMEM returns out of order, so while
+// one is pending hipcc turns every LDS wait into s_waitcnt lgkmcnt(0) and the LDS operand
+// prefetch ring stops overlapping (measured 63 % vs 91 % MFMA-busy).
+template <typename T>
+__device__ __forceinline__ T pick3(T a0, T a1, T a2, int i) {
+  T r = a0;
+  r = (i == 1) ? a1 : r;
+  r = (i == 2) ? a2 : r;
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ T pick4(T a0, T a1, T a2, T a3, int i) {
+  T r = pick3(a0, a1, a2, i);
+  r = (i == 3) ? a3 : r;
+  return r;
+}
+#define LDS_MAX_NL 4
+
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
 #define WBUF_BYTES 32768
 
-// half hk (0/1) of the 128 x 128 block W (leading dimension ldw) -> 32 KB LDS buffer.
-// Instruction q = 8*wv+i fills rows 4q..4q+3 (1 KB, lane-linear): lane -> row 4q + lane/16,
-// chunk position lane%16 holding global chunk (lane%16) ^ (row%16).  With row%16 =
-// 4*(i%4) + lane/16 the per-lane part of the address takes only 4 values, so each DMA is
-// (wave-uniform SGPR base) + (one of 4 precomputed 32-bit lane offsets): no 64-bit VALU,
-// nothing to spill, and the 8 DMAs issue back to back.
-__device__ __forceinline__ void dma_weights(const float* __restrict__ Wk, int ldw, int hk, lds_char* buf, int wv, int lane) {
+// One LDS-DMA of 1 KB: lane L fetches 16 bytes at sbase + voff(L) into LDS byte
+// lds_addr + 16*L.  Written in inline asm on purpose: hipcc models a pending
+// __builtin_amdgcn_global_load_lds as a FLAT access that also occupies the LGKM counter, and
+// with mixed event types pending it degrades EVERY LDS wait to s_waitcnt lgkmcnt(0) -- the
+// ds_read operand ring of the GEMM then stops overlapping (63 % vs 91 % MFMA-busy).  Hidden
+// in asm the DMA is invisible to that bookkeeping; the price is that WE must drain it
+// (dma_drain) before the barrier that publishes the buffer.  M0 (the DMA's LDS base) is
+// compiler-reserved: saved, set and restored inside the one statement.
+__device__ __forceinline__ void glds16(const float* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr)
+      : "memory");
+}
+// make a (really) wave-uniform pointer PROVABLY uniform, so that it may bind to an "s" operand
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Counted drain: called right after a half-GEMM, whose VMEM order is DMA pieces 0..7 (steps
+// 0..7) interleaved with the 4*MT "next tensor" loads, of which the last 2*MT (blocks 2 and 3,
+// steps 11 and 15) are YOUNGER than every DMA piece.  vmcnt counts in issue order, so
+// allowing 2*MT outstanding operations guarantees all DMA pieces have landed while the
+// youngest prefetch loads stay in flight across the barrier.  Must be called before any
+// further VMEM operation is issued (more young operations would only over-wait, fewer would
+// under-wait -- there are never fewer: the loads are issued unconditionally).
+template <int N>
+__device__ __forceinline__ void dma_drain_counted() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ unsigned lds_addr_of(lds_char* p) { return (unsigned)(size_t)p; }
+
+// The next half's weight DMA, issued one 1 KB instruction every other GEMM step instead of
+// eight back to back: a burst stalls the issuing wave for 1.2-4.2k cycles on VMEM
+// back-pressure (s_memtime timeline), spread out it rides under the MFMAs.
+struct DmaJob {
+  const float* su0;   // wave-uniform: first row of this wave's share, column offset included
+  int stride;         // floats between consecutive instructions' rows (4 * ldw)
+  unsigned lds0;      // LDS byte address of this wave's first instruction
+  unsigned vo[4];     // per-lane byte offsets (see dma_prepare)
+  bool on;
+};
+__device__ __forceinline__ DmaJob dma_prepare(const float* __restrict__ Wk, int ldw, int hk, lds_char* buf, int wv, int lane, bool on) {
+  // Instruction i of wave wv fills rows 4q..4q+3, q = 8*wv+i (1 KB, lane-linear): lane -> row
+  // 4q + lane/16, chunk position lane%16 holding global chunk (lane%16) ^ (row%16).  With
+  // row%16 = 4*(i%4) + lane/16 the per-lane part of the address takes only 4 values.
+  DmaJob j;
   const int lg = lane >> 4, bg = (lane & 15) ^ lg;
-  int vo[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) vo[j] = lg * ldw + 4 * (bg ^ (4 * j));
+  for (int k = 0; k < 4; ++k) j.vo[k] = 4u * (unsigned)(lg * ldw + 4 * (bg ^ (4 * k)));
+  j.su0 = uniform_ptr(Wk + (size_t)(32 * wv) * ldw + 64 * hk);
+  j.stride = 4 * ldw;
+  j.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(buf)) + 8 * wv * 1024;
+  j.on = on;
+  return j;
+}
+__device__ __forceinline__ void dma_issue(const DmaJob& j, int i) {
+  if (j.on) glds16(j.su0 + (size_t)i * j.stride, j.vo[i & 3], j.lds0 + i * 1024);
+}
+__device__ __forceinline__ void dma_weights(const float* __restrict__ Wk, int ldw, int hk, lds_char* buf, int wv, int lane) {
+  const DmaJob j = dma_prepare(Wk, ldw, hk, buf, wv, lane, true);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int q = 8 * wv + i;
-    const float* su = Wk + (size_t)(4 * q) * ldw + 64 * hk;  // wave-uniform
-    __builtin_amdgcn_global_load_lds((g_cfloat*)(su + vo[i & 3]), buf + q * 1024, 16, 0, 0);
-  }
+  for (int i = 0; i < 8; ++i) dma_issue(j, i);
 }
 
-// acc += W[:, 64*hk .. 64*hk+63](LDS) * in[4*hk .. 4*hk+3]; the consumed input blocks are
-// refilled from nxt (prefetch of the next tensor, see gemm_full).
+// acc += W[:, 64*HK .. 64*HK+63](LDS) * in[4*HK .. 4*HK+3]; the consumed input blocks are
+// refilled from nxt (prefetch of the next tensor, see gemm_full); `job` = the DMA of the half
+// after this one, interleaved.
 template <int MT, int HK>
 __device__ __forceinline__ void gemm_lds_half(f32x4 (&acc)[MT][8], f32x4 (&in)[MT][8], lds_char* wbuf,
-                                              const int (&off)[4], const float* const (&nxt)[MT]) {
+                                              const int (&off)[4], const float* const (&nxt)[MT], const DmaJob& job) {
   constexpr int NI = 4, NS = 16;
   f32x4 w[2][2];
 #pragma unroll
@@ -565,6 +668,7 @@ __device__ __forceinline__ void gemm_lds_half(f32x4 (&acc)[MT][8], f32x4 (&in)[M
 #pragma unroll
       for (int q = 0; q < 2; ++q) w[s2 & 1][q] = *(lds_cf32x4*)(wbuf + off[kb2] + (ib2 + q) * 4096);
     }
+    if (s < 8) dma_issue(job, s);  // early in the half: the last piece gets >= 8 steps to land
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -581,117 +685,192 @@ __device__ __forceinline__ void gemm_lds_half(f32x4 (&acc)[MT][8], f32x4 (&in)[M
   }
 }
 
+// Persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ... as ONE continuous stream of
+// half-GEMMs.  The weight DMA ring keeps rolling across tile boundaries, the last GEMM of a
+// tile prefetches the next tile's phase-0 rows, gather indices are fetched a tile ahead, and
+// biases / norm scale live in LDS -- so between two GEMMs a wave only does register work.
+// LDS: [2 x 32 KB weight halves][b0..b3, scale: 5 x 512 B].
+#define FWD_LDS_BYTES (2 * WBUF_BYTES + 5 * 512)
 template <int MT>
 __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a) {
   constexpr int HB = 8, H = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* wl = (lds_char*)smem;
+  lds_char* cst = wl + 2 * WBUF_BYTES;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, g = lane >> 4;
-  const long row0 = ((long)blockIdx.x * 4 + wv) * (16 * MT);
-  long mm[MT];
-  bool valid[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    const long m = row0 + 16 * t + c;
-    valid[t] = m < a.M;
-    mm[t] = valid[t] ? m : a.M - 1;  // waves past M still take part in the DMA / barriers
-  }
+  const long ntiles = (a.M + 64 * MT - 1) / (64 * MT);
+  long tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  const long my_tiles = (ntiles - tile + gridDim.x - 1) / gridDim.x;
   int off[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) off[j] = c * 256 + (((4 * j + g) ^ c) & 15) * 16;
 
-  const int G = a.nphase + a.NL - 1;  // GEMMs: the phases of layer 0, then layers 1..NL-1
+  const int G = a.nphase + a.NL - 1;  // GEMMs per tile: the phases of layer 0, then layers 1..NL-1
   const int ktot = H * a.nphase;
-  auto wsrc = [&](int k, const float*& Wk, int& ldw) {
-    if (k < a.nphase) {
-      Wk = a.W[0] + H * k;
-      ldw = ktot;
-    } else {
-      Wk = a.W[k - a.nphase + 1];
-      ldw = H;
+  const long total_halves = my_tiles * 2 * G;
+  // kernel-argument pointers in SGPRs, picked by select chains (no SMEM in the loop)
+  const float *W0 = a.W[0], *W1 = a.W[1], *W2 = a.W[2], *W3 = a.W[3];
+  float *sH0 = a.saveH[0], *sH1 = a.saveH[1], *sH2 = a.saveH[2];
+  const float *src0 = a.src[0], *src1 = a.src[1], *src2 = a.src[2];
+  const int32_t *idx0 = a.idx[0], *idx1 = a.idx[1], *idx2 = a.idx[2];
+  auto job_for = [&](long j) -> DmaJob {  // DMA of half j of this workgroup's stream -> buffer j&1
+    const int jj = (int)(j % (2 * G)), k = jj >> 1;
+    const float* Wk = (k < a.nphase) ? W0 + H * k : pick4(W0, W1, W2, W3, k - a.nphase + 1);
+    const int ldw = (k < a.nphase) ? ktot : H;
+    return dma_prepare(Wk, ldw, jj & 1, wl + (j & 1) * WBUF_BYTES, wv, lane, j < total_halves);
+  };
+  {
+    const DmaJob j0 = job_for(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_issue(j0, i);
+  }
+  // biases and scale -> LDS (zeros where absent)
+  for (int i = threadIdx.x; i < 5 * H; i += 256) {
+    const int l = i >> 7, jx = i & 127;
+    const float* bp = (l == 4) ? a.scale : pick4(a.b[0], a.b[1], a.b[2], a.b[3], l);
+    ((__attribute__((address_space(3))) float*)cst)[i] = (bp != nullptr && (l == 4 || l < a.NL)) ? bp[jx] : 0.f;
+  }
+  auto lds_bias = [&](f32x4 (&acc)[MT][HB], int l) {
+#pragma unroll
+    for (int ib = 0; ib < HB; ++ib) {
+      const f32x4 bv = *(lds_cf32x4*)(cst + l * 512 + 64 * ib + 16 * g);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][ib] = bv;
     }
   };
-  auto dma_half = [&](int j) {  // half j&1 of GEMM j>>1 -> buffer j&1
-    const float* Wk;
-    int ldw;
-    wsrc(j >> 1, Wk, ldw);
-    dma_weights(Wk, ldw, j & 1, wl + (j & 1) * WBUF_BYTES, wv, lane);
+
+  // rows of a tile and their (gathered) source rows per phase
+  auto rows_of = [&](long tl, long (&mm)[MT], bool (&valid)[MT], int (&rid)[MGN_MAX_PHASES][MT]) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const long m = (tl * 4 + wv) * (16 * MT) + 16 * t + c;
+      valid[t] = m < a.M;
+      mm[t] = valid[t] ? m : a.M - 1;  // waves past M still take part in the DMA / barriers
+      rid[0][t] = idx0 ? idx0[mm[t]] : (int)mm[t];
+      rid[1][t] = (a.nphase > 1) ? (idx1 ? idx1[mm[t]] : (int)mm[t]) : 0;
+      rid[2][t] = (a.nphase > 2) ? (idx2 ? idx2[mm[t]] : (int)mm[t]) : 0;
+    }
   };
-  dma_half(0);
-  dma_half(1);
+  long mm[MT];
+  bool valid[MT];
+  int rid[MGN_MAX_PHASES][MT];
+  rows_of(tile, mm, valid, rid);
   f32x4 in[MT][HB], acc[MT][HB];
   const float* dummy[MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) dummy[t] = a.W[0] + 4 * g;
-  init_bias<HB, MT>(acc, a.b[0], HB, g);
-  int nkb;
-  load_tl<HB, MT, false>(in, a.src[0], a.idx[0], H, mm, g, nkb);
+  for (int t = 0; t < MT; ++t) dummy[t] = W0 + 4 * g;
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int kb = 0; kb < HB; ++kb) in[t][kb] = ld4(src0 + (long)rid[0][t] * H + 4 * g + 16 * kb);
+  dma_drain();      // prologue burst of half 0 (and the first input rows)
+  __syncthreads();  // constants visible
 
-  for (int k = 0; k < G; ++k) {
-    const float* nx[MT];
+  long j = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long ntile = tile + gridDim.x;
+    const bool has_next = ntile < ntiles;
+    long mmn[MT];
+    bool validn[MT];
+    int ridn[MGN_MAX_PHASES][MT];
+    rows_of(has_next ? ntile : tile, mmn, validn, ridn);  // index loads land a tile ahead of use
+    TL_STAMP(1);
+    lds_bias(acc, 0);
+    f32x4 rs[MT][HB];  // residual rows, fetched under the last half-GEMM
+    for (int k = 0; k < G; ++k) {
+      const float* nx[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) nx[t] = dummy[t];
-    if (k < a.nphase) {
-      if (k + 1 < a.nphase) {  // prefetch the gathered rows of the next phase
-        const float* sp = a.src[k + 1];
-        const int32_t* ip = a.idx[k + 1];
+      for (int t = 0; t < MT; ++t) nx[t] = dummy[t];
+      if (k < a.nphase) {
+        if (k + 1 < a.nphase) {  // prefetch the gathered rows of the next phase
+          const float* sp = pick3(src0, src1, src2, k + 1);
 #pragma unroll
-        for (int t = 0; t < MT; ++t) nx[t] = sp + (ip ? (long)ip[mm[t]] : mm[t]) * H + 4 * g;
+          for (int t = 0; t < MT; ++t) nx[t] = sp + (long)((k == 0) ? rid[1][t] : rid[2][t]) * H + 4 * g;
+        }
+      } else {  // layer l >= 1: operand = ReLU(previous accumulator)
+        const int l = k - a.nphase + 1;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) in[t][ib][r] = fmaxf(acc[t][ib][r], 0.f);
+        float* sh = pick3(sH0, sH1, sH2, l - 1);
+        if (sh != nullptr) store_tl<HB, MT, false>(sh, in, H, mm, valid, g);
+        lds_bias(acc, l);
       }
-    } else {  // layer l >= 1: operand = ReLU(previous accumulator)
-      const int l = k - a.nphase + 1;
+      if (k == G - 1 && has_next) {  // last GEMM of the tile: pull in the next tile's phase-0 rows
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
+        for (int t = 0; t < MT; ++t) nx[t] = src0 + (long)ridn[0][t] * H + 4 * g;
+      }
+      TL_STAMP(2);
+      // barrier: this half's weights landed (own DMA drained right after the previous
+      // half-GEMM, now everyone's) and every wave is done reading the other buffer, which the
+      // DMA riding under this half-GEMM overwrites
+      __syncthreads();
+      TL_STAMP(4);
+      {
+        const DmaJob job = job_for(j + 1);
+        gemm_lds_half<MT, 0>(acc, in, wl + (j & 1) * WBUF_BYTES, off, nx, job);
+      }
+      dma_drain_counted<2 * MT>();
+      TL_STAMP(6);
+      ++j;
+      if (k == G - 1 && a.resid != nullptr) { int nk_; load_tl<HB, MT, false>(rs, a.resid, nullptr, H, mm, g, nk_); }
+      __syncthreads();
+      TL_STAMP(4);
+      {
+        const DmaJob job = job_for(j + 1);
+        gemm_lds_half<MT, 1>(acc, in, wl + (j & 1) * WBUF_BYTES, off, nx, job);
+      }
+      dma_drain_counted<2 * MT>();
+      TL_STAMP(7);
+      ++j;
+    }
+    // ---- epilogue: RMSNorm (reference epsilon placement), residual, stores.  `in` already holds
+    //      the next tile's rows and is not touched.
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      float inv = 1.f;
+      if (a.scale != nullptr) {
+        float ss = 0.f;
 #pragma unroll
         for (int ib = 0; ib < HB; ++ib)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) in[t][ib][r] = fmaxf(acc[t][ib][r], 0.f);
-      if (a.saveH[l - 1] != nullptr) store_tl<HB, MT, false>(a.saveH[l - 1], in, H, mm, valid, g);
-      init_bias<HB, MT>(acc, a.b[l], HB, g);
+          for (int r = 0; r < 4; ++r) ss = fmaf(acc[t][ib][r], acc[t][ib][r], ss);
+        ss = rowsum4(ss);
+        const float rms = sqrtf(ss) / sqrtf((float)H);
+        inv = 1.0f / (rms + a.eps);  // one reciprocal per row; u = z * inv (<= 1 ulp from z / den)
+        if (a.saveR != nullptr && valid[t] && g == 0) st1(a.saveR + mm[t], rms);
+      }
+      if (valid[t]) {
+        const long ro = mm[t] * H + 4 * g;
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib) {
+          f32x4 y = acc[t][ib];
+          if (a.scale != nullptr) {
+            const f32x4 u = y * inv;
+            if (a.saveU != nullptr) st4(a.saveU + ro + 16 * ib, u);
+            y = *(lds_cf32x4*)(cst + 4 * 512 + 64 * ib + 16 * g) * u;
+          }
+          if (a.y_out != nullptr) st4(a.y_out + ro + 16 * ib, y);
+          if (a.resid != nullptr) y = rs[t][ib] + y;
+          st4(a.out + ro + 16 * ib, y);
+        }
+      }
     }
-    // barrier: this half's weights landed (DMA issued one half ago) and every wave is done
-    // reading the other buffer, which the next DMA may now overwrite
-    __syncthreads();
-    if (k >= 1) dma_half(2 * k + 1);
-    gemm_lds_half<MT, 0>(acc, in, wl, off, nx);
-    __syncthreads();
-    if (k + 1 < G) dma_half(2 * k + 2);
-    gemm_lds_half<MT, 1>(acc, in, wl + WBUF_BYTES, off, nx);
-  }
-  // ---- epilogue: RMSNorm (reference epsilon placement), residual, stores
-  if (a.scale != nullptr) {
-    const float sqrt_d = sqrtf((float)H);
+    TL_STAMP(8);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      float ss = 0.f;
+      mm[t] = mmn[t];
+      valid[t] = validn[t];
 #pragma unroll
-      for (int ib = 0; ib < HB; ++ib)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ss = fmaf(acc[t][ib][r], acc[t][ib][r], ss);
-      ss = rowsum4(ss);
-      const float rms = sqrtf(ss) / sqrt_d;
-      const float den = rms + a.eps;
-#pragma unroll
-      for (int ib = 0; ib < HB; ++ib)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) in[t][ib][r] = acc[t][ib][r] / den;
-      if (a.saveR != nullptr && valid[t] && g == 0) st1(a.saveR + mm[t], rms);
-#pragma unroll
-      for (int ib = 0; ib < HB; ++ib) acc[t][ib] = ld4(a.scale + 16 * ib + 4 * g) * in[t][ib];
+      for (int p = 0; p < MGN_MAX_PHASES; ++p) rid[p][t] = ridn[p][t];
     }
-    if (a.saveU != nullptr) store_tl<HB, MT, false>(a.saveU, in, H, mm, valid, g);
   }
-  if (a.y_out != nullptr) store_tl<HB, MT, false>(a.y_out, acc, H, mm, valid, g);
-  if (a.resid != nullptr) {
-    load_tl<HB, MT, false>(in, a.resid, nullptr, H, mm, g, nkb);
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-      for (int ib = 0; ib < HB; ++ib) acc[t][ib] = in[t][ib] + acc[t][ib];
-  }
-  store_tl<HB, MT, false>(a.out, acc, H, mm, valid, g);
 }
 
 template <int MT>
@@ -719,12 +898,21 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bwd_lds(const mgn_mlp_bwd_args a
 #pragma unroll
   for (int j = 0; j < 4; ++j) off[j] = c * 256 + (((4 * j + g) ^ c) & 15) * 16;
   const int G = (a.NL - 1) + a.n_din;  // chain GEMMs (WT[NL-1]..WT[1]) then the input-grad GEMMs
-  auto wsrc = [&](int k) -> const float* { return (k < a.NL - 1) ? a.WT[a.NL - 1 - k] : a.WT0[k - (a.NL - 1)]; };
-  auto dma_half = [&](int j) { dma_weights(wsrc(j >> 1), H, j & 1, wl + (j & 1) * WBUF_BYTES, wv, lane); };
-  if (G > 0) {
-    dma_half(0);
-    dma_half(1);
-  }
+  // pointer tables in SGPRs (see pick())
+  const float *WT1 = a.WT[1], *WT2 = a.WT[2], *WT3 = a.WT[3];
+  const float *WT00 = a.WT0[0], *WT01 = a.WT0[1], *WT02 = a.WT0[2];
+  const float *Hs0 = a.Hs[0], *Hs1 = a.Hs[1], *Hs2 = a.Hs[2];
+  float *dZ0 = a.dZ[0], *dZ1 = a.dZ[1], *dZ2 = a.dZ[2], *dZ3 = a.dZ[3];
+  float *db0 = a.db[0], *db1 = a.db[1], *db2 = a.db[2], *db3 = a.db[3];
+  const float *dr0 = a.din_resid[0], *dr1 = a.din_resid[1], *dr2 = a.din_resid[2];
+  float *dI0 = a.dIn[0], *dI1 = a.dIn[1], *dI2 = a.dIn[2];
+  auto wsrc = [&](int k) -> const float* {
+    return (k < a.NL - 1) ? pick4(WT1, WT1, WT2, WT3, a.NL - 1 - k) : pick3(WT00, WT01, WT02, k - (a.NL - 1));
+  };
+  auto job_for = [&](int j) -> DmaJob {
+    return dma_prepare(wsrc((j < 2 * G) ? (j >> 1) : 0), H, j & 1, wl + (j & 1) * WBUF_BYTES, wv, lane, j < 2 * G);
+  };
+  if (G > 0) dma_weights(wsrc(0), H, 0, wl, wv, lane);
 
   f32x4 dz[MT][HB], acc[MT][HB];
   int nkb;
@@ -765,8 +953,8 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bwd_lds(const mgn_mlp_bwd_args a
     }
     if (a.dscale != nullptr) colsum_to_lds<HB, MT>(lds_w + a.NL * H, du, c, g);
   }
-  if (a.dZ[a.NL - 1] != nullptr) store_tl<HB, MT, false>(a.dZ[a.NL - 1], dz, H, mm, valid, g);
-  if (a.db[a.NL - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (a.NL - 1) * H, dz, c, g);
+  if (pick4(dZ0, dZ1, dZ2, dZ3, a.NL - 1) != nullptr) store_tl<HB, MT, false>(pick4(dZ0, dZ1, dZ2, dZ3, a.NL - 1), dz, H, mm, valid, g);
+  if (pick4(db0, db1, db2, db3, a.NL - 1) != nullptr) colsum_to_lds<HB, MT>(lds_w + (a.NL - 1) * H, dz, c, g);
 
   for (int k = 0; k < G; ++k) {
     const bool chain = k < a.NL - 1;
@@ -778,27 +966,35 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bwd_lds(const mgn_mlp_bwd_args a
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* hs = pick3(Hs0, Hs1, Hs2, l - 1);
 #pragma unroll
-      for (int t = 0; t < MT; ++t) nx[t] = a.Hs[l - 1] + mm[t] * H + 4 * g;  // dz <- h_l on the way out
+      for (int t = 0; t < MT; ++t) nx[t] = hs + mm[t] * H + 4 * g;  // dz <- h_l on the way out
     } else {
-      if (a.din_resid[q] != nullptr) {
-        load_tl<HB, MT, false>(acc, a.din_resid[q], nullptr, H, mm, g, nkb);
+      const float* dr = pick3(dr0, dr1, dr2, q);
+      if (dr != nullptr) {
+        load_tl<HB, MT, false>(acc, dr, nullptr, H, mm, g, nkb);
       } else {
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
           for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      const float* base = (a.dZ[0] != nullptr) ? a.dZ[0] : a.WT0[q];  // re-read dZ[0]: dz keeps its value
+      const float* base = (dZ0 != nullptr) ? dZ0 : WT00;  // re-read dZ[0]: dz keeps its value
 #pragma unroll
-      for (int t = 0; t < MT; ++t) nx[t] = base + ((a.dZ[0] != nullptr) ? mm[t] * H : 0) + 4 * g;
+      for (int t = 0; t < MT; ++t) nx[t] = base + ((dZ0 != nullptr) ? mm[t] * H : 0) + 4 * g;
     }
+    dma_drain();
     __syncthreads();
-    if (k >= 1) dma_half(2 * k + 1);
-    gemm_lds_half<MT, 0>(acc, dz, wl, off, nx);
+    {
+      const DmaJob job = job_for(2 * k + 1);
+      gemm_lds_half<MT, 0>(acc, dz, wl, off, nx, job);
+    }
+    dma_drain();
     __syncthreads();
-    if (k + 1 < G) dma_half(2 * k + 2);
-    gemm_lds_half<MT, 1>(acc, dz, wl + WBUF_BYTES, off, nx);
+    {
+      const DmaJob job = job_for(2 * k + 2);
+      gemm_lds_half<MT, 1>(acc, dz, wl + WBUF_BYTES, off, nx, job);
+    }
     if (chain) {
 #pragma unroll
       for (int t = 0; t < MT; ++t)
@@ -806,10 +1002,11 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bwd_lds(const mgn_mlp_bwd_args a
         for (int ib = 0; ib < HB; ++ib)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dz[t][ib][r] = (valid[t] && dz[t][ib][r] > 0.f) ? acc[t][ib][r] : 0.f;
-      if (a.dZ[l - 1] != nullptr) store_tl<HB, MT, false>(a.dZ[l - 1], dz, H, mm, valid, g);
-      if (a.db[l - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
+      float* dzp = pick3(dZ0, dZ1, dZ2, l - 1);
+      if (dzp != nullptr) store_tl<HB, MT, false>(dzp, dz, H, mm, valid, g);
+      if (pick3(db0, db1, db2, l - 1) != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
     } else {
-      store_tl<HB, MT, false>(a.dIn[q], acc, H, mm, valid, g);
+      store_tl<HB, MT, false>(pick3(dI0, dI1, dI2, q), acc, H, mm, valid, g);
     }
   }
   __syncthreads();
@@ -924,7 +1121,8 @@ __device__ __forceinline__ void dma_rows(const float* __restrict__ X, long row0,
     long row = row0 + r;
     row = row < M ? row : M - 1;  // tail rows are masked at the MFMA
     const int gch = (lane & 31) ^ (4 * (r & 1));
-    __builtin_amdgcn_global_load_lds((g_cfloat*)(X + row * 128 + 4 * gch), buf + q * 1024, 16, 0, 0);
+    const unsigned voff = (unsigned)((row - row0) * 512 + 16 * gch);  // bytes from the tile's first row
+    glds16(uniform_ptr(X + row0 * 128), voff, __builtin_amdgcn_readfirstlane(lds_addr_of(buf)) + q * 1024);
   }
 }
 
@@ -955,6 +1153,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
   }
   for (long tile = t0; tile < t1; ++tile) {
     const int buf = (int)((tile - t0) & 1);
+    dma_drain();
     __syncthreads();  // tile landed; the other buffer is free again
     if (tile + 1 < t1) {
       lds_char* nb = sm + (buf ^ 1) * 2 * WG_TILE_BYTES;
@@ -1177,7 +1376,7 @@ static bool fwd_ragged(const mgn_mlp_fwd_args& a) {
 
 static MlpPlan plan_mlp(int64_t M, int H, int NL, bool ragged, bool bwd) {
   MlpPlan p;
-  p.lds = (H == 128) && !ragged && NL >= 2 && NL <= 6;
+  p.lds = (H == 128) && !ragged && NL >= 2 && NL <= LDS_MAX_NL;
   if (getenv("MGN_NO_LDS") != nullptr) p.lds = false;
   p.mt = (M >= (int64_t)64 * 2048) ? 2 : 1;
   // measured on MI355X (tools/kbench.py, E = 180k): with LDS-shared weights the forward is
@@ -1186,7 +1385,9 @@ static MlpPlan plan_mlp(int64_t M, int H, int NL, bool ragged, bool bwd) {
   if (const char* e = getenv("MGN_MT")) p.mt = (atoi(e) == 2) ? 2 : 1;
   const int rows = 64 * p.mt;
   p.grid = (unsigned)((M + rows - 1) / rows);
-  p.smem = p.lds ? (size_t)2 * WBUF_BYTES + (bwd ? (size_t)4 * (NL + 1) * H * sizeof(float) : 0) : 0;
+  if (p.lds && !bwd && p.grid > 512) p.grid = 512;  // persistent: 2 workgroups per CU walk the tiles
+  if (const char* e = getenv("MGN_GRID")) { if (p.lds && !bwd && atoi(e) > 0 && (unsigned)atoi(e) < p.grid) p.grid = (unsigned)atoi(e); }
+  p.smem = p.lds ? (bwd ? (size_t)2 * WBUF_BYTES + (size_t)4 * (NL + 1) * H * sizeof(float) : (size_t)FWD_LDS_BYTES) : 0;
   return p;
 }
 
