@@ -74,6 +74,7 @@ class WgradJob(C.Structure):
         ("M", C.c_int64),
         ("lda", C.c_int), ("ldb", C.c_int), ("ldw", C.c_int),
         ("nja", C.c_int), ("nkb", C.c_int), ("kw", C.c_int),
+        ("db", _f32p),
     ]
 
 

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "mgn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -339,6 +340,20 @@ __device__ __forceinline__ void colsum_to_lds(float* lds_w, const f32x4 (&v)[MT]
 #pragma unroll
     for (int r = 0; r < 4; ++r) s[r] = colsum16(s[r]);
     if (c == 0) *(f32x4*)(lds_w + 16 * ib + 4 * g) = s;
+  }
+}
+
+// same, accumulating over the tiles a persistent wave walks (same-wave LDS ops are ordered)
+template <int HB, int MT>
+__device__ __forceinline__ void colsum_to_lds_add(float* lds_w, const f32x4 (&v)[MT][HB], int c, int g) {
+#pragma unroll
+  for (int ib = 0; ib < HB; ++ib) {
+    f32x4 s = v[0][ib];
+#pragma unroll
+    for (int t = 1; t < MT; ++t) s += v[t][ib];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = colsum16(s[r]);
+    if (c == 0) *(f32x4*)(lds_w + 16 * ib + 4 * g) += s;
   }
 }
 
@@ -873,140 +888,211 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a
   }
 }
 
+// Backward chain, persistent like the forward: a workgroup walks its tiles as one stream of
+// half-GEMMs.  While a tile computes, the NEXT tile's operands are already on their way:
+// its dOut rows refill dz under the last GEMM, its U rows / gathered dOut2 rows / rms are
+// loaded into spare registers right after the current ones were consumed.  dscale is summed
+// per lane across all tiles of the workgroup and reduced across lanes once at the end; bias
+// gradients (column sums of dZ) are left to the weight-gradient kernel, where dZ is read in
+// N-layout anyway (2 adds per 16 MFMAs there versus 128 shuffles per tile here) -- db[] is
+// still honoured (slow path) when a caller asks for it.
+// LDS: [2 x 32 KB weight halves][scale 512 B][4 waves x nslot x 512 B column-sum partials].
 template <int MT>
 __global__ void __launch_bounds__(256, 2) k_mlp_bwd_lds(const mgn_mlp_bwd_args a) {
   constexpr int HB = 8, H = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* wl = (lds_char*)smem;
-  float* lds = (float*)(smem + 2 * WBUF_BYTES);  // [4 waves][nslot][H] column-sum partials
+  lds_char* cst = wl + 2 * WBUF_BYTES;                          // scale
+  float* lds = (float*)(smem + 2 * WBUF_BYTES + 512);           // [4 waves][nslot][H]
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, g = lane >> 4;
-  const long row0 = ((long)blockIdx.x * 4 + wv) * (16 * MT);
   const int nslot = a.NL + 1;
   float* lds_w = lds + wv * nslot * H;
   for (int i = lane; i < nslot * H; i += 64) lds_w[i] = 0.f;
-  long mm[MT];
-  bool valid[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    const long m = row0 + 16 * t + c;
-    valid[t] = m < a.M;
-    mm[t] = valid[t] ? m : a.M - 1;
-  }
+  for (int i = threadIdx.x; i < H; i += 256)
+    ((__attribute__((address_space(3))) float*)cst)[i] = (a.scale != nullptr) ? a.scale[i] : 0.f;
+  const long ntiles = (a.M + 64 * MT - 1) / (64 * MT);
+  long tile = blockIdx.x;
+  const long my_tiles = (tile < ntiles) ? (ntiles - tile + gridDim.x - 1) / gridDim.x : 0;
   int off[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) off[j] = c * 256 + (((4 * j + g) ^ c) & 15) * 16;
-  const int G = (a.NL - 1) + a.n_din;  // chain GEMMs (WT[NL-1]..WT[1]) then the input-grad GEMMs
-  // pointer tables in SGPRs (see pick())
+  const int G = (a.NL - 1) + a.n_din;  // per tile: chain GEMMs (WT[NL-1]..WT[1]) then the input-grad GEMM
+  const long total_halves = my_tiles * 2 * G;
+  // kernel-argument pointers in SGPRs, picked by select chains (no SMEM in the loop)
   const float *WT1 = a.WT[1], *WT2 = a.WT[2], *WT3 = a.WT[3];
-  const float *WT00 = a.WT0[0], *WT01 = a.WT0[1], *WT02 = a.WT0[2];
+  const float* WT00 = a.WT0[0];
   const float *Hs0 = a.Hs[0], *Hs1 = a.Hs[1], *Hs2 = a.Hs[2];
   float *dZ0 = a.dZ[0], *dZ1 = a.dZ[1], *dZ2 = a.dZ[2], *dZ3 = a.dZ[3];
   float *db0 = a.db[0], *db1 = a.db[1], *db2 = a.db[2], *db3 = a.db[3];
-  const float *dr0 = a.din_resid[0], *dr1 = a.din_resid[1], *dr2 = a.din_resid[2];
-  float *dI0 = a.dIn[0], *dI1 = a.dIn[1], *dI2 = a.dIn[2];
-  auto wsrc = [&](int k) -> const float* {
-    return (k < a.NL - 1) ? pick4(WT1, WT1, WT2, WT3, a.NL - 1 - k) : pick3(WT00, WT01, WT02, k - (a.NL - 1));
+  const float* dr0 = a.din_resid[0];
+  float* dI0 = a.dIn[0];
+  auto job_for = [&](long j) -> DmaJob {
+    const int jj = (int)(j % (2 * G)), k = jj >> 1;
+    const float* Wk = (k < a.NL - 1) ? pick4(WT1, WT1, WT2, WT3, a.NL - 1 - k) : WT00;
+    return dma_prepare(Wk, H, jj & 1, wl + (j & 1) * WBUF_BYTES, wv, lane, j < total_halves);
   };
-  auto job_for = [&](int j) -> DmaJob {
-    return dma_prepare(wsrc((j < 2 * G) ? (j >> 1) : 0), H, j & 1, wl + (j & 1) * WBUF_BYTES, wv, lane, j < 2 * G);
-  };
-  if (G > 0) dma_weights(wsrc(0), H, 0, wl, wv, lane);
-
-  f32x4 dz[MT][HB], acc[MT][HB];
-  int nkb;
-  load_tl<HB, MT, false>(dz, a.dOut, nullptr, H, mm, g, nkb);
-  if (a.dOut2 != nullptr) {
-    load_tl<HB, MT, false>(acc, a.dOut2, a.idx2, H, mm, g, nkb);
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-      for (int ib = 0; ib < HB; ++ib) dz[t][ib] += acc[t][ib];
-  }
-#pragma unroll
-  for (int t = 0; t < MT; ++t)
-    if (!valid[t]) {
-#pragma unroll
-      for (int ib = 0; ib < HB; ++ib) dz[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  if (a.scale != nullptr) {  // RMSNorm backward (see k_mlp_bwd)
-    load_tl<HB, MT, false>(acc, a.U, nullptr, H, mm, g, nkb);
-    f32x4 du[MT][HB];
+  auto rows_of = [&](long tl, long (&mm)[MT], bool (&valid)[MT]) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      float dot = 0.f;
-#pragma unroll
-      for (int ib = 0; ib < HB; ++ib) {
-        du[t][ib] = dz[t][ib] * acc[t][ib];
-        const f32x4 gg = ld4(a.scale + 16 * ib + 4 * g) * dz[t][ib];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dot = fmaf(gg[r], acc[t][ib][r], dot);
-        dz[t][ib] = gg;
-      }
-      dot = rowsum4(dot);
-      const float rms = ld1(a.R + mm[t]);
-      const float inv = 1.0f / (rms + a.eps);
-      const float k2 = (rms > 0.f) ? dot / ((float)H * rms) : 0.f;
-#pragma unroll
-      for (int ib = 0; ib < HB; ++ib) dz[t][ib] = dz[t][ib] * inv - acc[t][ib] * k2;
+      const long m = (tl * 4 + wv) * (16 * MT) + 16 * t + c;
+      valid[t] = m < a.M;
+      mm[t] = valid[t] ? m : a.M - 1;
     }
-    if (a.dscale != nullptr) colsum_to_lds<HB, MT>(lds_w + a.NL * H, du, c, g);
-  }
-  if (pick4(dZ0, dZ1, dZ2, dZ3, a.NL - 1) != nullptr) store_tl<HB, MT, false>(pick4(dZ0, dZ1, dZ2, dZ3, a.NL - 1), dz, H, mm, valid, g);
-  if (pick4(db0, db1, db2, db3, a.NL - 1) != nullptr) colsum_to_lds<HB, MT>(lds_w + (a.NL - 1) * H, dz, c, g);
+  };
+  f32x4 dsum[HB];  // per-lane partial of dscale = sum_rows dY * U
+#pragma unroll
+  for (int ib = 0; ib < HB; ++ib) dsum[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int k = 0; k < G; ++k) {
-    const bool chain = k < a.NL - 1;
-    const int l = a.NL - 1 - k;  // chain: layer whose W^T is applied
-    const int q = k - (a.NL - 1);
-    const float* nx[MT];
-    if (chain) {
+  if (my_tiles > 0) {
+    {
+      const DmaJob j0 = job_for(0);
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
+      for (int i = 0; i < 8; ++i) dma_issue(j0, i);
+    }
+    long mm[MT];
+    bool valid[MT];
+    rows_of(tile, mm, valid);
+    f32x4 dz[MT][HB], acc[MT][HB], pu[MT][HB], pd2[MT][HB];
+    float prms[MT];
+    // first tile: operands loaded directly
 #pragma unroll
-        for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* hs = pick3(Hs0, Hs1, Hs2, l - 1);
+    for (int t = 0; t < MT; ++t) {
+      const long r2 = (a.dOut2 != nullptr) ? (a.idx2 ? (long)a.idx2[mm[t]] : mm[t]) : 0;
+      prms[t] = (a.scale != nullptr) ? ld1(a.R + mm[t]) : 0.f;
 #pragma unroll
-      for (int t = 0; t < MT; ++t) nx[t] = hs + mm[t] * H + 4 * g;  // dz <- h_l on the way out
-    } else {
-      const float* dr = pick3(dr0, dr1, dr2, q);
-      if (dr != nullptr) {
-        load_tl<HB, MT, false>(acc, dr, nullptr, H, mm, g, nkb);
-      } else {
+      for (int kb = 0; kb < HB; ++kb) {
+        dz[t][kb] = ld4(a.dOut + mm[t] * H + 4 * g + 16 * kb);
+        pd2[t][kb] = (a.dOut2 != nullptr) ? ld4(a.dOut2 + r2 * H + 4 * g + 16 * kb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        pu[t][kb] = (a.scale != nullptr) ? ld4(a.U + mm[t] * H + 4 * g + 16 * kb) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    dma_drain();
+    __syncthreads();  // scale visible
+
+    long j = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+      const long ntile = tile + gridDim.x;
+      const bool has_next = ntile < ntiles;
+      long mmn[MT];
+      bool validn[MT];
+      rows_of(has_next ? ntile : tile, mmn, validn);
+      // ---- dY, RMSNorm backward:  dz = g/(rms+eps) - u * <g,u> / (H*rms),  g = scale*dY
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib) dz[t][ib] = valid[t] ? dz[t][ib] + pd2[t][ib] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.scale != nullptr) {
+          float dot = 0.f;
+#pragma unroll
+          for (int ib = 0; ib < HB; ++ib) {
+            dsum[ib] += dz[t][ib] * pu[t][ib];
+            const f32x4 gg = *(lds_cf32x4*)(cst + 64 * ib + 16 * g) * dz[t][ib];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dot = fmaf(gg[r], pu[t][ib][r], dot);
+            dz[t][ib] = gg;
+          }
+          dot = rowsum4(dot);
+          const float rms = prms[t];
+          const float inv = 1.0f / (rms + a.eps);
+          const float k2 = (rms > 0.f) ? dot / ((float)H * rms) : 0.f;
+#pragma unroll
+          for (int ib = 0; ib < HB; ++ib) dz[t][ib] = dz[t][ib] * inv - pu[t][ib] * k2;
+        }
+      }
+      // the next tile's U / dOut2 / rms start travelling now (consumed one tile later)
+      if (has_next) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const long r2 = (a.dOut2 != nullptr) ? (a.idx2 ? (long)a.idx2[mmn[t]] : mmn[t]) : 0;
+          if (a.scale != nullptr) prms[t] = ld1(a.R + mmn[t]);
+#pragma unroll
+          for (int kb = 0; kb < HB; ++kb) {
+            if (a.dOut2 != nullptr) pd2[t][kb] = ld4(a.dOut2 + r2 * H + 4 * g + 16 * kb);
+            if (a.scale != nullptr) pu[t][kb] = ld4(a.U + mmn[t] * H + 4 * g + 16 * kb);
+          }
+        }
+      }
+      {
+        float* dzl = pick4(dZ0, dZ1, dZ2, dZ3, a.NL - 1);
+        if (dzl != nullptr) store_tl<HB, MT, false>(dzl, dz, H, mm, valid, g);
+        if (pick4(db0, db1, db2, db3, a.NL - 1) != nullptr) colsum_to_lds_add<HB, MT>(lds_w + (a.NL - 1) * H, dz, c, g);
+      }
+      for (int k = 0; k < G; ++k) {
+        const bool chain = k < a.NL - 1;
+        const int l = a.NL - 1 - k;  // chain: layer whose W^T is applied
+        const float* nx[MT];
+        if (chain) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float* hs = pick3(Hs0, Hs1, Hs2, l - 1);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) nx[t] = hs + mm[t] * H + 4 * g;  // dz <- h_l on the way out
+        } else {  // input-grad GEMM (the last of the tile): dz is dead afterwards -> next tile's dOut
+          if (dr0 != nullptr) {
+            int nk_;
+            load_tl<HB, MT, false>(acc, dr0, nullptr, H, mm, g, nk_);
+          } else {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+              for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int t = 0; t < MT; ++t) nx[t] = a.dOut + mmn[t] * H + 4 * g;
+        }
+        __syncthreads();
+        {
+          const DmaJob job = job_for(j + 1);
+          gemm_lds_half<MT, 0>(acc, dz, wl + (j & 1) * WBUF_BYTES, off, nx, job);
+        }
+        dma_drain_counted<2 * MT>();
+        ++j;
+        __syncthreads();
+        {
+          const DmaJob job = job_for(j + 1);
+          gemm_lds_half<MT, 1>(acc, dz, wl + (j & 1) * WBUF_BYTES, off, nx, job);
+        }
+        dma_drain_counted<2 * MT>();
+        ++j;
+        if (chain) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) dz[t][ib][r] = (valid[t] && dz[t][ib][r] > 0.f) ? acc[t][ib][r] : 0.f;
+          float* dzp = pick3(dZ0, dZ1, dZ2, l - 1);
+          if (dzp != nullptr) store_tl<HB, MT, false>(dzp, dz, H, mm, valid, g);
+          if (pick3(db0, db1, db2, l - 1) != nullptr) colsum_to_lds_add<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
+        } else {
+          store_tl<HB, MT, false>(dI0, acc, H, mm, valid, g);
+        }
+      }
+      if (a.n_din == 0 && has_next) {  // no input-grad GEMM to hide it under: load the next dOut rows directly
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
-          for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int kb = 0; kb < HB; ++kb) dz[t][kb] = ld4(a.dOut + mmn[t] * H + 4 * g + 16 * kb);
       }
-      const float* base = (dZ0 != nullptr) ? dZ0 : WT00;  // re-read dZ[0]: dz keeps its value
 #pragma unroll
-      for (int t = 0; t < MT; ++t) nx[t] = base + ((dZ0 != nullptr) ? mm[t] * H : 0) + 4 * g;
+      for (int t = 0; t < MT; ++t) {
+        mm[t] = mmn[t];
+        valid[t] = validn[t];
+      }
     }
-    dma_drain();
-    __syncthreads();
-    {
-      const DmaJob job = job_for(2 * k + 1);
-      gemm_lds_half<MT, 0>(acc, dz, wl, off, nx, job);
-    }
-    dma_drain();
-    __syncthreads();
-    {
-      const DmaJob job = job_for(2 * k + 2);
-      gemm_lds_half<MT, 1>(acc, dz, wl + WBUF_BYTES, off, nx, job);
-    }
-    if (chain) {
+  }
+  // dscale: one cross-lane reduction per workgroup
+  if (a.scale != nullptr && a.dscale != nullptr) {
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
+    for (int ib = 0; ib < HB; ++ib) {
+      f32x4 v = dsum[ib];
 #pragma unroll
-        for (int ib = 0; ib < HB; ++ib)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dz[t][ib][r] = (valid[t] && dz[t][ib][r] > 0.f) ? acc[t][ib][r] : 0.f;
-      float* dzp = pick3(dZ0, dZ1, dZ2, l - 1);
-      if (dzp != nullptr) store_tl<HB, MT, false>(dzp, dz, H, mm, valid, g);
-      if (pick3(db0, db1, db2, l - 1) != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
-    } else {
-      store_tl<HB, MT, false>(pick3(dI0, dI1, dI2, q), acc, H, mm, valid, g);
+      for (int r = 0; r < 4; ++r) v[r] = colsum16(v[r]);
+      if (c == 0) *(f32x4*)(lds_w + a.NL * H + 16 * ib + 4 * g) = v;
     }
   }
   __syncthreads();
@@ -1020,7 +1106,7 @@ struct WgradLaunch {
   int njobs;
   mgn_wgrad_job job[MGN_MAX_WGRAD_JOBS];
   int wg0[MGN_MAX_WGRAD_JOBS + 1];  // first workgroup of each job
-  float* partial;                   // [total_wg][H*H]
+  float* partial;                   // [total_wg][H*H + H]: dW partial, then the db partial
   int H;
 };
 
@@ -1044,6 +1130,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WgradLaunch L) {
 #pragma unroll
     for (int jb = 0; jb < HB; ++jb) acc[kk][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  float cs[HB];  // wave 0: per-lane column sums of A (bias gradient)
+#pragma unroll
+  for (int jb = 0; jb < HB; ++jb) cs[jb] = 0.f;
   const int kb0 = wv * KPW;
   if (kb0 < J.nkb && t0 < t1) {
     // operands of one 16-row tile in N-layout; tile t+1 is loaded while tile t multiplies
@@ -1071,6 +1160,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WgradLaunch L) {
         for (int kk = 0; kk < KPW; ++kk)
 #pragma unroll
           for (int jb = 0; jb < HB; ++jb) acc[kk][jb] = MFMA16(a[jb][r], b[kk][r], acc[kk][jb]);
+      if (wv == 0 && J.db != nullptr) {
+#pragma unroll
+        for (int jb = 0; jb < HB; ++jb) cs[jb] += (a[jb][0] + a[jb][1]) + (a[jb][2] + a[jb][3]);
+      }
     };
     load_tile(t0, av[0], bv[0]);
     long tile = t0;
@@ -1089,7 +1182,14 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WgradLaunch L) {
     }
   }
   // D layout: lane (c,g), reg q -> dW[16*jb + 4g + q][16*kb + c]
-  float* P = L.partial + (size_t)blockIdx.x * (H * H);
+  float* P = L.partial + (size_t)blockIdx.x * (H * H + H);
+  if (wv == 0 && J.db != nullptr) {
+#pragma unroll
+    for (int jb = 0; jb < HB; ++jb) {
+      const float v = rowsum4(cs[jb]);
+      if (g == 0 && jb < J.nja) P[H * H + 16 * jb + c] = v;
+    }
+  }
 #pragma unroll
   for (int kk = 0; kk < KPW; ++kk) {
     const int kb = kb0 + kk;
@@ -1112,18 +1212,15 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WgradLaunch L) {
 #define WG_TILE_ROWS 32
 #define WG_TILE_BYTES (WG_TILE_ROWS * 512)
 
-__device__ __forceinline__ void dma_rows(const float* __restrict__ X, long row0, long M, lds_char* buf, int wv, int lane) {
-  // 32 rows x 512 B = 16 instructions of 1 KB (2 rows each); 4 per wave
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = 4 * wv + i;
-    const int r = 2 * q + (lane >> 5);
-    long row = row0 + r;
-    row = row < M ? row : M - 1;  // tail rows are masked at the MFMA
-    const int gch = (lane & 31) ^ (4 * (r & 1));
-    const unsigned voff = (unsigned)((row - row0) * 512 + 16 * gch);  // bytes from the tile's first row
-    glds16(uniform_ptr(X + row0 * 128), voff, __builtin_amdgcn_readfirstlane(lds_addr_of(buf)) + q * 1024);
-  }
+// one 1 KB piece (2 rows) of a 32-row tile of X -> LDS; piece q = 4*wv + i, i in 0..3
+__device__ __forceinline__ void dma_row_piece(const float* __restrict__ X, long row0, long M, unsigned lds0, int wv, int lane, int i) {
+  const int q = 4 * wv + i;
+  const int r = 2 * q + (lane >> 5);
+  long row = row0 + r;
+  row = row < M ? row : M - 1;  // tail rows are masked at the MFMA
+  const int gch = (lane & 31) ^ (4 * (r & 1));
+  const unsigned voff = (unsigned)((row - row0) * 512 + 16 * gch);  // bytes from the tile's first row
+  glds16(uniform_ptr(X + row0 * 128), voff, lds0 + q * 1024);
 }
 
 __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
@@ -1139,53 +1236,92 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
   const int wg = blockIdx.x - L.wg0[j];
   const long ntiles = (J.M + WG_TILE_ROWS - 1) / WG_TILE_ROWS;
   const long t0 = ntiles * wg / nwg, t1 = ntiles * (wg + 1) / nwg;
+  const unsigned sm0 = __builtin_amdgcn_readfirstlane(lds_addr_of(sm));
 
   f32x4 acc[2][8];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb) acc[kk][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // lane (c,g) reads feature 16*b + c of row (4*quad + g): swizzled by the row parity
+  float cs[8];  // wave 0 only: per-lane column sums of A (bias gradient)
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) cs[jb] = 0.f;
+  const bool want_db = (J.db != nullptr) && (wv == 0);
   const int kb0 = 2 * wv;
+  // lane (c,g) reads feature 16*b + c of row 4*quad + g; rows of odd parity are stored with
+  // their 64-byte chunks pair-swapped (XOR 64 on the byte offset), and 4*quad is even, so the
+  // swizzle is a per-lane constant: two base offsets (even / odd feature block) + immediates
+  const int lb = g * 512 + 4 * c;
+  const int sw = (g & 1) << 6;
+  auto ld_quad = [&](lds_char* ta, lds_char* tb, int quad, float (&av)[8], float (&bv)[2]) {
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+      av[jb] = *(__attribute__((address_space(3))) const float*)(ta + quad * 2048 + ((lb + 64 * jb) ^ sw));
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      bv[kk] = *(__attribute__((address_space(3))) const float*)(tb + quad * 2048 + ((lb + 64 * (kb0 + kk)) ^ sw));
+  };
   if (t0 < t1) {
-    dma_rows(J.A, t0 * WG_TILE_ROWS, J.M, sm, wv, lane);
-    dma_rows(J.B, t0 * WG_TILE_ROWS, J.M, sm + WG_TILE_BYTES, wv, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma_row_piece(J.A, t0 * WG_TILE_ROWS, J.M, sm0, wv, lane, i);
+      dma_row_piece(J.B, t0 * WG_TILE_ROWS, J.M, sm0 + WG_TILE_BYTES, wv, lane, i);
+    }
   }
   for (long tile = t0; tile < t1; ++tile) {
     const int buf = (int)((tile - t0) & 1);
     dma_drain();
     __syncthreads();  // tile landed; the other buffer is free again
-    if (tile + 1 < t1) {
-      lds_char* nb = sm + (buf ^ 1) * 2 * WG_TILE_BYTES;
-      dma_rows(J.A, (tile + 1) * WG_TILE_ROWS, J.M, nb, wv, lane);
-      dma_rows(J.B, (tile + 1) * WG_TILE_ROWS, J.M, nb + WG_TILE_BYTES, wv, lane);
-    }
+    const bool more = tile + 1 < t1;
+    const unsigned nb0 = sm0 + (buf ^ 1) * 2 * WG_TILE_BYTES;
     lds_char* ta = sm + buf * 2 * WG_TILE_BYTES;
     lds_char* tb = ta + WG_TILE_BYTES;
-    const bool tail = (tile + 1) * WG_TILE_ROWS > J.M;
+    const bool tail = (tile + 1) * WG_TILE_ROWS > J.M;  // only a job's very last tile
+    float av[2][8], bv[2][2];
+    ld_quad(ta, tb, 0, av[0], bv[0]);
+    // rows past M (the DMA clamps them to row M-1) must not contribute: in the tail tile the A
+    // operand is multiplied by a 0/1 lane mask; every other tile runs the mask-free body
+    const int rows_left = (int)(J.M - tile * WG_TILE_ROWS);
+    auto body = [&](auto TAIL) {
 #pragma unroll
-    for (int quad = 0; quad < WG_TILE_ROWS / 4; ++quad) {
-      const int r = 4 * quad + g;
-      const int rb = r * 512 + ((r & 1) ? 64 : 0);  // XOR 16 floats on odd rows == toggle byte bit 6
-      float av[8], bv[2];
+      for (int quad = 0; quad < WG_TILE_ROWS / 4; ++quad) {
+        if (quad + 1 < WG_TILE_ROWS / 4) ld_quad(ta, tb, quad + 1, av[(quad + 1) & 1], bv[(quad + 1) & 1]);
+#ifndef MGN_EXP_NODMA
+        if (more && quad < 4) {  // next tile's DMA: two pieces per quad, early, under the MFMAs
+          dma_row_piece(J.A, (tile + 1) * WG_TILE_ROWS, J.M, nb0, wv, lane, quad);
+          dma_row_piece(J.B, (tile + 1) * WG_TILE_ROWS, J.M, nb0 + WG_TILE_BYTES, wv, lane, quad);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if (decltype(TAIL)::value) {
+          const float keep = (4 * quad + g < rows_left) ? 1.f : 0.f;
 #pragma unroll
-      for (int jb = 0; jb < 8; ++jb)
-        av[jb] = *(__attribute__((address_space(3))) const float*)(ta + ((r * 512 + 64 * jb + 4 * c) ^ ((r & 1) << 6)));
+          for (int jb = 0; jb < 8; ++jb) av[quad & 1][jb] *= keep;
+        }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        bv[kk] = *(__attribute__((address_space(3))) const float*)(tb + ((r * 512 + 64 * (kb0 + kk) + 4 * c) ^ ((r & 1) << 6)));
-      (void)rb;
-      if (tail && tile * WG_TILE_ROWS + r >= J.M) {
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb) av[jb] = 0.f;
+          for (int jb = 0; jb < 8; ++jb) acc[kk][jb] = MFMA16(av[quad & 1][jb], bv[quad & 1][kk], acc[kk][jb]);
+        if (want_db) {
+#pragma unroll
+          for (int jb = 0; jb < 8; ++jb) cs[jb] += av[quad & 1][jb];
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
+    };
+    if (tail)
+      body(std::true_type{});
+    else
+      body(std::false_type{});
+  }
+  float* P = L.partial + (size_t)blockIdx.x * (128 * 128 + 128);
+  if (want_db) {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int jb = 0; jb < 8; ++jb) acc[kk][jb] = MFMA16(av[jb], bv[kk], acc[kk][jb]);
+    for (int jb = 0; jb < 8; ++jb) {
+      const float v = rowsum4(cs[jb]);
+      if (g == 0) P[128 * 128 + 16 * jb + c] = v;
     }
   }
-  float* P = L.partial + (size_t)blockIdx.x * (128 * 128);
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -1194,24 +1330,51 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
       for (int q = 0; q < 4; ++q) P[(16 * jb + 4 * g + q) * 128 + 16 * (kb0 + kk) + c] = acc[kk][jb][q];
 }
 
-__global__ void k_wgrad_red(const WgradLaunch L) {
+// dW[r,k] = sum over the job's workgroup partials.  64 outputs x 4 partial-lanes per block:
+// consecutive threads read consecutive addresses of one partial (coalesced), four lanes walk
+// the partials interleaved (short dependent chains), then a fixed-order LDS combine.
+__global__ void __launch_bounds__(256) k_wgrad_red(const WgradLaunch L) {
+  __shared__ float red[4][64];
   const int H = L.H;
-  int j = blockIdx.y;
+  const size_t st = (size_t)H * H + H;
+  const int j = blockIdx.y;
   const mgn_wgrad_job J = L.job[j];
   const int rows = 16 * J.nja, cols = 16 * J.nkb;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * cols) return;
-  const int r = i / cols, k = i % cols;
-  const float* P = L.partial + (size_t)L.wg0[j] * (H * H) + r * H + k;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int pl = threadIdx.x >> 6;
   const int nwg = L.wg0[j + 1] - L.wg0[j];
+  const float* P0 = L.partial + (size_t)L.wg0[j] * st;
+  const bool is_w = i < rows * cols;
+  const bool is_b = !is_w && i < rows * cols + rows && J.db != nullptr;
+  int r = 0, k = 0;
   float s0 = 0.f, s1 = 0.f;
-  int b = 0;
-  for (; b + 2 <= nwg; b += 2) {
-    s0 += P[(size_t)b * (H * H)];
-    s1 += P[(size_t)(b + 1) * (H * H)];
+  if (is_w || is_b) {
+    const float* P;
+    if (is_w) {
+      r = i / cols;
+      k = i % cols;
+      P = P0 + r * H + k;
+    } else {
+      r = i - rows * cols;
+      P = P0 + (size_t)H * H + r;
+    }
+    int b = pl;
+    for (; b + 4 < nwg; b += 8) {
+      s0 += P[(size_t)b * st];
+      s1 += P[(size_t)(b + 4) * st];
+    }
+    if (b < nwg) s0 += P[(size_t)b * st];
   }
-  if (b < nwg) s0 += P[(size_t)b * (H * H)];
-  if (k < J.ldw) J.dW[(size_t)r * J.ldw + k] = s0 + s1;
+  red[pl][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (pl == 0) {
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (is_w) {
+      if (k < J.ldw) J.dW[(size_t)r * J.ldw + k] = v;
+    } else if (is_b) {
+      J.db[r] = v;
+    }
+  }
 }
 
 // ===================================================================== segment sum
@@ -1381,13 +1544,13 @@ static MlpPlan plan_mlp(int64_t M, int H, int NL, bool ragged, bool bwd) {
   p.mt = (M >= (int64_t)64 * 2048) ? 2 : 1;
   // measured on MI355X (tools/kbench.py, E = 180k): with LDS-shared weights the forward is
   // faster at 16 rows per wave (172 VGPRs, no spills: 352 vs 368 us), the backward chain at 32
-  if (p.lds && !bwd) p.mt = 1;
+  if (p.lds) p.mt = 1;
   if (const char* e = getenv("MGN_MT")) p.mt = (atoi(e) == 2) ? 2 : 1;
   const int rows = 64 * p.mt;
   p.grid = (unsigned)((M + rows - 1) / rows);
-  if (p.lds && !bwd && p.grid > 512) p.grid = 512;  // persistent: 2 workgroups per CU walk the tiles
+  if (p.lds && p.grid > 512) p.grid = 512;  // persistent: 2 workgroups per CU walk the tiles
   if (const char* e = getenv("MGN_GRID")) { if (p.lds && !bwd && atoi(e) > 0 && (unsigned)atoi(e) < p.grid) p.grid = (unsigned)atoi(e); }
-  p.smem = p.lds ? (bwd ? (size_t)2 * WBUF_BYTES + (size_t)4 * (NL + 1) * H * sizeof(float) : (size_t)FWD_LDS_BYTES) : 0;
+  p.smem = p.lds ? (bwd ? (size_t)2 * WBUF_BYTES + 512 + (size_t)4 * (NL + 1) * H * sizeof(float) : (size_t)FWD_LDS_BYTES) : 0;
   return p;
 }
 
@@ -1433,7 +1596,7 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
 
 template <int HB>
 static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
-  const MlpPlan p = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H, true);
+  MlpPlan p = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true);
   if (p.lds) {
     if (p.mt == 2) {
       if (set_smem(k_mlp_bwd_lds<2>, p.smem)) return 1;
@@ -1566,7 +1729,7 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   if (lrc) return fail(2, "mgn_mlp_bwd: cannot reserve LDS");
   if (int rc = check_launch("mgn_mlp_bwd")) return rc;
   // column reductions: db[l], dscale
-  const unsigned grid = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H, true).grid;
+  const unsigned grid = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).grid;
   const int nslot = a.NL + 1;
   ColredOuts outs;
   bool any = false;
@@ -1607,7 +1770,7 @@ static int wgrad_plan(int njobs, const mgn_wgrad_job* jobs, int* wg0, bool lds) 
 size_t mgn_wgrad_workspace_bytes(int njobs, const mgn_wgrad_job* jobs) {
   if (njobs < 1 || njobs > MGN_MAX_WGRAD_JOBS) return 0;
   // upper bound over the two launches (LDS-staged + generic)
-  return (size_t)(512 + 1024 + 2 * MGN_MAX_WGRAD_JOBS) * 128 * 128 * sizeof(float);
+  return (size_t)(512 + 1024 + 2 * MGN_MAX_WGRAD_JOBS) * (128 * 128 + 128) * sizeof(float);
 }
 
 static bool wgrad_job_full(const mgn_wgrad_job& j) {
@@ -1634,7 +1797,7 @@ int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, v
     const int HB = maxb <= 1 ? 1 : maxb <= 2 ? 2 : maxb <= 4 ? 4 : 8;
     L.H = 16 * HB;
     const int total = wgrad_plan(L.njobs, L.job, L.wg0, pass == 0);
-    const size_t need = (size_t)total * L.H * L.H * sizeof(float);
+    const size_t need = (size_t)total * (L.H * L.H + L.H) * sizeof(float);
     if (ws_bytes < ws_off + need) return fail(1, "mgn_wgrad: workspace too small");
     L.partial = (float*)((char*)ws + ws_off);
     ws_off += need;
@@ -1656,7 +1819,7 @@ int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, v
       }
     }
     if (int rc = check_launch("mgn_wgrad")) return rc;
-    hipLaunchKernelGGL(k_wgrad_red, dim3((L.H * L.H + 255) / 256, L.njobs), dim3(256), 0, s, L);
+    hipLaunchKernelGGL(k_wgrad_red, dim3((L.H * L.H + L.H + 63) / 64, L.njobs), dim3(256), 0, s, L);
     if (int rc = check_launch("mgn_wgrad/reduce")) return rc;
   }
   return 0;

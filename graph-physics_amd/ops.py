@@ -181,13 +181,16 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
     _capi.check(rc, "mgn_mlp_bwd")
 
 
-def wgrad(jobs: Sequence[Tuple[torch.Tensor, int, int, torch.Tensor, int, int, int, torch.Tensor, int, int]], dev):
-    """jobs: (A, lda, nja, B, ldb, nkb, kw, dW_view_ptr_tensor, dW_offset_elems, ldw); M = A.shape[0]."""
+def wgrad(jobs, dev):
+    """jobs: (A, lda, nja, B, ldb, nkb, kw, dW_tensor, dW_offset_elems, ldw[, db]); M = A.shape[0].
+    ``db`` (optional tensor [16*nja]) receives the column sums of A = the bias gradient."""
     L = _capi.lib()
     for i0 in range(0, len(jobs), _capi.MAX_WGRAD_JOBS):
         chunk = jobs[i0:i0 + _capi.MAX_WGRAD_JOBS]
         arr = (_capi.WgradJob * len(chunk))()
-        for j, (A, lda, nja, B, ldb, nkb, kw, dW, off, ldw) in enumerate(chunk):
+        for j, job in enumerate(chunk):
+            A, lda, nja, B, ldb, nkb, kw, dW, off, ldw = job[:10]
+            arr[j].db = _ptr(job[10]) if len(job) > 10 else None
             arr[j].A, arr[j].B = _ptr(A), _ptr(B)
             arr[j].dW = dW.data_ptr() + 4 * off
             arr[j].M = A.shape[0]
@@ -264,13 +267,14 @@ class MlpFunction(torch.autograd.Function):
                 raise NotImplementedError("input gradient of a ragged-width MLP input is not needed by the path")
             dx = torch.empty(M, H, dtype=torch.float32, device=dev)
             din = [(Wk[0].t().contiguous(), None, dx)]
-        mlp_bwd(M, H, NL, dy, None, None, out_w, U, R, scale, saveH, WT, dZ, din, db, dscale)
+        # bias gradients are a by-product of the weight-gradient kernel (it reads dZ anyway)
+        mlp_bwd(M, H, NL, dy, None, None, out_w, U, R, scale, saveH, WT, dZ, din, [None] * NL, dscale)
         ins = [x] + list(saveH)
         in_w = [kin] + [H] * (NL - 1)
         dWs = [torch.empty(widths[l], pad16(in_w[l]), dtype=torch.float32, device=dev) for l in range(NL)]
         jobs = []
         for l in range(NL):
-            jobs.append((dZ[l], widths[l], widths[l] // 16, ins[l], in_w[l], pad16(in_w[l]) // 16, in_w[l], dWs[l], 0, pad16(in_w[l])))
+            jobs.append((dZ[l], widths[l], widths[l] // 16, ins[l], in_w[l], pad16(in_w[l]) // 16, in_w[l], dWs[l], 0, pad16(in_w[l]), db[l]))
         wgrad(jobs, dev)
         grads = []
         for l in range(NL):
@@ -370,11 +374,11 @@ class ProcessorFunction(torch.autograd.Function):
             Wcat = torch.cat([Wn[0][:, :H].t(), We[0][:, H:2 * H].t(), We[0][:, 2 * H:].t()], dim=1).contiguous()
             # node MLP chain: dX' -> dZn[3..0], dAgg = W0n[:,H:]^T dZn0
             mlp_bwd(N, H, 4, dx, None, None, H, Un, Rn, sn, Hn, WTn, dZn, [(WT0n_agg, None, dAgg)],
-                    [g[10], g[12], g[14], g[16]], g[17])
+                    [None] * 4, g[17])
             # edge MLP chain: dM = dE' + dAgg[dst] -> dZe[3..0], dE = dE' + W0e[:, :H]^T dZe0
             de_new = de_buf[0] if de.data_ptr() != de_buf[0].data_ptr() else de_buf[1]
             mlp_bwd(E, H, 4, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
-                    [g[1], g[3], g[5], g[7]], g[8])
+                    [None] * 4, g[8])
             # scatter of the first-layer pre-activations' grads onto dst / src nodes
             segsum(dZe[0], topo.rowptr_dst, None, Sd)
             segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)
@@ -382,16 +386,17 @@ class ProcessorFunction(torch.autograd.Function):
             dx_new = dx_buf[0] if dx.data_ptr() != dx_buf[0].data_ptr() else dx_buf[1]
             mlp_fwd(N, H, [(dZn[0], None, H), (Sd, None, H), (Ss, None, H)], [Wcat], [None], None, H, dx, dx_new)
             # weight gradients: dW = dZ^T X
+            # (A = dZ, B = layer input, dW slab[, db = bias gradient as a by-product])
             jobs = [
-                (dZn[0], H, nb, x, H, nb, H, g[9], 0, 2 * H),
+                (dZn[0], H, nb, x, H, nb, H, g[9], 0, 2 * H, g[10]),
                 (dZn[0], H, nb, agg, H, nb, H, g[9], H, 2 * H),
-                (dZe[0], H, nb, e, H, nb, H, g[0], 0, 3 * H),
+                (dZe[0], H, nb, e, H, nb, H, g[0], 0, 3 * H, g[1]),
                 (Sd, H, nb, x, H, nb, H, g[0], H, 3 * H),
                 (Ss, H, nb, x, H, nb, H, g[0], 2 * H, 3 * H),
             ]
             for l in (1, 2, 3):
-                jobs.append((dZn[l], H, nb, Hn[l - 1], H, nb, H, g[9 + 2 * l], 0, H))
-                jobs.append((dZe[l], H, nb, He[l - 1], H, nb, H, g[2 * l], 0, H))
+                jobs.append((dZn[l], H, nb, Hn[l - 1], H, nb, H, g[9 + 2 * l], 0, H, g[10 + 2 * l]))
+                jobs.append((dZe[l], H, nb, He[l - 1], H, nb, H, g[2 * l], 0, H, g[1 + 2 * l]))
             wgrad(jobs, dev)
             grads[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)] = g
             dx, de = dx_new, de_new

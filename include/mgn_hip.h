@@ -127,12 +127,15 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream);
 /* ------------------------------------------------------------------ weight grads
  * For each job: dW[j, k] = sum_m A[m, j] * B[m, k],  j < 16*nja, k < 16*nkb
  * (B columns >= kw read as zero).  A is [M,lda], B is [M,ldb], dW is [16*nja, ldw].
+ * db (optional, [16*nja]): db[j] = sum_m A[m, j] -- the bias gradient of the same Linear,
+ * a by-product of reading A (= dZ) here.
  * ws: device scratch of mgn_wgrad_workspace_bytes(njobs, jobs) bytes. */
 typedef struct {
   const float* A; const float* B; float* dW;
   int64_t M;
   int lda, ldb, ldw;
   int nja, nkb, kw;
+  float* db;
 } mgn_wgrad_job;
 size_t mgn_wgrad_workspace_bytes(int njobs, const mgn_wgrad_job* jobs);
 int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, void* stream);
