@@ -43,6 +43,10 @@ class MlpFwdArgs(C.Structure):
         ("saveH", _f32p * MAX_LAYERS),
         ("saveU", _f32p),
         ("saveR", _f32p),
+        ("ldw0", C.c_int), ("n_add", C.c_int),
+        ("add_src", _f32p * 2), ("add_idx", _i32p * 2),
+        ("n_post", C.c_int), ("post_ldw", C.c_int),
+        ("post_W", _f32p * 2), ("post_out", _f32p * 2),
     ]
 
 

@@ -704,6 +704,9 @@ __device__ __forceinline__ void gemm_lds_half(f32x4 (&acc)[MT][8], f32x4 (&in)[M
 // half-GEMMs.  The weight DMA ring keeps rolling across tile boundaries, the last GEMM of a
 // tile prefetches the next tile's phase-0 rows, gather indices are fetched a tile ahead, and
 // biases / norm scale live in LDS -- so between two GEMMs a wave only does register work.
+// Per tile: GEMMs of layer 0 (one per input phase; optional gathered adds = split first
+// layer), layers 1..NL-1, epilogue (RMSNorm, residual, stores), optional post-products of the
+// freshly computed output rows.
 // LDS: [2 x 32 KB weight halves][b0..b3, scale: 5 x 512 B].
 #define FWD_LDS_BYTES (2 * WBUF_BYTES + 5 * 512)
 template <int MT>
@@ -723,18 +726,32 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a
 #pragma unroll
   for (int j = 0; j < 4; ++j) off[j] = c * 256 + (((4 * j + g) ^ c) & 15) * 16;
 
-  const int G = a.nphase + a.NL - 1;  // GEMMs per tile: the phases of layer 0, then layers 1..NL-1
-  const int ktot = H * a.nphase;
+  const int GL = a.nphase + a.NL - 1;  // GEMMs of the MLP proper: phases of layer 0, layers 1..NL-1
+  const int G = GL + a.n_post;         // + post-products
+  const int ldw0 = (a.ldw0 > 0) ? a.ldw0 : H * a.nphase;
   const long total_halves = my_tiles * 2 * G;
   // kernel-argument pointers in SGPRs, picked by select chains (no SMEM in the loop)
   const float *W0 = a.W[0], *W1 = a.W[1], *W2 = a.W[2], *W3 = a.W[3];
+  const float *PW0 = a.post_W[0], *PW1 = a.post_W[1];
   float *sH0 = a.saveH[0], *sH1 = a.saveH[1], *sH2 = a.saveH[2];
   const float *src0 = a.src[0], *src1 = a.src[1], *src2 = a.src[2];
   const int32_t *idx0 = a.idx[0], *idx1 = a.idx[1], *idx2 = a.idx[2];
+  const float *as0 = a.add_src[0], *as1 = a.add_src[1];
+  const int32_t *ai0 = a.add_idx[0], *ai1 = a.add_idx[1];
   auto job_for = [&](long j) -> DmaJob {  // DMA of half j of this workgroup's stream -> buffer j&1
     const int jj = (int)(j % (2 * G)), k = jj >> 1;
-    const float* Wk = (k < a.nphase) ? W0 + H * k : pick4(W0, W1, W2, W3, k - a.nphase + 1);
-    const int ldw = (k < a.nphase) ? ktot : H;
+    const float* Wk;
+    int ldw;
+    if (k < a.nphase) {
+      Wk = W0 + H * k;
+      ldw = ldw0;
+    } else if (k < GL) {
+      Wk = pick4(W0, W1, W2, W3, k - a.nphase + 1);
+      ldw = H;
+    } else {
+      Wk = (k == GL) ? PW0 : PW1;
+      ldw = a.post_ldw;
+    }
     return dma_prepare(Wk, ldw, jj & 1, wl + (j & 1) * WBUF_BYTES, wv, lane, j < total_halves);
   };
   {
@@ -757,8 +774,8 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a
     }
   };
 
-  // rows of a tile and their (gathered) source rows per phase
-  auto rows_of = [&](long tl, long (&mm)[MT], bool (&valid)[MT], int (&rid)[MGN_MAX_PHASES][MT]) {
+  // rows of a tile and their (gathered) source rows: rid[0..2] = input phases, rid[3..4] = adds
+  auto rows_of = [&](long tl, long (&mm)[MT], bool (&valid)[MT], int (&rid)[5][MT]) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const long m = (tl * 4 + wv) * (16 * MT) + 16 * t + c;
@@ -767,11 +784,13 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a
       rid[0][t] = idx0 ? idx0[mm[t]] : (int)mm[t];
       rid[1][t] = (a.nphase > 1) ? (idx1 ? idx1[mm[t]] : (int)mm[t]) : 0;
       rid[2][t] = (a.nphase > 2) ? (idx2 ? idx2[mm[t]] : (int)mm[t]) : 0;
+      rid[3][t] = (a.n_add > 0) ? (ai0 ? ai0[mm[t]] : (int)mm[t]) : 0;
+      rid[4][t] = (a.n_add > 1) ? (ai1 ? ai1[mm[t]] : (int)mm[t]) : 0;
     }
   };
   long mm[MT];
   bool valid[MT];
-  int rid[MGN_MAX_PHASES][MT];
+  int rid[5][MT];
   rows_of(tile, mm, valid, rid);
   f32x4 in[MT][HB], acc[MT][HB];
   const float* dummy[MT];
@@ -785,17 +804,52 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a
   __syncthreads();  // constants visible
 
   long j = 0;
+  f32x4 pa[MT][HB];  // split first layer: one gathered projection at a time rides under a half-GEMM
+  bool add_mid = false;
+  auto gemm_pair = [&](const float* const (&nx)[MT]) {  // one full GEMM = two half-GEMMs of the stream
+    __syncthreads();  // this half's weights landed everywhere; the other buffer is free again
+    {
+      const DmaJob job = job_for(j + 1);
+      gemm_lds_half<MT, 0>(acc, in, wl + (j & 1) * WBUF_BYTES, off, nx, job);
+    }
+    dma_drain_counted<2 * MT>();
+    ++j;
+    if (add_mid) {  // first projection landed under half 0: add it, send for the second one
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib) {
+          acc[t][ib] += pa[t][ib];
+          if (a.n_add > 1) pa[t][ib] = ld4(as1 + (long)rid[4][t] * H + 4 * g + 16 * ib);
+        }
+    }
+    __syncthreads();
+    {
+      const DmaJob job = job_for(j + 1);
+      gemm_lds_half<MT, 1>(acc, in, wl + (j & 1) * WBUF_BYTES, off, nx, job);
+    }
+    dma_drain_counted<2 * MT>();
+    ++j;
+  };
+
   for (; tile < ntiles; tile += gridDim.x) {
     const long ntile = tile + gridDim.x;
     const bool has_next = ntile < ntiles;
     long mmn[MT];
     bool validn[MT];
-    int ridn[MGN_MAX_PHASES][MT];
+    int ridn[5][MT];
     rows_of(has_next ? ntile : tile, mmn, validn, ridn);  // index loads land a tile ahead of use
     TL_STAMP(1);
     lds_bias(acc, 0);
-    f32x4 rs[MT][HB];  // residual rows, fetched under the last half-GEMM
-    for (int k = 0; k < G; ++k) {
+    // split first layer: the gathered projections travel while the phase GEMM runs
+    if (a.n_add > 0) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int kb = 0; kb < HB; ++kb) pa[t][kb] = ld4(as0 + (long)rid[3][t] * H + 4 * g + 16 * kb);
+    }
+    f32x4 rs[MT][HB];  // residual rows, fetched under the last layer's GEMM
+    for (int k = 0; k < GL; ++k) {
       const float* nx[MT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) nx[t] = dummy[t];
@@ -807,6 +861,12 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a
         }
       } else {  // layer l >= 1: operand = ReLU(previous accumulator)
         const int l = k - a.nphase + 1;
+        if (l == 1 && a.n_add > 1) {  // second projection (landed under half 1 of the phase GEMM)
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int ib = 0; ib < HB; ++ib) acc[t][ib] += pa[t][ib];
+        }
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -817,36 +877,29 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a
         if (sh != nullptr) store_tl<HB, MT, false>(sh, in, H, mm, valid, g);
         lds_bias(acc, l);
       }
-      if (k == G - 1 && has_next) {  // last GEMM of the tile: pull in the next tile's phase-0 rows
+      if (k == GL - 1 && a.n_post == 0 && has_next) {  // last GEMM of the tile: next tile's phase-0 rows
 #pragma unroll
         for (int t = 0; t < MT; ++t) nx[t] = src0 + (long)ridn[0][t] * H + 4 * g;
       }
       TL_STAMP(2);
-      // barrier: this half's weights landed (own DMA drained right after the previous
-      // half-GEMM, now everyone's) and every wave is done reading the other buffer, which the
-      // DMA riding under this half-GEMM overwrites
-      __syncthreads();
-      TL_STAMP(4);
-      {
-        const DmaJob job = job_for(j + 1);
-        gemm_lds_half<MT, 0>(acc, in, wl + (j & 1) * WBUF_BYTES, off, nx, job);
+      if (k == GL - 1 && a.resid != nullptr) {
+        int nk_;
+        load_tl<HB, MT, false>(rs, a.resid, nullptr, H, mm, g, nk_);
       }
-      dma_drain_counted<2 * MT>();
-      TL_STAMP(6);
-      ++j;
-      if (k == G - 1 && a.resid != nullptr) { int nk_; load_tl<HB, MT, false>(rs, a.resid, nullptr, H, mm, g, nk_); }
-      __syncthreads();
-      TL_STAMP(4);
-      {
-        const DmaJob job = job_for(j + 1);
-        gemm_lds_half<MT, 1>(acc, in, wl + (j & 1) * WBUF_BYTES, off, nx, job);
-      }
-      dma_drain_counted<2 * MT>();
+      add_mid = (k == a.nphase - 1) && (a.n_add > 0);  // under the last phase GEMM of layer 0
+      gemm_pair(nx);
+      add_mid = false;
       TL_STAMP(7);
-      ++j;
     }
-    // ---- epilogue: RMSNorm (reference epsilon placement), residual, stores.  `in` already holds
-    //      the next tile's rows and is not touched.
+    if (a.NL == 1 && a.n_add > 1) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib) acc[t][ib] += pa[t][ib];
+    }
+    // ---- epilogue: RMSNorm (reference epsilon placement), residual, stores.  Without
+    //      post-products `in` already holds the next tile's rows and is not touched; with them
+    //      the output rows go to `in` (they are the operand of the post GEMMs).
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       float inv = 1.f;
@@ -861,29 +914,42 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a
         inv = 1.0f / (rms + a.eps);  // one reciprocal per row; u = z * inv (<= 1 ulp from z / den)
         if (a.saveR != nullptr && valid[t] && g == 0) st1(a.saveR + mm[t], rms);
       }
-      if (valid[t]) {
-        const long ro = mm[t] * H + 4 * g;
+      const long ro = mm[t] * H + 4 * g;
 #pragma unroll
-        for (int ib = 0; ib < HB; ++ib) {
-          f32x4 y = acc[t][ib];
-          if (a.scale != nullptr) {
-            const f32x4 u = y * inv;
-            if (a.saveU != nullptr) st4(a.saveU + ro + 16 * ib, u);
-            y = *(lds_cf32x4*)(cst + 4 * 512 + 64 * ib + 16 * g) * u;
-          }
-          if (a.y_out != nullptr) st4(a.y_out + ro + 16 * ib, y);
-          if (a.resid != nullptr) y = rs[t][ib] + y;
-          st4(a.out + ro + 16 * ib, y);
+      for (int ib = 0; ib < HB; ++ib) {
+        f32x4 y = acc[t][ib];
+        if (a.scale != nullptr) {
+          const f32x4 u = y * inv;
+          if (a.saveU != nullptr && valid[t]) st4(a.saveU + ro + 16 * ib, u);
+          y = *(lds_cf32x4*)(cst + 4 * 512 + 64 * ib + 16 * g) * u;
         }
+        if (a.y_out != nullptr && valid[t]) st4(a.y_out + ro + 16 * ib, y);
+        if (a.resid != nullptr) y = rs[t][ib] + y;
+        if (valid[t]) st4(a.out + ro + 16 * ib, y);
+        if (a.n_post > 0) in[t][ib] = y;
       }
     }
     TL_STAMP(8);
+    // ---- post-products of the fresh output rows (next round's node projections)
+    for (int q = 0; q < a.n_post; ++q) {
+      const float* nx[MT];
+      const bool last = (q == a.n_post - 1);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        // not last: re-read the rows just stored, `in` keeps its value; last: next tile's phase 0
+        nx[t] = (last && has_next) ? src0 + (long)ridn[0][t] * H + 4 * g : a.out + mm[t] * H + 4 * g;
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      gemm_pair(nx);
+      store_tl<HB, MT, false>((q == 0) ? a.post_out[0] : a.post_out[1], acc, H, mm, valid, g);
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       mm[t] = mmn[t];
       valid[t] = validn[t];
 #pragma unroll
-      for (int p = 0; p < MGN_MAX_PHASES; ++p) rid[p][t] = ridn[p][t];
+      for (int p = 0; p < 5; ++p) rid[p][t] = ridn[p][t];
     }
   }
 }
@@ -1539,7 +1605,7 @@ static bool fwd_ragged(const mgn_mlp_fwd_args& a) {
 
 static MlpPlan plan_mlp(int64_t M, int H, int NL, bool ragged, bool bwd) {
   MlpPlan p;
-  p.lds = (H == 128) && !ragged && NL >= 2 && NL <= LDS_MAX_NL;
+  p.lds = (H == 128) && !ragged && NL >= (bwd ? 2 : 1) && NL <= LDS_MAX_NL;
   if (getenv("MGN_NO_LDS") != nullptr) p.lds = false;
   p.mt = (M >= (int64_t)64 * 2048) ? 2 : 1;
   // measured on MI355X (tools/kbench.py, E = 180k): with LDS-shared weights the forward is
@@ -1691,6 +1757,9 @@ int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream) {
   for (int p = 0; p < a.nphase; ++p)
     if (a.kw[p] < 1 || a.kw[p] > a.H) return fail(1, "mgn_mlp_fwd: phase width out of range");
   if (a.scale != nullptr && a.out_w != a.H) return fail(1, "mgn_mlp_fwd: RMSNorm needs out_w == H");
+  if (a.n_add < 0 || a.n_add > 2 || a.n_post < 0 || a.n_post > 2) return fail(1, "mgn_mlp_fwd: n_add / n_post out of range");
+  if ((a.n_add > 0 || a.n_post > 0 || a.ldw0 > 0) && !plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds)
+    return fail(1, "mgn_mlp_fwd: ldw0 / n_add / n_post need the H = 128 full-width kernel");
   if (a.M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   int rc;

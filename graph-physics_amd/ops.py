@@ -134,7 +134,11 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
             Ws: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]], scale: Optional[torch.Tensor],
             out_w: int, resid: Optional[torch.Tensor], out: torch.Tensor, y_out: Optional[torch.Tensor] = None,
             saveH: Optional[Sequence[torch.Tensor]] = None, saveU: Optional[torch.Tensor] = None,
-            saveR: Optional[torch.Tensor] = None):
+            saveR: Optional[torch.Tensor] = None, ldw0: int = 0,
+            adds: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]] = (),
+            posts: Sequence[Tuple[int, torch.Tensor]] = (), post_ldw: int = 0):
+    """``adds``: (rows[*,H], idx or None) gathered into the layer-0 pre-activation;
+    ``posts``: (device address of a [H,H] weight block with leading dim ``post_ldw``, out[M,H])."""
     a = _capi.MlpFwdArgs()
     a.M, a.H, a.NL, a.nphase = M, H, len(Ws), len(phases)
     for p, (src, idx, kw) in enumerate(phases):
@@ -147,6 +151,11 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
         for l, h in enumerate(saveH):
             a.saveH[l] = _ptr(h)
     a.saveU, a.saveR = _ptr(saveU), _ptr(saveR)
+    a.ldw0, a.n_add, a.n_post, a.post_ldw = ldw0, len(adds), len(posts), post_ldw
+    for q, (t, ix) in enumerate(adds):
+        a.add_src[q], a.add_idx[q] = _ptr(t), _ptr(ix)
+    for q, (wptr, o) in enumerate(posts):
+        a.post_W[q], a.post_out[q] = wptr, _ptr(o)
     dev = out.device
     with torch.cuda.device(dev):
         rc = _capi.lib().mgn_mlp_fwd(C.byref(a), _stream(dev))
@@ -318,6 +327,17 @@ class ProcessorFunction(torch.autograd.Function):
         f = dict(dtype=torch.float32, device=dev)
         m = torch.empty(E, H, **f)
         saved = []
+        # H = 128: algebraic split of the first edge layer (W0 = [W_e | W_d | W_s]):
+        #   W0.[e, x_dst, x_src] = W_e.e + (x W_d^T)[dst] + (x W_s^T)[src]
+        # the two node-level projections of round i+1 are post-products of round i's node
+        # kernel (x' still in registers); round 0's come from two small launches.
+        split = (H == 128)
+        Pd = Ps = None
+        if split and L > 0 and E > 0:
+            W0 = P[0]
+            Pd, Ps = torch.empty(N, H, **f), torch.empty(N, H, **f)
+            for slab, dst_t in ((1, Pd), (2, Ps)):
+                mlp_fwd(N, H, [(x, None, H)], [W0[:, slab * H:(slab + 1) * H].contiguous()], [None], None, H, None, dst_t)
         for i in range(L):
             q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
             We, be, se = [q[0], q[2], q[4], q[6]], [q[1], q[3], q[5], q[7]], q[8]
@@ -334,14 +354,25 @@ class ProcessorFunction(torch.autograd.Function):
                 He = Hn = None
                 Ue = Re = Un = Rn = None
             # R3: m = edge_block(cat[e, x[dst], x[src]]);  e' = e + m     (layers.py:1017-1028,1039)
-            mlp_fwd(E, H, [(e, None, H), (x, topo.dst_s, H), (x, topo.src_s, H)], We, be, se, H, e, e_new, m, He, Ue, Re)
+            if split and E > 0:
+                mlp_fwd(E, H, [(e, None, H)], We, be, se, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
+                        adds=[(Pd, topo.dst_s), (Ps, topo.src_s)])
+            else:
+                mlp_fwd(E, H, [(e, None, H), (x, topo.dst_s, H), (x, topo.src_s, H)], We, be, se, H, e, e_new, m, He, Ue, Re)
             # R4: agg = segment-sum of m over dst                          (layers.py:1031-1037)
             segsum(m, topo.rowptr_dst, None, agg)
             # R5: x' = x + node_block(cat[x, agg])                         (layers.py:1100-1101,1040)
-            mlp_fwd(N, H, [(x, None, H), (agg, None, H)], Wn, bn, sn, H, x, x_new, None, Hn, Un, Rn)
+            posts, Pd_n, Ps_n = (), None, None
+            if split and E > 0 and i + 1 < L:
+                W0n = P[PARAMS_PER_BLOCK * (i + 1)]
+                Pd_n, Ps_n = torch.empty(N, H, **f), torch.empty(N, H, **f)
+                posts = [(W0n.data_ptr() + 4 * H, Pd_n), (W0n.data_ptr() + 8 * H, Ps_n)]
+            mlp_fwd(N, H, [(x, None, H), (agg, None, H)], Wn, bn, sn, H, x, x_new, None, Hn, Un, Rn,
+                    posts=posts, post_ldw=3 * H)
             if need:
                 saved.append((x, e, agg, He, Ue, Re, Hn, Un, Rn))
             x, e = x_new, e_new
+            Pd, Ps = Pd_n, Ps_n
         ctx.topo, ctx.L, ctx.P, ctx.saved_acts = topo, L, P, saved
         return x, e
 

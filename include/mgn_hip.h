@@ -89,6 +89,21 @@ typedef struct {
   float* saveH[MGN_MAX_LAYERS];
   float* saveU;
   float* saveR;
+  /* --- optional extensions (H = 128, full widths only; zero them when unused) ------------
+   * ldw0   : leading dimension of W[0] when it is a column slab of a wider matrix (0 = ktot).
+   * n_add  : layer-0 pre-activation += add_src[q][ add_idx[q] ? add_idx[q][m] : m , 0:H ]
+   *          -- the algebraic split of the first edge layer: W0.[e,x_d,x_s] =
+   *          W_e.e + (x W_d^T)[dst] + (x W_s^T)[src], the two projections being N-row products.
+   * n_post : post_out[q][m,:] = post_W[q] . out[m,:]   (post_W[q] is [H,H], leading dim post_ldw)
+   *          -- the next round's node projections, computed while `out` is still in registers. */
+  int ldw0;
+  int n_add;
+  const float* add_src[2];
+  const int32_t* add_idx[2];
+  int n_post;
+  int post_ldw;
+  const float* post_W[2];
+  float* post_out[2];
 } mgn_mlp_fwd_args;
 int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream);
 

@@ -30,7 +30,7 @@ def test_struct_layout_matches_header():
     from graph_physics_amd import _capi as c
 
     # sizes the C compiler produces for the same field order (LP64)
-    assert ctypes.sizeof(c.MlpFwdArgs) == 8 + 12 + 4 + 24 + 24 + 12 + 4 + 64 + 64 + 8 + 8 + 24 + 64 + 16
+    assert ctypes.sizeof(c.MlpFwdArgs) == 8 + 12 + 4 + 24 + 24 + 12 + 4 + 64 + 64 + 8 + 8 + 24 + 64 + 16 + 8 + 32 + 8 + 32
     assert ctypes.sizeof(c.WgradJob) == 24 + 8 + 24 + 8
     assert c.MAX_LAYERS == 8 and c.MAX_PHASES == 3 and c.MAX_WGRAD_JOBS == 12
 
