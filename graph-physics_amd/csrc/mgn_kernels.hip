@@ -541,27 +541,36 @@ __global__ void __launch_bounds__(1024) k_colred(const float* __restrict__ ws, i
 // LDS destination of a DMA is lane-linear), and makes the rows a b128 lane group reads hit
 // different 4-bank groups (SQ_LDS_BANK_CONFLICT = 0).  One barrier per half-GEMM.
 #ifdef MGN_TIMELINE
-// debug build only (tools/): s_memtime stamps of wave 0 of a few workgroups
+// debug build only (tools/): s_memtime stamps of wave 0 of the first workgroups, buffered in LDS
+// (no VMEM traffic, position counter in a register) and dumped when the kernel ends
 __device__ unsigned long long g_timeline[8][512];
 __device__ int g_tlpos[8];
-#define TL_STAMP(tag)                                                                                  \
-  do {                                                                                                 \
-    if (threadIdx.x == 0 && blockIdx.x < 8) {                                                          \
-      int p_ = g_tlpos[blockIdx.x];                                                                    \
-      if (p_ < 512) {                                                                                  \
-        g_timeline[blockIdx.x][p_] = (__builtin_readcyclecounter() << 8) | (unsigned long long)(tag);  \
-        g_tlpos[blockIdx.x] = p_ + 1;                                                                  \
-      }                                                                                                \
-    }                                                                                                  \
+#define TL_DECL()                                                                            \
+  __shared__ unsigned long long tl_buf_[512];                                                \
+  int tl_n_ = 0;                                                                             \
+  const int tl_slot_ = (blockIdx.x < 4) ? (int)blockIdx.x                                    \
+                       : ((blockIdx.x + 4 >= gridDim.x) ? (int)(blockIdx.x + 8 - gridDim.x) : -1)
+#define TL_STAMP(tag)                                                                        \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && tl_slot_ >= 0 && tl_n_ < 512)                                    \
+      tl_buf_[tl_n_++] = (__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)(tag);\
+  } while (0)
+#define TL_DUMP()                                                                            \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && tl_slot_ >= 0) {                                                 \
+      for (int i_ = 0; i_ < tl_n_; ++i_) g_timeline[tl_slot_][i_] = tl_buf_[i_];            \
+      g_tlpos[tl_slot_] = tl_n_;                                                             \
+    }                                                                                        \
   } while (0)
 extern "C" int mgn_debug_timeline(unsigned long long* out, int* pos) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 8 * 512) != hipSuccess) return 1;
   if (hipMemcpyFromSymbol(pos, HIP_SYMBOL(g_tlpos), sizeof(int) * 8) != hipSuccess) return 1;
-  int z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_tlpos), z, sizeof(z)) != hipSuccess;
+  return 0;
 }
 #else
+#define TL_DECL() ((void)0)
 #define TL_STAMP(tag) ((void)0)
+#define TL_DUMP() ((void)0)
 #endif
 #ifdef MGN_EXP_NOSYNC
 #define MGN_SYNC() ((void)0)
@@ -713,6 +722,7 @@ template <int MT>
 __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a) {
   constexpr int HB = 8, H = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  TL_DECL();
   lds_char* wl = (lds_char*)smem;
   lds_char* cst = wl + 2 * WBUF_BYTES;
   const int lane = threadIdx.x & 63;
@@ -807,12 +817,16 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a
   f32x4 pa[MT][HB];  // split first layer: one gathered projection at a time rides under a half-GEMM
   bool add_mid = false;
   auto gemm_pair = [&](const float* const (&nx)[MT]) {  // one full GEMM = two half-GEMMs of the stream
+    TL_STAMP(3);
     __syncthreads();  // this half's weights landed everywhere; the other buffer is free again
+    TL_STAMP(4);
     {
       const DmaJob job = job_for(j + 1);
       gemm_lds_half<MT, 0>(acc, in, wl + (j & 1) * WBUF_BYTES, off, nx, job);
     }
+    TL_STAMP(5);
     dma_drain_counted<2 * MT>();
+    TL_STAMP(6);
     ++j;
     if (add_mid) {  // first projection landed under half 0: add it, send for the second one
 #pragma unroll
@@ -952,6 +966,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwd_lds(const mgn_mlp_fwd_args a
       for (int p = 0; p < 5; ++p) rid[p][t] = ridn[p][t];
     }
   }
+  TL_DUMP();
 }
 
 // Backward chain, persistent like the forward: a workgroup walks its tiles as one stream of
@@ -1291,6 +1306,7 @@ __device__ __forceinline__ void dma_row_piece(const float* __restrict__ X, long 
 
 __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  TL_DECL();
   lds_char* sm = (lds_char*)smem;  // [2 buffers][A tile | B tile]
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1336,8 +1352,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
   }
   for (long tile = t0; tile < t1; ++tile) {
     const int buf = (int)((tile - t0) & 1);
+    TL_STAMP(1);
     dma_drain();
+    TL_STAMP(3);
     __syncthreads();  // tile landed; the other buffer is free again
+    TL_STAMP(4);
     const bool more = tile + 1 < t1;
     const unsigned nb0 = sm0 + (buf ^ 1) * 2 * WG_TILE_BYTES;
     lds_char* ta = sm + buf * 2 * WG_TILE_BYTES;
@@ -1379,7 +1398,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
       body(std::true_type{});
     else
       body(std::false_type{});
+    TL_STAMP(7);
   }
+  TL_DUMP();
   float* P = L.partial + (size_t)blockIdx.x * (128 * 128 + 128);
   if (want_db) {
 #pragma unroll
@@ -1816,21 +1837,47 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
 }
 
 static int wgrad_plan(int njobs, const mgn_wgrad_job* jobs, int* wg0, bool lds) {
-  // a fixed budget of workgroups shared out in proportion to the rows of each job:
-  // 512 for the LDS kernel (2 resident per CU), ~1024 for the generic one
+  // A fixed budget of workgroups -- exactly what is co-resident (512 = 2 per CU for the LDS
+  // kernel, 1024 for the generic one) -- shared out in proportion to the rows of each job.
+  // The total must NEVER exceed the budget: four workgroups too many start a second
+  // scheduling round and the kernel takes 1.4x as long (measured).  Floor shares first, the
+  // remainder goes to the jobs with the most tiles per workgroup.
   const int rows = lds ? WG_TILE_ROWS : 16;
   const int budget = lds ? 512 : 1024;
-  int64_t tot = 0;
-  for (int j = 0; j < njobs; ++j) tot += (jobs[j].M + rows - 1) / rows;
+  int64_t tiles[MGN_MAX_WGRAD_JOBS], tot = 0;
+  int n[MGN_MAX_WGRAD_JOBS];
+  for (int j = 0; j < njobs; ++j) {
+    tiles[j] = (jobs[j].M + rows - 1) / rows;
+    if (tiles[j] < 1) tiles[j] = 1;
+    tot += tiles[j];
+  }
+  int used = 0;
+  for (int j = 0; j < njobs; ++j) {
+    int64_t s = tiles[j] * budget / tot;  // floor
+    const int64_t cap = (tiles[j] + 3) / 4;  // at least 4 tiles per workgroup
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    n[j] = (int)s;
+    used += n[j];
+  }
+  while (used < budget) {  // hand out what is left, one at a time, to the most loaded job
+    int best = -1;
+    double load = 4.0;  // do not go below 4 tiles per workgroup
+    for (int j = 0; j < njobs; ++j) {
+      const double l = (double)tiles[j] / n[j];
+      if (l > load) {
+        load = l;
+        best = j;
+      }
+    }
+    if (best < 0) break;
+    ++n[best];
+    ++used;
+  }
   int acc = 0;
   for (int j = 0; j < njobs; ++j) {
-    const int64_t tiles = (jobs[j].M + rows - 1) / rows;
-    int64_t n = tot > 0 ? (tiles * budget + tot - 1) / tot : 1;
-    const int64_t cap = (tiles + 3) / 4;  // at least 4 tiles per workgroup
-    if (n > cap) n = cap;
-    if (n < 1) n = 1;
     wg0[j] = acc;
-    acc += (int)n;
+    acc += n[j];
   }
   wg0[njobs] = acc;
   return acc;

@@ -25,11 +25,24 @@ try:
     L = _capi.lib()
     L.mgn_debug_timeline.restype = C.c_int
     buf = (C.c_ulonglong * (8 * 512))(); pos = (C.c_int * 8)()
+    which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+    dZ = [torch.randn(E, H, **f) for _ in range(4)]
+    Hs = [torch.randn(E, H, **f) for _ in range(3)]
+    g0, gh = torch.empty(H, 3 * H, **f), [torch.empty(H, H, **f) for _ in range(3)]
+    nb = H // 16
+    jobs = [(dZ[0], H, nb, e, H, nb, H, g0, 0, 3 * H)] + [(dZ[l + 1], H, nb, Hs[l], H, nb, H, gh[l], 0, H) for l in range(3)]
     for it in range(3):
-        ops.mlp_fwd(E, H, ph, [W0] + Wh, bs, sc, H, e, e_new, m)
+        if which == "fwd":
+            ops.mlp_fwd(E, H, ph, [W0] + Wh, bs, sc, H, e, e_new, m)
+        else:
+            ops.wgrad(jobs, dev)
         torch.cuda.synchronize()
         L.mgn_debug_timeline(buf, pos)
-    names = {1: "tile_start", 2: "prework", 3: "drained", 4: "barrier", 5: "dma_issued", 6: "half0", 7: "half1", 8: "epilogue"}
+    names = {1: "tile_start", 2: "prework", 3: "pre_barrier", 4: "barrier", 5: "half0_issued", 6: "drained", 7: "gemm_done", 8: "epilogue"}
+    firsts = [(buf[b * 512] >> 8) for b in range(8)]
+    lasts = [(buf[b * 512 + max(pos[b] - 1, 0)] >> 8) for b in range(8)]
+    print("census (s_memrealtime, 100 MHz ticks): first stamp rel. to WG0:", [f - firsts[0] for f in firsts])
+    print("                                       last  stamp rel. to WG0 first:", [l - firsts[0] for l in lasts])
     for b in (0, 1):
         n = pos[b]
         ev = [(buf[b * 512 + i] >> 8, buf[b * 512 + i] & 255) for i in range(n)]
@@ -38,7 +51,7 @@ try:
         line = []
         for i in range(1, min(n, 140)):
             line.append(f"{names[ev[i][1]]}+{ev[i][0] - ev[i-1][0]}")
-            if ev[i][1] == 8:
+            if ev[i][1] == 8 or (which != "fwd" and ev[i][1] == 7):
                 print("  tile: " + " ".join(line)); line = []
         print("  total span", ev[min(n, 140) - 1][0] - t0)
 finally:
