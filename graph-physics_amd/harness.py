@@ -60,6 +60,7 @@ class Engine:
         self.opt = torch.optim.AdamW(self.sim.parameters(), lr=learning_rate, weight_decay=0.0001, betas=(0.9, 0.95))
         self.step_count = 0
         self.grad_sync = None  # set by distributed.DataParallel: callable(params) all-reducing .grad
+        self._graph = None     # hipGraph of one training step (capture_train_step)
 
     def train_step(self, batch: Graph) -> torch.Tensor:
         self.sim.train()
@@ -76,6 +77,74 @@ class Engine:
         self.opt.step()
         self.step_count += 1
         return loss.detach()
+
+    # ---------------------------------------------------------------- hipGraph replay
+    def capture_train_step(self, batch: Graph, warmup: int = 3):
+        """Capture one whole training step (forward, loss, backward, clip, AdamW) in a hipGraph.
+
+        A step is ~450 dependent launches; driven from Python that is ~10 ms of host time --
+        launch-bound for a 2k-node mesh.  The engine's kernels are launched on torch's current
+        stream, allocate nothing and never synchronise, so the step captures as is; replay costs
+        ~1 us per node.  The mesh topology and tensor shapes are frozen in the graph: capture
+        once per mesh/batch shape, feed new data through ``train_step_graphed`` (copied into the
+        static input tensors).  The learning rate lives in a device tensor updated before replay.
+        """
+        dev = self.device
+        assert self.grad_sync is None, "graph capture of the multi-GPU step is not supported yet"
+        # >= 1 eager step first: the optimiser creates its state lazily, and state created under
+        # capture would be re-zeroed by every replay
+        warmup = max(1, warmup)
+        self.sim.train()
+        from .layers import Normalizer
+        for mod in self.sim.modules():  # host mirrors of the accumulation counters: no .item() under capture
+            if isinstance(mod, Normalizer) and mod._host_num_acc is None:
+                mod._host_num_acc = int(mod._num_accumulations.item())
+        self._lr_t = torch.tensor(self.learning_rate, dtype=torch.float32, device=dev)
+        self.opt = torch.optim.AdamW(self.sim.parameters(), lr=self._lr_t, weight_decay=0.0001, betas=(0.9, 0.95),
+                                     capturable=True, foreach=True)
+        self._static = batch.clone()
+        if getattr(batch, "mgn_topology", None) is not None:
+            self._static.mgn_topology = batch.mgn_topology
+        else:
+            from . import ops
+            self._static.mgn_topology = ops.Topology(self._static.edge_index, self._static.x.shape[0])
+
+        def body():
+            node_type = self._static.x[:, self.sim.node_type_index]
+            net_out, target, _ = self.sim(self._static)
+            loss = l2_loss(net_out, target, node_type)
+            self.opt.zero_grad(set_to_none=True)
+            loss.backward()
+            gn = torch.nn.utils.clip_grad_norm_(self.sim.parameters(), self.grad_clip)
+            self.opt.step()
+            return loss.detach(), gn
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._lr_t.fill_(self.learning_rate * lr_factor(self.step_count, self.warmup, self.num_steps))
+                body()
+                self.step_count += 1
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._g_loss, self._g_gn = body()
+        self._graph = g
+        return g
+
+    def train_step_graphed(self, batch: Optional[Graph] = None) -> torch.Tensor:
+        """Replay the captured step; ``batch`` (same shapes / topology) is copied into the static inputs."""
+        if batch is not None and batch is not self._static:
+            self._static.x.copy_(batch.x, non_blocking=True)
+            self._static.y.copy_(batch.y, non_blocking=True)
+            self._static.edge_attr.copy_(batch.edge_attr, non_blocking=True)
+        self._lr_t.fill_(self.learning_rate * lr_factor(self.step_count, self.warmup, self.num_steps))
+        self._graph.replay()
+        self.step_count += 1
+        self.last_grad_norm = self._g_gn
+        return self._g_loss
 
     @torch.no_grad()
     def predict_step(self, batch: Graph, last_prediction: Optional[torch.Tensor]) -> torch.Tensor:
