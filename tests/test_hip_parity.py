@@ -365,3 +365,23 @@ def test_graphed_train_step_equals_eager(dev):
         assert abs(a - b) < 2e-5 * abs(a), (losses_e, losses_g)
     for (k, v), (_, w) in zip(eager.model.state_dict().items(), graphed.model.state_dict().items()):
         assert torch.allclose(v, w, rtol=1e-4, atol=2e-6), k
+
+
+def test_large_mesh_forward_vs_oracle(dev):
+    """300k-node / 1.8M-edge mesh (offsets past 2^31 bytes per tensor are exercised by the
+    64-bit row arithmetic): 2-round forward against the oracle + determinism."""
+    N = 300_000
+    g = gp.square_mesh(N, seed=1)
+    E = g.edge_index.shape[1]
+    assert E * 128 * 4 > 2 ** 29
+    params = R.make_params(R.epd_param_shapes(2, 128, 11, 3, 2), 5)
+    net = gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=128).to(dev)
+    net.load_state_dict(params)
+    x_in, e_in = R.randn((N, 11), 1), R.randn((E, 3), 2)
+    graph = gp.Graph(x=x_in.to(dev), edge_attr=e_in.to(dev), edge_index=g.edge_index.to(dev))
+    with torch.no_grad():
+        a = net(graph)
+        b = net(graph)
+    assert torch.equal(a, b)
+    ref = O.epd_forward(x_in, e_in, g.edge_index, params, 2)
+    assert rel_err(a, ref) < FWD_TOL
