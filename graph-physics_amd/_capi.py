@@ -82,6 +82,10 @@ class WgradJob(C.Structure):
     ]
 
 
+class TBlock(C.Structure):
+    _fields_ = [("src", _f32p), ("dst", _f32p), ("ld_src", C.c_int), ("ld_dst", C.c_int)]
+
+
 #: every symbol include/mgn_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "mgn_version": (C.c_int, []),
@@ -94,6 +98,7 @@ SYMBOLS = {
     "mgn_mlp_bwd": (C.c_int, [C.POINTER(MlpBwdArgs), C.c_void_p]),
     "mgn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(WgradJob)]),
     "mgn_wgrad": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_transpose_blocks": (C.c_int, [C.c_int, C.POINTER(TBlock), C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -1526,6 +1526,27 @@ __global__ void __launch_bounds__(256) k_segsum(const float* __restrict__ src, c
   st4(out + node * H + 4 * l, s);
 }
 
+// ================================================================ batched transpose
+#define TB_MAX 128
+struct TBlocks {
+  mgn_tblock b[TB_MAX];
+};
+// one workgroup per 32x32 tile of one block; LDS tile padded against bank conflicts
+__global__ void __launch_bounds__(256) k_transpose_blocks(const TBlocks T, int H) {
+  __shared__ float tile[32][33];
+  const mgn_tblock B = T.b[blockIdx.y];
+  const int tpr = H / 32 > 0 ? H / 32 : 1;
+  const int tj = (blockIdx.x / tpr) * 32, tk = (blockIdx.x % tpr) * 32;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = ly; r < 32; r += 8)
+    if (tj + r < H && tk + lx < H) tile[r][lx] = B.src[(size_t)(tj + r) * B.ld_src + tk + lx];
+  __syncthreads();
+#pragma unroll
+  for (int r = ly; r < 32; r += 8)
+    if (tk + r < H && tj + lx < H) B.dst[(size_t)(tk + r) * B.ld_dst + tj + lx] = tile[lx][r];
+}
+
 // ======================================================================= CSR build
 __global__ void k_csr_hist(const int64_t* __restrict__ key, long E, long N, int* __restrict__ cnt, int* __restrict__ err) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1968,6 +1989,19 @@ int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, v
     if (int rc = check_launch("mgn_wgrad/reduce")) return rc;
   }
   return 0;
+}
+
+int mgn_transpose_blocks(int n, const mgn_tblock* blocks, int H, void* stream) {
+  if (n < 0 || H < 1 || H > 128) return fail(1, "mgn_transpose_blocks: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = ((H + 31) / 32) * ((H + 31) / 32);
+  for (int i0 = 0; i0 < n; i0 += TB_MAX) {
+    TBlocks T;
+    const int m = (n - i0 < TB_MAX) ? n - i0 : TB_MAX;
+    for (int i = 0; i < m; ++i) T.b[i] = blocks[i0 + i];
+    hipLaunchKernelGGL(k_transpose_blocks, dim3(tiles, m), dim3(256), 0, s, T, H);
+  }
+  return check_launch("mgn_transpose_blocks");
 }
 
 }  // extern "C"

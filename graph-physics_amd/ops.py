@@ -212,6 +212,18 @@ def wgrad(jobs, dev):
         _capi.check(rc, "mgn_wgrad")
 
 
+def transpose_blocks(blocks: Sequence[Tuple[int, int, int, int]], H: int, dev):
+    """blocks: (src_address, ld_src, dst_address, ld_dst) of H x H blocks: dst[k,j] = src[j,k]."""
+    if not blocks:
+        return
+    arr = (_capi.TBlock * len(blocks))()
+    for i, (src, lds, dst, ldd) in enumerate(blocks):
+        arr[i].src, arr[i].ld_src, arr[i].dst, arr[i].ld_dst = src, lds, dst, ldd
+    with torch.cuda.device(dev):
+        rc = _capi.lib().mgn_transpose_blocks(len(blocks), arr, H, _stream(dev))
+    _capi.check(rc, "mgn_transpose_blocks")
+
+
 # ------------------------------------------------------------ generic MLP (R2)
 class MlpFunction(torch.autograd.Function):
     """build_mlp forward/backward on the engine (encoders, decoder, stand-alone MLPs).
@@ -391,18 +403,36 @@ class ProcessorFunction(torch.autograd.Function):
         dx_buf, de_buf = [torch.empty(N, H, **f), torch.empty(N, H, **f)], [torch.empty(E, H, **f), torch.empty(E, H, **f)]
         grads: List[Optional[torch.Tensor]] = [None] * (PARAMS_PER_BLOCK * L)
         nb = H // 16
+        # W^T operands of every round in one buffer, filled by one batched transpose launch:
+        # per round 11 H x H blocks  [WTn1..3 | WTe1..3 | WT0n_agg | WT0e_e | Wcat (H x 3H)]
+        HH = H * H
+        wt = torch.empty(L, 11, H, H, **f)
+        tb = []
+        for i in range(L):
+            q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
+            base = wt.data_ptr() + 4 * (i * 11 * HH)
+            We0, Wn0 = q[0].data_ptr(), q[9].data_ptr()
+            for k, l in enumerate((1, 2, 3)):
+                tb.append((q[9 + 2 * l].data_ptr(), H, base + 4 * (k * HH), H))          # WTn[l]
+                tb.append((q[2 * l].data_ptr(), H, base + 4 * ((3 + k) * HH), H))        # WTe[l]
+            tb.append((Wn0 + 4 * H, 2 * H, base + 4 * (6 * HH), H))                      # (W0n[:, H:])^T
+            tb.append((We0, 3 * H, base + 4 * (7 * HH), H))                              # (W0e[:, :H])^T
+            cat = base + 4 * (8 * HH)                                                    # Wcat [H, 3H]
+            tb.append((Wn0, 2 * H, cat, 3 * H))                                          # (W0n[:, :H])^T
+            tb.append((We0 + 4 * H, 3 * H, cat + 4 * H, 3 * H))                          # (W0e[:, H:2H])^T
+            tb.append((We0 + 8 * H, 3 * H, cat + 8 * H, 3 * H))                          # (W0e[:, 2H:])^T
+        transpose_blocks(tb, H, dev)
         for i in reversed(range(L)):
             q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
             We, se = [q[0], q[2], q[4], q[6]], q[8]
             Wn, sn = [q[9], q[11], q[13], q[15]], q[17]
             x, e, agg, He, Ue, Re, Hn, Un, Rn = saved[i]
             g = [torch.empty_like(t) for t in q]
-            # transposed weights for the dgrad chains (plumbing copies of 128x128 blocks)
-            WTn = [None] + [Wn[l].t().contiguous() for l in (1, 2, 3)]
-            WTe = [None] + [We[l].t().contiguous() for l in (1, 2, 3)]
-            WT0n_agg = Wn[0][:, H:].t().contiguous()
-            WT0e_e = We[0][:, :H].t().contiguous()
-            Wcat = torch.cat([Wn[0][:, :H].t(), We[0][:, H:2 * H].t(), We[0][:, 2 * H:].t()], dim=1).contiguous()
+            w = wt[i]
+            WTn = [None, w[0], w[1], w[2]]
+            WTe = [None, w[3], w[4], w[5]]
+            WT0n_agg, WT0e_e = w[6], w[7]
+            Wcat = w[8:11].reshape(H, 3 * H)
             # node MLP chain: dX' -> dZn[3..0], dAgg = W0n[:,H:]^T dZn0
             mlp_bwd(N, H, 4, dx, None, None, H, Un, Rn, sn, Hn, WTn, dZn, [(WT0n_agg, None, dAgg)],
                     [None] * 4, g[17])

@@ -24,6 +24,7 @@
  *   mgn_wgrad          autograd backward of nn.Linear wrt weight (dW = dZ^T X)
  *   mgn_csr_build      the dst-sorted edge order that replaces PyG's index-based
  *                        scatter (no reference counterpart: layout prep)
+ *   mgn_transpose_blocks  layout prep for mgn_mlp_bwd (autograd's implicit W^T of nn.Linear)
  */
 #ifndef MGN_HIP_H
 #define MGN_HIP_H
@@ -154,6 +155,16 @@ typedef struct {
 } mgn_wgrad_job;
 size_t mgn_wgrad_workspace_bytes(int njobs, const mgn_wgrad_job* jobs);
 int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------- batched block transpose
+ * dst[k, j] = src[j, k] for n square H x H blocks (leading dimensions ld_src / ld_dst; a block
+ * may be a column slab of a wider matrix).  Prepares the W^T operands of mgn_mlp_bwd for all
+ * rounds in one or two launches instead of ~10 small copies per round. */
+typedef struct {
+  const float* src; float* dst;
+  int ld_src, ld_dst;
+} mgn_tblock;
+int mgn_transpose_blocks(int n, const mgn_tblock* blocks, int H, void* stream);
 
 #ifdef __cplusplus
 }
