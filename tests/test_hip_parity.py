@@ -385,3 +385,26 @@ def test_large_mesh_forward_vs_oracle(dev):
     assert torch.equal(a, b)
     ref = O.epd_forward(x_in, e_in, g.edge_index, params, 2)
     assert rel_err(a, ref) < FWD_TOL
+
+
+def test_plate_like_config_vs_oracle(dev):
+    """BASELINE configs[2] shape in fp32: 3-D tetrahedral mesh (~1.3k nodes), mesh edges plus
+    radius 'world' edges (duplicates of mesh edges allowed, as add_world_edges can produce),
+    4 edge features, 3 outputs (plate.json with type=epd, SURVEY.md TL;DR item 2)."""
+    from scipy.spatial import cKDTree
+
+    N, L = 1300, 15
+    pos, ei, ea = R.delaunay_graph(N, 61, dim=3)
+    assert ea.shape[1] == 4
+    pairs = cKDTree(pos.numpy()).query_pairs(0.06, output_type="ndarray")
+    world = torch.from_numpy(np.concatenate([pairs, pairs[:, ::-1]], axis=0).T.astype(np.int64))
+    ei2 = torch.cat([ei, world], dim=1)
+    src, dst = ei2[0], ei2[1]
+    ea2 = torch.cat([pos[src] - pos[dst], (pos[dst] - pos[src]).norm(dim=-1, keepdim=True)], dim=-1)
+    params = R.make_params(R.epd_param_shapes(L, 128, 3 + 9, 4, 3), 62)
+    net = gp.EncodeProcessDecode(L, 12, 4, 3, hidden_size=128).to(dev)
+    net.load_state_dict(params)
+    x_in = R.randn((N, 12), 63)
+    out = net(gp.Graph(x=x_in.to(dev), edge_attr=ea2.to(dev), edge_index=ei2.to(dev), pos=pos.to(dev)))
+    assert out.shape == (N, 3)
+    assert rel_err(out, O.epd_forward(x_in, ea2, ei2, params, L)) < FWD_TOL
