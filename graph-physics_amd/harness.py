@@ -57,10 +57,23 @@ class Engine:
         self.model = get_model(param)
         self.sim = get_simulator(param, self.model, device)
         self.learning_rate, self.num_steps, self.warmup, self.grad_clip = learning_rate, num_steps, warmup, grad_clip
-        self.opt = torch.optim.AdamW(self.sim.parameters(), lr=learning_rate, weight_decay=0.0001, betas=(0.9, 0.95))
+        self.opt = self._make_optimizer(learning_rate, capturable=False)
         self.step_count = 0
         self.grad_sync = None  # set by distributed.DataParallel: callable(params) all-reducing .grad
         self._graph = None     # hipGraph of one training step (capture_train_step)
+
+    def _make_optimizer(self, lr, capturable: bool):
+        """AdamW(lr, betas=(0.9,0.95), weight_decay=1e-4) as the reference configures it
+        (lightning_module.py:494-511); the fused multi-tensor implementation when the device
+        supports it (one kernel instead of ~15 foreach launches over 296 tensors)."""
+        kw = dict(lr=lr, weight_decay=0.0001, betas=(0.9, 0.95))
+        params = list(self.sim.parameters())
+        if params and params[0].is_cuda:
+            try:
+                return torch.optim.AdamW(params, fused=True, capturable=capturable, **kw)
+            except (RuntimeError, ValueError, TypeError):
+                pass
+        return torch.optim.AdamW(params, capturable=capturable, **kw) if capturable else torch.optim.AdamW(params, **kw)
 
     def train_step(self, batch: Graph) -> torch.Tensor:
         self.sim.train()
@@ -100,8 +113,7 @@ class Engine:
             if isinstance(mod, Normalizer) and mod._host_num_acc is None:
                 mod._host_num_acc = int(mod._num_accumulations.item())
         self._lr_t = torch.tensor(self.learning_rate, dtype=torch.float32, device=dev)
-        self.opt = torch.optim.AdamW(self.sim.parameters(), lr=self._lr_t, weight_decay=0.0001, betas=(0.9, 0.95),
-                                     capturable=True, foreach=True)
+        self.opt = self._make_optimizer(self._lr_t, capturable=True)
         self._static = batch.clone()
         if getattr(batch, "mgn_topology", None) is not None:
             self._static.mgn_topology = batch.mgn_topology
