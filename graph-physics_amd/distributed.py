@@ -78,8 +78,11 @@ class HaloExchange(torch.autograd.Function):
         ctx.plan, ctx.group, ctx.n_own = plan, group, x_own.shape[0]
         idx = plan.send_idx.to(x_own.device)
         ctx.idx = idx
+        ctx.local = plan.world == 1 or not dist.is_initialized()
         send = x_own.detach().index_select(0, idx).contiguous()
         recv = torch.empty(plan.n_ghost, x_own.shape[1], dtype=x_own.dtype, device=x_own.device)
+        if ctx.local:  # single process: nothing to exchange (a world-1 plan has no ghosts)
+            return recv.zero_()
         dist.all_to_all_single(recv, send, output_split_sizes=plan.recv_counts, input_split_sizes=plan.send_counts, group=group)
         return recv
 
@@ -88,6 +91,8 @@ class HaloExchange(torch.autograd.Function):
         plan = ctx.plan
         d_ghost = d_ghost.contiguous()
         back = torch.empty(ctx.idx.numel(), d_ghost.shape[1], dtype=d_ghost.dtype, device=d_ghost.device)
+        if ctx.local:
+            return torch.zeros(ctx.n_own, d_ghost.shape[1], dtype=d_ghost.dtype, device=d_ghost.device), None, None
         dist.all_to_all_single(back, d_ghost, output_split_sizes=plan.send_counts, input_split_sizes=plan.recv_counts, group=ctx.group)
         d_own = torch.zeros(ctx.n_own, d_ghost.shape[1], dtype=d_ghost.dtype, device=d_ghost.device)
         d_own.index_add_(0, ctx.idx, back)

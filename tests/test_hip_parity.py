@@ -408,3 +408,30 @@ def test_plate_like_config_vs_oracle(dev):
     out = net(gp.Graph(x=x_in.to(dev), edge_attr=ea2.to(dev), edge_index=ei2.to(dev), pos=pos.to(dev)))
     assert out.shape == (N, 3)
     assert rel_err(out, O.epd_forward(x_in, ea2, ei2, params, L)) < FWD_TOL
+
+
+def test_partitioned_epd_hip_backend_world1(dev):
+    """The partitioned model on its default (HIP) backend: with a world-1 plan (everything
+    owned, no ghosts) forward and weight gradients equal the plain EncodeProcessDecode."""
+    from graph_physics_amd import distributed as D
+    from graph_physics_amd import partition as P
+
+    L, N, seed = 3, 500, 71
+    pos, ei, ea = R.delaunay_graph(N, seed)
+    params = R.make_params(R.epd_param_shapes(L, 128, 11, 3, 2), seed)
+    x_in, e_in = R.randn((N, 11), 1).to(dev), R.randn((ei.shape[1], 3), 2).to(dev)
+    cot = R.randn((N, 2), 3).to(dev)
+    ref = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=128).to(dev)
+    ref.load_state_dict(params)
+    out_ref = ref(gp.Graph(x=x_in, edge_attr=e_in, edge_index=ei.to(dev)))
+    (out_ref * cot).sum().backward()
+    net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=128).to(dev)
+    net.load_state_dict(params)
+    plan = P.build_rank_plan(ei, np.zeros(N, dtype=np.int64), 0, 1)
+    assert plan.n_ghost == 0 and plan.n_own == N
+    pm = D.PartitionedEPD(net, plan)
+    out = pm(x_in[plan.owned.to(dev)], e_in[plan.edge_ids.to(dev)])
+    (out * cot).sum().backward()
+    assert rel_err(out, out_ref) < 1e-6
+    for (k, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
+        assert rel_err(a.grad, b.grad) < 1e-5, k
