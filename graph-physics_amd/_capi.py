@@ -15,6 +15,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _REPO = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_CSRC, "libmgn_hip.so")
 SOURCES = [os.path.join(_CSRC, "mgn_kernels.hip")]
+DEPS = [os.path.join(_CSRC, "mgn_x6.inc")]  # included by the source
 HEADER = os.path.join(_REPO, "include", "mgn_hip.h")
 
 MAX_LAYERS = 8
@@ -47,6 +48,7 @@ class MlpFwdArgs(C.Structure):
         ("add_src", _f32p * 2), ("add_idx", _i32p * 2),
         ("n_post", C.c_int), ("post_ldw", C.c_int),
         ("post_W", _f32p * 2), ("post_out", _f32p * 2),
+        ("wpk", C.c_void_p * 8),
     ]
 
 
@@ -82,6 +84,13 @@ class WgradJob(C.Structure):
     ]
 
 
+class WpackBlock(C.Structure):
+    _fields_ = [("src", _f32p), ("dst", C.c_void_p), ("ld_src", C.c_int), ("transpose", C.c_int)]
+
+
+WPACK_BYTES = 98304
+
+
 class TBlock(C.Structure):
     _fields_ = [("src", _f32p), ("dst", _f32p), ("ld_src", C.c_int), ("ld_dst", C.c_int)]
 
@@ -99,6 +108,7 @@ SYMBOLS = {
     "mgn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(WgradJob)]),
     "mgn_wgrad": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_transpose_blocks": (C.c_int, [C.c_int, C.POINTER(TBlock), C.c_int, C.c_void_p]),
+    "mgn_wpack": (C.c_int, [C.c_int, C.POINTER(WpackBlock), C.c_void_p]),
 }
 
 _lib = None
@@ -118,7 +128,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(s) > t for s in SOURCES + [HEADER])
+    return any(os.path.getmtime(s) > t for s in SOURCES + DEPS + [HEADER])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -1211,6 +1211,9 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bwd_lds(const mgn_mlp_bwd_args a
     ws[i] = ((lds[i] + lds[nslot * H + i]) + lds[2 * nslot * H + i]) + lds[3 * nslot * H + i];
 }
 
+#define TB_MAX 128
+#include "mgn_x6.inc"
+
 // ===================================================================== weight grads
 struct WgradLaunch {
   int njobs;
@@ -1527,7 +1530,6 @@ __global__ void __launch_bounds__(256) k_segsum(const float* __restrict__ src, c
 }
 
 // ================================================================ batched transpose
-#define TB_MAX 128
 struct TBlocks {
   mgn_tblock b[TB_MAX];
 };
@@ -1703,10 +1705,33 @@ static int set_smem(K kern, size_t bytes) {
   return 0;
 }
 
+// split-bf16 kernels: every GEMM unit of the launch comes packed (and the fp32 override is off)
+static bool fwd_x6(const mgn_mlp_fwd_args& a) {
+  if (a.wpk[0] == nullptr || getenv("MGN_FP32_MFMA") != nullptr) return false;
+  const int G = a.nphase + a.NL - 1 + a.n_post;
+  if (G > X6_MAX_UNITS || a.NL > LDS_MAX_NL) return false;
+  // register sharing inside the kernel: gathered adds ride in the next-phase buffer
+  if (a.n_add > 0 && (a.nphase != 1 || (a.NL == 1 && a.resid != nullptr))) return false;
+  for (int u = 0; u < G; ++u)
+    if (a.wpk[u] == nullptr) return false;
+  return true;
+}
+
 template <int HB>
 static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
   const bool ragged = fwd_ragged(a);
   const MlpPlan p = plan_mlp(a.M, a.H, a.NL, ragged, false);
+  if (p.lds && fwd_x6(a)) {
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES) != hipSuccess) return 1;
+      attr_done = true;
+    }
+    unsigned grid = (unsigned)((a.M + 63) / 64);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(k_mlp_fwd_x6, dim3(grid), dim3(256), X6_FWD_LDS_BYTES, s, a);
+    return 0;
+  }
   if (p.lds) {
     if (p.mt == 2) {
       if (set_smem(k_mlp_fwd_lds<2>, p.smem)) return 1;
@@ -1760,7 +1785,7 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
 
 extern "C" {
 
-int mgn_version(void) { return 100; }
+int mgn_version(void) { return 110; }
 const char* mgn_last_error(void) { return g_err; }
 
 size_t mgn_csr_workspace_bytes(int64_t E, int64_t N) {
@@ -1989,6 +2014,21 @@ int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, v
     if (int rc = check_launch("mgn_wgrad/reduce")) return rc;
   }
   return 0;
+}
+
+int mgn_wpack(int n, const mgn_wpack_block* blocks, void* stream) {
+  if (n < 0) return fail(1, "mgn_wpack: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n; i0 += TB_MAX) {
+    WpackLaunch T;
+    const int m = (n - i0 < TB_MAX) ? n - i0 : TB_MAX;
+    for (int i = 0; i < m; ++i) {
+      T.b[i] = blocks[i0 + i];
+      if (T.b[i].src == nullptr || T.b[i].dst == nullptr || ((size_t)T.b[i].dst & 15) != 0) return fail(1, "mgn_wpack: null / misaligned block");
+    }
+    hipLaunchKernelGGL(k_wpack, dim3(8, m), dim3(256), 0, s, T);
+  }
+  return check_launch("mgn_wpack");
 }
 
 int mgn_transpose_blocks(int n, const mgn_tblock* blocks, int H, void* stream) {

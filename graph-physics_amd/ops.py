@@ -16,6 +16,10 @@ import torch
 from . import _capi
 
 EPS = 1e-8  # RMSNorm epsilon of the reference (layers.py:80)
+#: matrix path of the H = 128 kernels: split-bf16 (bf16x3 operands, 6 MFMA terms, fp32-grade
+#: accuracy at 2.67x the fp32 MFMA rate) unless MGN_FP32_MFMA is set (exact-fp32 MFMA kernels)
+import os as _os
+X6_ENABLED = _os.environ.get("MGN_FP32_MFMA") is None
 SUPPORTED_H = (16, 32, 64, 128)
 
 
@@ -136,9 +140,11 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
             saveH: Optional[Sequence[torch.Tensor]] = None, saveU: Optional[torch.Tensor] = None,
             saveR: Optional[torch.Tensor] = None, ldw0: int = 0,
             adds: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]] = (),
-            posts: Sequence[Tuple[int, torch.Tensor]] = (), post_ldw: int = 0):
+            posts: Sequence[Tuple[int, torch.Tensor]] = (), post_ldw: int = 0, wpk: Sequence[int] = ()):
     """``adds``: (rows[*,H], idx or None) gathered into the layer-0 pre-activation;
-    ``posts``: (device address of a [H,H] weight block with leading dim ``post_ldw``, out[M,H])."""
+    ``posts``: (device address of a [H,H] weight block with leading dim ``post_ldw``, out[M,H]);
+    ``wpk``: device addresses of the launch's GEMM units packed by :func:`wpack` (phases of
+    layer 0, layers 1.., post-products) -- selects the split-bf16 kernels."""
     a = _capi.MlpFwdArgs()
     a.M, a.H, a.NL, a.nphase = M, H, len(Ws), len(phases)
     for p, (src, idx, kw) in enumerate(phases):
@@ -156,6 +162,8 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
         a.add_src[q], a.add_idx[q] = _ptr(t), _ptr(ix)
     for q, (wptr, o) in enumerate(posts):
         a.post_W[q], a.post_out[q] = wptr, _ptr(o)
+    for u, addr in enumerate(wpk):
+        a.wpk[u] = addr
     dev = out.device
     with torch.cuda.device(dev):
         rc = _capi.lib().mgn_mlp_fwd(C.byref(a), _stream(dev))
@@ -210,6 +218,19 @@ def wgrad(jobs, dev):
         with torch.cuda.device(dev):
             rc = L.mgn_wgrad(len(chunk), arr, _ptr(ws), ws.numel(), _stream(dev))
         _capi.check(rc, "mgn_wgrad")
+
+
+def wpack(blocks: Sequence[Tuple[int, int, bool, int]], dev):
+    """blocks: (src_address, ld_src, transpose, dst_address) of 128 x 128 fp32 blocks ->
+    96 KB bf16x3 MFMA images (include/mgn_hip.h, mgn_wpack)."""
+    if not blocks:
+        return
+    arr = (_capi.WpackBlock * len(blocks))()
+    for i, (src, ld, tr, dst) in enumerate(blocks):
+        arr[i].src, arr[i].ld_src, arr[i].transpose, arr[i].dst = src, ld, int(bool(tr)), dst
+    with torch.cuda.device(dev):
+        rc = _capi.lib().mgn_wpack(len(blocks), arr, _stream(dev))
+    _capi.check(rc, "mgn_wpack")
 
 
 def transpose_blocks(blocks: Sequence[Tuple[int, int, int, int]], H: int, dev):
@@ -345,11 +366,33 @@ class ProcessorFunction(torch.autograd.Function):
         # kernel (x' still in registers); round 0's come from two small launches.
         split = (H == 128)
         Pd = Ps = None
+        # split-bf16 matrix path: all GEMM units of all rounds packed by one launch; per round
+        # [We0|e, We1, We2, We3, Wn0|x, Wn0|agg, Wn1, Wn2, Wn3, We0|x_dst, We0|x_src]
+        x6 = split and L > 0 and E > 0 and X6_ENABLED
+        NU = 11
+        if x6:
+            pk = torch.empty(L * NU * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+            pk0 = pk.data_ptr()
+            blocks = []
+            for i in range(L):
+                q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
+                We0, Wn0 = q[0].data_ptr(), q[9].data_ptr()
+                srcs = [(We0, 3 * H), (q[2].data_ptr(), H), (q[4].data_ptr(), H), (q[6].data_ptr(), H),
+                        (Wn0, 2 * H), (Wn0 + 4 * H, 2 * H), (q[11].data_ptr(), H), (q[13].data_ptr(), H), (q[15].data_ptr(), H),
+                        (We0 + 4 * H, 3 * H), (We0 + 8 * H, 3 * H)]
+                for u, (sa, ld) in enumerate(srcs):
+                    blocks.append((sa, ld, False, pk0 + (i * NU + u) * _capi.WPACK_BYTES))
+            wpack(blocks, dev)
+            ctx_pk = pk  # keeps the buffer alive until the launches below are enqueued
+
+            def unit(i, u):
+                return pk0 + (i * NU + u) * _capi.WPACK_BYTES
         if split and L > 0 and E > 0:
             W0 = P[0]
             Pd, Ps = torch.empty(N, H, **f), torch.empty(N, H, **f)
             for slab, dst_t in ((1, Pd), (2, Ps)):
-                mlp_fwd(N, H, [(x, None, H)], [W0[:, slab * H:(slab + 1) * H].contiguous()], [None], None, H, None, dst_t)
+                mlp_fwd(N, H, [(x, None, H)], [W0[:, slab * H:(slab + 1) * H].contiguous()], [None], None, H, None, dst_t,
+                        wpk=[unit(0, 8 + slab)] if x6 else ())
         for i in range(L):
             q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
             We, be, se = [q[0], q[2], q[4], q[6]], [q[1], q[3], q[5], q[7]], q[8]
@@ -368,7 +411,8 @@ class ProcessorFunction(torch.autograd.Function):
             # R3: m = edge_block(cat[e, x[dst], x[src]]);  e' = e + m     (layers.py:1017-1028,1039)
             if split and E > 0:
                 mlp_fwd(E, H, [(e, None, H)], We, be, se, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
-                        adds=[(Pd, topo.dst_s), (Ps, topo.src_s)])
+                        adds=[(Pd, topo.dst_s), (Ps, topo.src_s)],
+                        wpk=[unit(i, u) for u in range(4)] if x6 else ())
             else:
                 mlp_fwd(E, H, [(e, None, H), (x, topo.dst_s, H), (x, topo.src_s, H)], We, be, se, H, e, e_new, m, He, Ue, Re)
             # R4: agg = segment-sum of m over dst                          (layers.py:1031-1037)
@@ -379,8 +423,11 @@ class ProcessorFunction(torch.autograd.Function):
                 W0n = P[PARAMS_PER_BLOCK * (i + 1)]
                 Pd_n, Ps_n = torch.empty(N, H, **f), torch.empty(N, H, **f)
                 posts = [(W0n.data_ptr() + 4 * H, Pd_n), (W0n.data_ptr() + 8 * H, Ps_n)]
+            wn = ()
+            if x6:
+                wn = [unit(i, u) for u in range(4, 9)] + ([unit(i + 1, 9), unit(i + 1, 10)] if posts else [])
             mlp_fwd(N, H, [(x, None, H), (agg, None, H)], Wn, bn, sn, H, x, x_new, None, Hn, Un, Rn,
-                    posts=posts, post_ldw=3 * H)
+                    posts=posts, post_ldw=3 * H, wpk=wn)
             if need:
                 saved.append((x, e, agg, He, Ue, Re, Hn, Un, Rn))
             x, e = x_new, e_new

@@ -25,6 +25,7 @@
  *   mgn_csr_build      the dst-sorted edge order that replaces PyG's index-based
  *                        scatter (no reference counterpart: layout prep)
  *   mgn_transpose_blocks  layout prep for mgn_mlp_bwd (autograd's implicit W^T of nn.Linear)
+ *   mgn_wpack          layout prep: nn.Linear weights (or their transposes) as bf16x3 MFMA images
  */
 #ifndef MGN_HIP_H
 #define MGN_HIP_H
@@ -105,6 +106,12 @@ typedef struct {
   int post_ldw;
   const float* post_W[2];
   float* post_out[2];
+  /* --- split-bf16 matrix path (H = 128, full widths).  wpk[u] = the GEMM units of this launch
+   * packed by mgn_wpack, in stream order: the nphase column slabs of W[0], W[1..NL-1], then the
+   * n_post post_W blocks.  All of them non-NULL selects the bf16x3-operand / 6-term kernels
+   * (fp32-grade accuracy at 2.67x the fp32 MFMA rate); W[] / post_W[] are then not read, b[] /
+   * scale still are.  wpk[0] == NULL keeps the exact-fp32 MFMA kernels. */
+  const void* wpk[8];
 } mgn_mlp_fwd_args;
 int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream);
 
@@ -165,6 +172,19 @@ typedef struct {
   int ld_src, ld_dst;
 } mgn_tblock;
 int mgn_transpose_blocks(int n, const mgn_tblock* blocks, int H, void* stream);
+
+/* ------------------------------------------------------- split-bf16 weight packing
+ * Packs n 128x128 fp32 blocks (src[o*ld_src + f], or src[f*ld_src + o] when transpose != 0;
+ * a block may be a slab of a wider matrix) into the 96 KB bf16x3 image the split-bf16 kernels
+ * stream through LDS: [K-slice 0..3][piece 0..2][out block 0..7][lane 0..63][8 bf16], where
+ * w = w1 + w2 + w3 (bf16 each, round to nearest) and element i of lane (c,g) is
+ * W[16*ob + c][32*j + 16*(i>>2) + 4*g + (i&3)].  dst must be 16-byte aligned. */
+#define MGN_WPACK_BYTES 98304
+typedef struct {
+  const float* src; void* dst;
+  int ld_src, transpose;
+} mgn_wpack_block;
+int mgn_wpack(int n, const mgn_wpack_block* blocks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Split-bf16 (x6) vs exact-fp32 MFMA forward kernels on the bench edge/node shapes: HIP-event
+timing and error of both against an fp64 torch evaluation of the same MLP."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import graph_physics_amd as gp
+from graph_physics_amd import ops, _capi
+from tools.kbench import timeit
+
+dev = torch.device("cuda:0")
+g = gp.cylinder_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 16, 1885, 0).to(dev)
+topo = ops.Topology(g.edge_index, g.x.shape[0])
+N, E, H = topo.N, topo.E, 128
+f = dict(dtype=torch.float32, device=dev)
+torch.manual_seed(0)
+x, e = torch.randn(N, H, **f), torch.randn(E, H, **f)
+W0 = torch.randn(H, 3 * H, **f) * 0.05
+Wh = [torch.randn(H, H, **f) * 0.09 for _ in range(3)]
+bs = [torch.randn(H, **f) * 0.1 for _ in range(4)]
+sc = torch.rand(H, **f) + 0.5
+Pd, Ps = x @ W0[:, H:2 * H].t(), x @ W0[:, 2 * H:].t()
+
+pk = torch.empty(4 * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+units = [pk.data_ptr() + u * _capi.WPACK_BYTES for u in range(4)]
+ops.wpack([(W0.data_ptr(), 3 * H, False, units[0])] + [(Wh[l].data_ptr(), H, False, units[l + 1]) for l in range(3)], dev)
+
+
+def run(wpk, save):
+    m, e_new = torch.empty(E, H, **f), torch.empty(E, H, **f)
+    He = [torch.empty(E, H, **f) for _ in range(3)] if save else None
+    Ue, Re = (torch.empty(E, H, **f), torch.empty(E, **f)) if save else (None, None)
+    fn = lambda: ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
+                             adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=wpk)
+    fn()
+    torch.cuda.synchronize()
+    return m, e_new, He, Ue, fn
+
+
+# fp64 reference of the same MLP
+d = torch.float64
+z = e.to(d) @ W0[:, :H].to(d).t() + Pd.to(d)[topo.dst_s.long()] + Ps.to(d)[topo.src_s.long()] + bs[0].to(d)
+hs = []
+for l in range(3):
+    h = z.clamp_min(0)
+    hs.append(h)
+    z = h @ Wh[l].to(d).t() + bs[l + 1].to(d)
+rms = z.norm(dim=1, keepdim=True) / H ** 0.5
+m_ref = sc.to(d) * z / (rms + 1e-8)
+
+
+def rel(a, b):
+    return float((a.to(d) - b).abs().max() / b.abs().max())
+
+
+print(f"N={N} E={E}")
+for name, wpk in (("fp32 MFMA", ()), ("split-bf16 x6", units)):
+    for save in (False, True):
+        m, e_new, He, Ue, fn = run(wpk, save)
+        t = timeit(fn)
+        s = f"{name:14s} save={int(save)} {t*1e3:8.1f} us  {8.0*E*H*H/t/1e9:7.1f} TFLOP/s   err m {rel(m, m_ref):.2e}  e' {rel(e_new, e.to(d) + m_ref):.2e}"
+        if save:
+            s += f"  H3 {rel(He[2], hs[2]):.2e}"
+        print(s, flush=True)
