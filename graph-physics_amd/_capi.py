@@ -71,6 +71,7 @@ class MlpBwdArgs(C.Structure):
         ("db", _f32p * MAX_LAYERS),
         ("dscale", _f32p),
         ("red_ws", C.c_void_p), ("red_ws_bytes", C.c_size_t),
+        ("wpk", C.c_void_p * 4),
     ]
 
 

@@ -1212,8 +1212,6 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bwd_lds(const mgn_mlp_bwd_args a
 }
 
 #define TB_MAX 128
-#include "mgn_x6.inc"
-
 // ===================================================================== weight grads
 struct WgradLaunch {
   int njobs;
@@ -1448,6 +1446,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) P[(16 * jb + 4 * g + q) * 128 + 16 * (kb0 + kk) + c] = acc[kk][jb][q];
 }
+
+#include "mgn_x6.inc"
 
 // dW[r,k] = sum over the job's workgroup partials.  64 outputs x 4 partial-lanes per block:
 // consecutive threads read consecutive addresses of one partial (coalesced), four lanes walk
@@ -1756,9 +1756,27 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
   return 0;
 }
 
+static bool bwd_x6(const mgn_mlp_bwd_args& a) {
+  if (a.wpk[0] == nullptr || getenv("MGN_FP32_MFMA") != nullptr) return false;
+  const int G = a.NL - 1 + a.n_din;
+  if (G > 4 || G < 1) return false;
+  for (int u = 0; u < G; ++u)
+    if (a.wpk[u] == nullptr) return false;
+  return true;
+}
+
 template <int HB>
 static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
   MlpPlan p = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true);
+  if (p.lds && bwd_x6(a)) {
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6, hipFuncAttributeMaxDynamicSharedMemorySize, X6_BWD_LDS_BYTES(LDS_MAX_NL)) != hipSuccess) return 1;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(k_mlp_bwd_x6, dim3(p.grid), dim3(256), X6_BWD_LDS_BYTES(a.NL), s, a);
+    return 0;
+  }
   if (p.lds) {
     if (p.mt == 2) {
       if (set_smem(k_mlp_bwd_lds<2>, p.smem)) return 1;
@@ -2000,7 +2018,17 @@ int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, v
           return fail(2, "mgn_wgrad: cannot reserve LDS");
         attr_done = true;
       }
-      hipLaunchKernelGGL(k_wgrad_lds, dim3(total), dim3(256), smem, s, L);
+      if (getenv("MGN_FP32_MFMA") == nullptr) {
+        static thread_local bool attr6_done = false;
+        if (!attr6_done) {
+          if (hipFuncSetAttribute((const void*)k_wgrad_x6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return fail(2, "mgn_wgrad: cannot reserve LDS");
+          attr6_done = true;
+        }
+        hipLaunchKernelGGL(k_wgrad_x6, dim3(total), dim3(256), smem, s, L);
+      } else {
+        hipLaunchKernelGGL(k_wgrad_lds, dim3(total), dim3(256), smem, s, L);
+      }
     } else {
       switch (HB) {
         case 8: hipLaunchKernelGGL(k_wgrad<8>, dim3(total), dim3(256), 0, s, L); break;

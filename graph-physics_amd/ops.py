@@ -173,7 +173,7 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
 def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int, U, R, scale,
             Hs: Sequence[torch.Tensor], WT: Sequence[Optional[torch.Tensor]], dZ: Sequence[Optional[torch.Tensor]],
             din: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]],
-            db: Sequence[Optional[torch.Tensor]], dscale: Optional[torch.Tensor]):
+            db: Sequence[Optional[torch.Tensor]], dscale: Optional[torch.Tensor], wpk: Sequence[int] = ()):
     L = _capi.lib()
     a = _capi.MlpBwdArgs()
     a.M, a.H, a.NL = M, H, NL
@@ -189,6 +189,8 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
     for q, (wt0, res, dst) in enumerate(din):
         a.WT0[q], a.din_resid[q], a.dIn[q] = _ptr(wt0), _ptr(res), _ptr(dst)
     a.dscale = _ptr(dscale)
+    for u, addr in enumerate(wpk):
+        a.wpk[u] = addr
     dev = dOut.device
     nbytes = L.mgn_mlp_bwd_workspace_bytes(M, H, NL)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
@@ -450,49 +452,79 @@ class ProcessorFunction(torch.autograd.Function):
         dx_buf, de_buf = [torch.empty(N, H, **f), torch.empty(N, H, **f)], [torch.empty(E, H, **f), torch.empty(E, H, **f)]
         grads: List[Optional[torch.Tensor]] = [None] * (PARAMS_PER_BLOCK * L)
         nb = H // 16
-        # W^T operands of every round in one buffer, filled by one batched transpose launch:
-        # per round 11 H x H blocks  [WTn1..3 | WTe1..3 | WT0n_agg | WT0e_e | Wcat (H x 3H)]
         HH = H * H
-        wt = torch.empty(L, 11, H, H, **f)
-        tb = []
-        for i in range(L):
-            q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
-            base = wt.data_ptr() + 4 * (i * 11 * HH)
-            We0, Wn0 = q[0].data_ptr(), q[9].data_ptr()
-            for k, l in enumerate((1, 2, 3)):
-                tb.append((q[9 + 2 * l].data_ptr(), H, base + 4 * (k * HH), H))          # WTn[l]
-                tb.append((q[2 * l].data_ptr(), H, base + 4 * ((3 + k) * HH), H))        # WTe[l]
-            tb.append((Wn0 + 4 * H, 2 * H, base + 4 * (6 * HH), H))                      # (W0n[:, H:])^T
-            tb.append((We0, 3 * H, base + 4 * (7 * HH), H))                              # (W0e[:, :H])^T
-            cat = base + 4 * (8 * HH)                                                    # Wcat [H, 3H]
-            tb.append((Wn0, 2 * H, cat, 3 * H))                                          # (W0n[:, :H])^T
-            tb.append((We0 + 4 * H, 3 * H, cat + 4 * H, 3 * H))                          # (W0e[:, H:2H])^T
-            tb.append((We0 + 8 * H, 3 * H, cat + 8 * H, 3 * H))                          # (W0e[:, 2H:])^T
-        transpose_blocks(tb, H, dev)
+        x6 = (H == 128) and X6_ENABLED
+        NU = 11
+        if x6:
+            # split-bf16 path: the transposed GEMM units of every round packed by one launch; per
+            # round [Wn3^T, Wn2^T, Wn1^T, Wn0|agg^T, We3^T, We2^T, We1^T, We0|e^T, Wn0|x^T, We0|x_dst^T, We0|x_src^T]
+            pk = torch.empty(L * NU * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+            pk0 = pk.data_ptr()
+            blocks = []
+            for i in range(L):
+                q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
+                We0, Wn0 = q[0].data_ptr(), q[9].data_ptr()
+                srcs = [(q[15].data_ptr(), H), (q[13].data_ptr(), H), (q[11].data_ptr(), H), (Wn0 + 4 * H, 2 * H),
+                        (q[6].data_ptr(), H), (q[4].data_ptr(), H), (q[2].data_ptr(), H), (We0, 3 * H),
+                        (Wn0, 2 * H), (We0 + 4 * H, 3 * H), (We0 + 8 * H, 3 * H)]
+                for u, (sa, ld) in enumerate(srcs):
+                    blocks.append((sa, ld, True, pk0 + (i * NU + u) * _capi.WPACK_BYTES))
+            wpack(blocks, dev)
+
+            def unit(i, u):
+                return pk0 + (i * NU + u) * _capi.WPACK_BYTES
+            wt = None
+        else:
+            # W^T operands of every round in one buffer, filled by one batched transpose launch:
+            # per round 11 H x H blocks  [WTn1..3 | WTe1..3 | WT0n_agg | WT0e_e | Wcat (H x 3H)]
+            wt = torch.empty(L, 11, H, H, **f)
+            tb = []
+            for i in range(L):
+                q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
+                base = wt.data_ptr() + 4 * (i * 11 * HH)
+                We0, Wn0 = q[0].data_ptr(), q[9].data_ptr()
+                for k, l in enumerate((1, 2, 3)):
+                    tb.append((q[9 + 2 * l].data_ptr(), H, base + 4 * (k * HH), H))          # WTn[l]
+                    tb.append((q[2 * l].data_ptr(), H, base + 4 * ((3 + k) * HH), H))        # WTe[l]
+                tb.append((Wn0 + 4 * H, 2 * H, base + 4 * (6 * HH), H))                      # (W0n[:, H:])^T
+                tb.append((We0, 3 * H, base + 4 * (7 * HH), H))                              # (W0e[:, :H])^T
+                cat = base + 4 * (8 * HH)                                                    # Wcat [H, 3H]
+                tb.append((Wn0, 2 * H, cat, 3 * H))                                          # (W0n[:, :H])^T
+                tb.append((We0 + 4 * H, 3 * H, cat + 4 * H, 3 * H))                          # (W0e[:, H:2H])^T
+                tb.append((We0 + 8 * H, 3 * H, cat + 8 * H, 3 * H))                          # (W0e[:, 2H:])^T
+            transpose_blocks(tb, H, dev)
         for i in reversed(range(L)):
             q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
             We, se = [q[0], q[2], q[4], q[6]], q[8]
             Wn, sn = [q[9], q[11], q[13], q[15]], q[17]
             x, e, agg, He, Ue, Re, Hn, Un, Rn = saved[i]
             g = [torch.empty_like(t) for t in q]
-            w = wt[i]
-            WTn = [None, w[0], w[1], w[2]]
-            WTe = [None, w[3], w[4], w[5]]
-            WT0n_agg, WT0e_e = w[6], w[7]
-            Wcat = w[8:11].reshape(H, 3 * H)
+            if x6:
+                # never dereferenced on the packed path: any valid [H,H] / [H,3H] tensors do
+                WTn = WTe = [None, q[2], q[2], q[2]]
+                WT0n_agg = WT0e_e = q[2]
+                Wcat = q[0]
+                kn, ke, kx = [unit(i, u) for u in range(4)], [unit(i, u) for u in range(4, 8)], [unit(i, u) for u in range(8, 11)]
+            else:
+                w = wt[i]
+                WTn = [None, w[0], w[1], w[2]]
+                WTe = [None, w[3], w[4], w[5]]
+                WT0n_agg, WT0e_e = w[6], w[7]
+                Wcat = w[8:11].reshape(H, 3 * H)
+                kn = ke = kx = ()
             # node MLP chain: dX' -> dZn[3..0], dAgg = W0n[:,H:]^T dZn0
             mlp_bwd(N, H, 4, dx, None, None, H, Un, Rn, sn, Hn, WTn, dZn, [(WT0n_agg, None, dAgg)],
-                    [None] * 4, g[17])
+                    [None] * 4, g[17], wpk=kn)
             # edge MLP chain: dM = dE' + dAgg[dst] -> dZe[3..0], dE = dE' + W0e[:, :H]^T dZe0
             de_new = de_buf[0] if de.data_ptr() != de_buf[0].data_ptr() else de_buf[1]
             mlp_bwd(E, H, 4, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
-                    [None] * 4, g[8])
+                    [None] * 4, g[8], wpk=ke)
             # scatter of the first-layer pre-activations' grads onto dst / src nodes
             segsum(dZe[0], topo.rowptr_dst, None, Sd)
             segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)
             # dX = dX' + W0n[:, :H]^T dZn0 + W0e[:, H:2H]^T Sd + W0e[:, 2H:]^T Ss
             dx_new = dx_buf[0] if dx.data_ptr() != dx_buf[0].data_ptr() else dx_buf[1]
-            mlp_fwd(N, H, [(dZn[0], None, H), (Sd, None, H), (Ss, None, H)], [Wcat], [None], None, H, dx, dx_new)
+            mlp_fwd(N, H, [(dZn[0], None, H), (Sd, None, H), (Ss, None, H)], [Wcat], [None], None, H, dx, dx_new, wpk=kx)
             # weight gradients: dW = dZ^T X
             # (A = dZ, B = layer input, dW slab[, db = bias gradient as a by-product])
             jobs = [

@@ -143,6 +143,10 @@ typedef struct {
   float* db[MGN_MAX_LAYERS];        /* [pad16(width)] or NULL */
   float* dscale;                    /* [H] or NULL */
   void* red_ws; size_t red_ws_bytes;
+  /* split-bf16 matrix path (H = 128, full widths, n_din <= 1): the launch's GEMM units packed
+   * by mgn_wpack(transpose = 1 of the forward weights) in stream order WT[NL-1], ..., WT[1],
+   * then WT0[0] if n_din == 1.  wpk[0] == NULL keeps the exact-fp32 MFMA kernels. */
+  const void* wpk[4];
 } mgn_mlp_bwd_args;
 size_t mgn_mlp_bwd_workspace_bytes(int64_t M, int H, int NL);
 int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream);

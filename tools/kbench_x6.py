@@ -65,3 +65,26 @@ for name, wpk in (("fp32 MFMA", ()), ("split-bf16 x6", units)):
         if save:
             s += f"  H3 {rel(He[2], hs[2]):.2e}"
         print(s, flush=True)
+
+# ---- backward chain: fp32 vs x6 (timing; values checked against each other)
+m, e_new, He, Ue, fn = run((), True)
+Re = torch.empty(E, **f)
+ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, m, He, Ue, Re, ldw0=3 * H, adds=[(Pd, topo.dst_s), (Ps, topo.src_s)])
+de, dagg = torch.randn(E, H, **f), torch.randn(N, H, **f)
+WT = [None] + [w.t().contiguous() for w in Wh]
+WT0 = W0[:, :H].t().contiguous()
+pkb = torch.empty(4 * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+ub = [pkb.data_ptr() + u * _capi.WPACK_BYTES for u in range(4)]
+ops.wpack([(Wh[2].data_ptr(), H, True, ub[0]), (Wh[1].data_ptr(), H, True, ub[1]), (Wh[0].data_ptr(), H, True, ub[2]), (W0.data_ptr(), 3 * H, True, ub[3])], dev)
+res = {}
+for name, wpk in (("fp32 MFMA", ()), ("split-bf16 x6", ub)):
+    dZ = [torch.empty(E, H, **f) for _ in range(4)]
+    de_new, dsc = torch.empty(E, H, **f), torch.empty(H, **f)
+    fnb = lambda: ops.mlp_bwd(E, H, 4, de, dagg, topo.dst_s, H, Ue, Re, sc, He, WT, dZ, [(WT0, de, de_new)], [None] * 4, dsc, wpk=wpk)
+    fnb()
+    torch.cuda.synchronize()
+    res[name] = (dZ, de_new, dsc)
+    t = timeit(fnb)
+    print(f"bwd chain {name:14s} {t*1e3:8.1f} us  {8.0*E*H*H/t/1e9:7.1f} TFLOP/s", flush=True)
+a_, b_ = res["fp32 MFMA"], res["split-bf16 x6"]
+print("bwd x6 vs fp32: dZ", [f"{rel(b_[0][l], a_[0][l].to(d)):.1e}" for l in range(4)], f"dE {rel(b_[1], a_[1].to(d)):.1e} dscale {rel(b_[2], a_[2].to(d)):.1e}")

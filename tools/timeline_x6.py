@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Debug: s_memrealtime timeline of wave 0 of the first / last workgroups of the split-bf16
+edge-forward kernel (needs tools/libexp_TLX.so = the engine built with -DMGN_TIMELINE)."""
+import ctypes as C, os, shutil, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+lib_path = os.path.join(R, "graph-physics_amd", "csrc", "libmgn_hip.so")
+shutil.copy(lib_path, "/tmp/libmgn_orig.so")
+shutil.copy(os.path.join(R, "tools", "libexp_TLX.so"), lib_path)
+try:
+    import torch, graph_physics_amd as gp
+    from graph_physics_amd import ops, _capi
+    dev = torch.device("cuda:0")
+    g = gp.cylinder_batch(16, 1885, 0).to(dev)
+    topo = ops.Topology(g.edge_index, g.x.shape[0])
+    N, E, H = topo.N, topo.E, 128
+    f = dict(dtype=torch.float32, device=dev)
+    x, e = torch.randn(N, H, **f), torch.randn(E, H, **f)
+    W0 = torch.randn(H, 3 * H, **f) * 0.05
+    Wh = [torch.randn(H, H, **f) * 0.09 for _ in range(3)]
+    bs = [torch.zeros(H, **f) for _ in range(4)]
+    sc = torch.ones(H, **f)
+    Pd, Ps = x @ W0[:, H:2 * H].t(), x @ W0[:, 2 * H:].t()
+    m, e_new = torch.empty(E, H, **f), torch.empty(E, H, **f)
+    save = len(sys.argv) > 1 and sys.argv[1] == "save"
+    He = [torch.empty(E, H, **f) for _ in range(3)] if save else None
+    Ue, Re = (torch.empty(E, H, **f), torch.empty(E, **f)) if save else (None, None)
+    pk = torch.empty(4 * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+    units = [pk.data_ptr() + u * _capi.WPACK_BYTES for u in range(4)]
+    ops.wpack([(W0.data_ptr(), 3 * H, False, units[0])] + [(Wh[l].data_ptr(), H, False, units[l + 1]) for l in range(3)], dev)
+    L = _capi.lib()
+    L.mgn_debug_timeline.restype = C.c_int
+    buf = (C.c_ulonglong * (8 * 512))(); pos = (C.c_int * 8)()
+    for it in range(3):
+        ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
+                    adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units)
+        torch.cuda.synchronize()
+        L.mgn_debug_timeline(buf, pos)
+    names = {1: "T", 3: "pre", 4: "bar", 5: "gemm", 6: "drain", 7: "epi", 8: "end"}
+    firsts = [(buf[b * 512] >> 8) for b in range(8)]
+    lasts = [(buf[b * 512 + max(pos[b] - 1, 0)] >> 8) for b in range(8)]
+    print("census (100 MHz ticks = 10 ns): first stamp rel. to WG0:", [f - firsts[0] for f in firsts])
+    print("                                last stamp rel. to WG0 first:", [l - firsts[0] for l in lasts])
+    for b in (0, 1, 4):
+        n = pos[b]
+        ev = [(buf[b * 512 + i] >> 8, buf[b * 512 + i] & 255) for i in range(n)]
+        print(f"--- workgroup slot {b}: {n} stamps; deltas in 10 ns ticks (tag = interval ENDING at that stamp)")
+        tot = {}
+        line = []
+        for i in range(1, n):
+            d = ev[i][0] - ev[i - 1][0]
+            tag = names[ev[i][1]]
+            tot[tag] = tot.get(tag, 0) + d
+            line.append(f"{tag}{d}")
+            if ev[i][1] == 8:
+                print("  " + " ".join(line)); line = []
+        print("  totals:", tot, "span", ev[n - 1][0] - ev[0][0])
+finally:
+    shutil.copy("/tmp/libmgn_orig.so", lib_path)
