@@ -10,9 +10,11 @@ already resident in HBM).  For N>1 every rank steps its own batch of 16 and the
 gradients are all-reduced over RCCL each step (weak scaling; value = N*K/T).
 
 The JSON line also carries
-  roofline      MFMA roofline of the dominant kernel (edge-MLP forward, fp32 MFMA),
-                timed live with HIP events on the launch stream,
+  roofline      HBM roofline of the edge-update kernel (with the split-bf16 matrix path the
+                fused MLP kernels are bound by HBM traffic, not by MFMA; the MFMA fraction is
+                carried along), timed in situ with HIP events on the launch stream,
   roofline_scatter   HBM roofline of the segment-sum (scatter-add) kernel,
+  roofline_other_kernels   the same for the backward chain and the weight-gradient kernel,
   cpu_baseline  the torch-CPU oracle timed on the host cores on a bounded sample.
 """
 import argparse
@@ -49,62 +51,88 @@ def parse():
     return ap.parse_args()
 
 
-def time_kernel(fn, iters=20, warm=3):
-    """average launch duration (ms) measured with HIP events on the current stream"""
-    for _ in range(warm):
-        fn()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters):
-        fn()
-    b.record()
-    b.synchronize()
-    return a.elapsed_time(b) / iters
+PEAK_MFMA_BF16 = 2500.0  # TFLOP/s dense bf16 MFMA (same table)
 
 
-def kernel_rooflines(gp, ops, batch, model, dev):
-    """Live per-kernel timings (HIP events on the launch stream) of the two kernels the
-    rooflines are quoted for, launched exactly as the training step launches them."""
-    from graph_physics_amd.layers import _block_params
-
+def kernel_rooflines(gp, ops, eng, batch, dev, steps=3):
+    """In-situ per-kernel timings: HIP events (torch's current stream = the launch stream) around
+    every launch of the hot kernels inside `steps` real training steps -- cold caches, the real
+    operands -- rather than a warm micro-benchmark (a 92 MB operand set sits in the 256 MB
+    Infinity Cache and flatters the kernel by ~15 %).  The rocprofv3 kernel-trace average of the
+    same command (profiles/) must agree with `launch_ms`."""
     topo = batch.mgn_topology
-    N, E, H = topo.N, topo.E, model.hidden_size
-    f = dict(dtype=torch.float32, device=dev)
-    x, e = torch.randn(N, H, **f), torch.randn(E, H, **f)
-    Pd, Ps = torch.randn(N, H, **f), torch.randn(N, H, **f)
-    q = [p.detach() for p in _block_params(model.processor_list[0])]
-    We, be, se = [q[0], q[2], q[4], q[6]], [q[1], q[3], q[5], q[7]], q[8]
-    m, e_new, agg = torch.empty(E, H, **f), torch.empty(E, H, **f), torch.empty(N, H, **f)
-    He = [torch.empty(E, H, **f) for _ in range(3)]
-    Ue, Re = torch.empty(E, H, **f), torch.empty(E, **f)
+    N, E, H = topo.N, topo.E, eng.model.hidden_size
+    rec = {"edge_fwd": [], "edge_bwd": [], "wgrad": [], "segsum": []}
+    orig = (ops.mlp_fwd, ops.mlp_bwd, ops.wgrad, ops.segsum)
 
-    def edge_fwd():  # training-mode edge update: split first layer + 3 layers + RMSNorm + residual + saves
-        ops.mlp_fwd(E, H, [(e, None, H)], We, be, se, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
-                    adds=[(Pd, topo.dst_s), (Ps, topo.src_s)])
+    def timed(tag, fn, pred):
+        def w(*a, **k):
+            if not pred(a, k):
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            rec[tag].append((e0, e1))
+            return r
+        return w
 
-    def seg():
-        ops.segsum(m, topo.rowptr_dst, None, agg)
-
-    t_edge = min(time_kernel(edge_fwd) for _ in range(3))
-    t_seg = min(time_kernel(seg, iters=50) for _ in range(3))
-    flops = 8.0 * E * H * H  # 4 GEMM units of 2*E*H*H: W_e.e + 3 layers (the x projections are N-row work)
-    ach = flops / (t_edge * 1e-3) / 1e12
-    seg_bytes = 4.0 * E * H + 4.0 * N * H + 4.0 * (N + 1)  # read m, write agg, read rowptr
-    ach_seg = seg_bytes / (t_seg * 1e-3) / 1e9
-    traffic = None
+    ops.mlp_fwd = timed("edge_fwd", orig[0], lambda a, k: a[0] == E and a[1] == H and (k.get("saveH") is not None or (len(a) > 10 and a[10] is not None)))
+    ops.mlp_bwd = timed("edge_bwd", orig[1], lambda a, k: a[0] == E and a[1] == H)
+    ops.wgrad = timed("wgrad", orig[2], lambda a, k: len(a[0]) >= 8)
+    ops.segsum = timed("segsum", orig[3], lambda a, k: a[0].shape[0] == E and a[2] is None)
+    try:
+        for _ in range(steps):
+            eng.train_step(batch)
+        torch.cuda.synchronize()
+    finally:
+        ops.mlp_fwd, ops.mlp_bwd, ops.wgrad, ops.segsum = orig
+    ms = {t: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None) for t, v in rec.items()}
+    n = {t: len(v) // steps for t, v in rec.items()}
+    traffic = {}
     try:
         with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as fh:
             traffic = json.load(fh)
     except Exception:  # noqa: BLE001
-        traffic = {}
-    roof = {"kernel": "k_mlp_fwd_lds<1> (edge update: W_e.e + gathered node projections, 3 Linear, RMSNorm, residual, training saves)",
-            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic.get("edge_fwd_bytes"), "launch_ms": round(t_edge, 4),
-            "flops_per_launch": flops, "algorithmic_bytes_per_launch": 4.0 * H * (8 * E)}
-    roof_seg = {"kernel": "k_segsum<8> (CSR segment-sum of edge messages)", "bound": "hbm", "achieved": round(ach_seg, 1),
-                "peak": PEAK_HBM, "unit": "GB/s", "frac": round(ach_seg / PEAK_HBM, 4), "traffic": traffic.get("segsum_bytes"),
-                "launch_ms": round(t_seg, 5), "bytes_per_launch": seg_bytes}
-    return roof, roof_seg
+        pass
+    x6 = ops.X6_ENABLED and H == 128
+    units = 8.0 * E * H * H  # 4 GEMM units of 2*E*H*H per edge launch (the x projections are N-row work)
+
+    def hbm(kernel, t, nbytes, key, extra=None):
+        ach = nbytes / (t * 1e-3) / 1e9
+        d = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM, "unit": "GB/s",
+             "frac": round(ach / PEAK_HBM, 4), "traffic": traffic.get(key), "launch_ms": round(t, 5),
+             "algorithmic_bytes_per_launch": nbytes}
+        if extra:
+            d.update(extra)
+        return d
+
+    def mfma(t, terms):
+        ach = terms * units / (t * 1e-3) / 1e12
+        peak = PEAK_MFMA_BF16 if x6 else PEAK_MFMA_F32
+        return {"mfma_achieved_tflops": round(ach, 1), "mfma_peak_tflops": peak, "mfma_frac": round(ach / peak, 4),
+                "mfma_note": ("6 bf16 MFMA terms per fp32 product (bf16x3 split operands, fp32 accumulate)" if x6 else "fp32 MFMA"),
+                "fp32_equiv_tflops": round(units / (t * 1e-3) / 1e12, 1)}
+
+    # algorithmic bytes (DESIGN.md section 4): fp32 rows of H floats; masks 3 x 16 B, rms 4 B per row
+    row = 4.0 * H
+    b_fwd = row * (7 * E + 2 * N) + 52.0 * E + 8.0 * E   # e, e', m, H1-3, U | Pd, Ps | rms + masks | dst/src idx
+    b_bwd = row * (7 * E + N) + 52.0 * E + 4.0 * E       # dE', U, dZ0-3 (w), dE (w) | dAgg | rms + masks | dst idx
+    b_wg = row * (8 * E + 12 * N)                        # 4 edge jobs (dZ, X) + 6 node jobs, 1 launch per round
+    b_seg = row * (E + N) + 4.0 * (N + 1)
+    t = "x6" if x6 else "lds<1>"
+    roof = hbm(f"k_mlp_fwd_{t} (edge update, training mode: W_e.e + gathered node projections, 3 Linear, RMSNorm, residual, saves)",
+               ms["edge_fwd"], b_fwd, "edge_fwd_bytes", mfma(ms["edge_fwd"], 6 if x6 else 1))
+    roof["launches_per_step"] = n["edge_fwd"]
+    others = [
+        hbm(f"k_mlp_bwd_{t} + k_colred (edge backward chain: RMSNorm bwd, 3 masked dgrad GEMMs, input grad)", ms["edge_bwd"], b_bwd,
+            "edge_bwd_bytes", dict(mfma(ms["edge_bwd"], 6 if x6 else 1), launches_per_step=n["edge_bwd"])),
+        hbm(f"k_wgrad_{'x6' if x6 else 'lds'} + k_wgrad_red (weight gradients of one round: 4 edge + 6..7 node jobs)", ms["wgrad"], b_wg,
+            "wgrad_bytes", {"launches_per_step": n["wgrad"]}),
+    ]
+    roof_seg = hbm("k_segsum<8> (CSR segment-sum of edge messages)", ms["segsum"], b_seg, "segsum_bytes",
+                   {"launches_per_step": n["segsum"]})
+    return roof, roof_seg, others
 
 
 def cpu_baseline(args, gp):
@@ -225,6 +253,8 @@ def main():
             "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "matrix_path": ("bf16x3 split operands, 6-term products on v_mfma_f32_16x16x32_bf16, fp32 accumulate "
+                            "(fp32-grade accuracy: forward parity 1e-5 vs the CPU oracle)" if ops.X6_ENABLED else "fp32 MFMA"),
             "config": {"workload": f"CylinderFlow-like Delaunay meshes, {args.batch} x {args.nodes} nodes per GPU batch "
                        f"(N={N}, E={E}), {args.rounds} MP rounds, latent {args.hidden}, fp32, random-init weights; "
                        "BASELINE.json configs[1]", "global_batch_meshes": args.batch * world, "launch": graph_note,
@@ -233,8 +263,8 @@ def main():
             "rollout_ms_per_step": round(1e3 * dt_r / args.rollout_steps, 3),
         }
         if not args.no_kernel_timing:
-            roof, roof_seg = kernel_rooflines(gp, ops, batch, eng.model, dev)
-            out["roofline"], out["roofline_scatter"] = roof, roof_seg
+            roof, roof_seg, others = kernel_rooflines(gp, ops, eng, batch, dev)
+            out["roofline"], out["roofline_scatter"], out["roofline_other_kernels"] = roof, roof_seg, others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, gp)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

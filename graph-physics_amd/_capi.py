@@ -49,6 +49,7 @@ class MlpFwdArgs(C.Structure):
         ("n_post", C.c_int), ("post_ldw", C.c_int),
         ("post_W", _f32p * 2), ("post_out", _f32p * 2),
         ("wpk", C.c_void_p * 8),
+        ("saveM", C.c_void_p * MAX_LAYERS),
     ]
 
 
@@ -72,6 +73,7 @@ class MlpBwdArgs(C.Structure):
         ("dscale", _f32p),
         ("red_ws", C.c_void_p), ("red_ws_bytes", C.c_size_t),
         ("wpk", C.c_void_p * 4),
+        ("Ms", C.c_void_p * MAX_LAYERS),
     ]
 
 

@@ -1762,6 +1762,8 @@ static bool bwd_x6(const mgn_mlp_bwd_args& a) {
   if (G > 4 || G < 1) return false;
   for (int u = 0; u < G; ++u)
     if (a.wpk[u] == nullptr) return false;
+  for (int l = 1; l < a.NL; ++l)
+    if (a.Ms[l - 1] == nullptr) return false;  // the split-bf16 chain reads ReLU masks as bits
   return true;
 }
 

@@ -140,7 +140,8 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
             saveH: Optional[Sequence[torch.Tensor]] = None, saveU: Optional[torch.Tensor] = None,
             saveR: Optional[torch.Tensor] = None, ldw0: int = 0,
             adds: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]] = (),
-            posts: Sequence[Tuple[int, torch.Tensor]] = (), post_ldw: int = 0, wpk: Sequence[int] = ()):
+            posts: Sequence[Tuple[int, torch.Tensor]] = (), post_ldw: int = 0, wpk: Sequence[int] = (),
+            saveM: Optional[Sequence[torch.Tensor]] = None):
     """``adds``: (rows[*,H], idx or None) gathered into the layer-0 pre-activation;
     ``posts``: (device address of a [H,H] weight block with leading dim ``post_ldw``, out[M,H]);
     ``wpk``: device addresses of the launch's GEMM units packed by :func:`wpack` (phases of
@@ -164,6 +165,9 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
         a.post_W[q], a.post_out[q] = wptr, _ptr(o)
     for u, addr in enumerate(wpk):
         a.wpk[u] = addr
+    if saveM is not None:
+        for l, t in enumerate(saveM):
+            a.saveM[l] = _ptr(t)
     dev = out.device
     with torch.cuda.device(dev):
         rc = _capi.lib().mgn_mlp_fwd(C.byref(a), _stream(dev))
@@ -173,7 +177,8 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
 def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int, U, R, scale,
             Hs: Sequence[torch.Tensor], WT: Sequence[Optional[torch.Tensor]], dZ: Sequence[Optional[torch.Tensor]],
             din: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]],
-            db: Sequence[Optional[torch.Tensor]], dscale: Optional[torch.Tensor], wpk: Sequence[int] = ()):
+            db: Sequence[Optional[torch.Tensor]], dscale: Optional[torch.Tensor], wpk: Sequence[int] = (),
+            Ms: Optional[Sequence[torch.Tensor]] = None):
     L = _capi.lib()
     a = _capi.MlpBwdArgs()
     a.M, a.H, a.NL = M, H, NL
@@ -191,6 +196,9 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
     a.dscale = _ptr(dscale)
     for u, addr in enumerate(wpk):
         a.wpk[u] = addr
+    if Ms is not None:
+        for l, t in enumerate(Ms):
+            a.Ms[l] = _ptr(t)
     dev = dOut.device
     nbytes = L.mgn_mlp_bwd_workspace_bytes(M, H, NL)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
@@ -407,14 +415,18 @@ class ProcessorFunction(torch.autograd.Function):
                 Ue, Re = torch.empty(E, H, **f), torch.empty(E, **f)
                 Hn = [torch.empty(N, H, **f) for _ in range(3)]
                 Un, Rn = torch.empty(N, H, **f), torch.empty(N, **f)
+                # ReLU masks as bits (16 B per row and layer): what the backward chain reads
+                Me = [torch.empty(E, 4, dtype=torch.int32, device=dev) for _ in range(3)] if x6 else None
+                Mn = [torch.empty(N, 4, dtype=torch.int32, device=dev) for _ in range(3)] if x6 else None
             else:
                 He = Hn = None
                 Ue = Re = Un = Rn = None
+                Me = Mn = None
             # R3: m = edge_block(cat[e, x[dst], x[src]]);  e' = e + m     (layers.py:1017-1028,1039)
             if split and E > 0:
                 mlp_fwd(E, H, [(e, None, H)], We, be, se, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
                         adds=[(Pd, topo.dst_s), (Ps, topo.src_s)],
-                        wpk=[unit(i, u) for u in range(4)] if x6 else ())
+                        wpk=[unit(i, u) for u in range(4)] if x6 else (), saveM=Me)
             else:
                 mlp_fwd(E, H, [(e, None, H), (x, topo.dst_s, H), (x, topo.src_s, H)], We, be, se, H, e, e_new, m, He, Ue, Re)
             # R4: agg = segment-sum of m over dst                          (layers.py:1031-1037)
@@ -429,9 +441,9 @@ class ProcessorFunction(torch.autograd.Function):
             if x6:
                 wn = [unit(i, u) for u in range(4, 9)] + ([unit(i + 1, 9), unit(i + 1, 10)] if posts else [])
             mlp_fwd(N, H, [(x, None, H), (agg, None, H)], Wn, bn, sn, H, x, x_new, None, Hn, Un, Rn,
-                    posts=posts, post_ldw=3 * H, wpk=wn)
+                    posts=posts, post_ldw=3 * H, wpk=wn, saveM=Mn)
             if need:
-                saved.append((x, e, agg, He, Ue, Re, Hn, Un, Rn))
+                saved.append((x, e, agg, He, Ue, Re, Hn, Un, Rn, Me, Mn))
             x, e = x_new, e_new
             Pd, Ps = Pd_n, Ps_n
         ctx.topo, ctx.L, ctx.P, ctx.saved_acts = topo, L, P, saved
@@ -453,7 +465,7 @@ class ProcessorFunction(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * (PARAMS_PER_BLOCK * L)
         nb = H // 16
         HH = H * H
-        x6 = (H == 128) and X6_ENABLED
+        x6 = (H == 128) and X6_ENABLED and L > 0 and saved[0][9] is not None
         NU = 11
         if x6:
             # split-bf16 path: the transposed GEMM units of every round packed by one launch; per
@@ -497,7 +509,7 @@ class ProcessorFunction(torch.autograd.Function):
             q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
             We, se = [q[0], q[2], q[4], q[6]], q[8]
             Wn, sn = [q[9], q[11], q[13], q[15]], q[17]
-            x, e, agg, He, Ue, Re, Hn, Un, Rn = saved[i]
+            x, e, agg, He, Ue, Re, Hn, Un, Rn, Me, Mn = saved[i]
             g = [torch.empty_like(t) for t in q]
             if x6:
                 # never dereferenced on the packed path: any valid [H,H] / [H,3H] tensors do
@@ -514,11 +526,11 @@ class ProcessorFunction(torch.autograd.Function):
                 kn = ke = kx = ()
             # node MLP chain: dX' -> dZn[3..0], dAgg = W0n[:,H:]^T dZn0
             mlp_bwd(N, H, 4, dx, None, None, H, Un, Rn, sn, Hn, WTn, dZn, [(WT0n_agg, None, dAgg)],
-                    [None] * 4, g[17], wpk=kn)
+                    [None] * 4, g[17], wpk=kn, Ms=Mn)
             # edge MLP chain: dM = dE' + dAgg[dst] -> dZe[3..0], dE = dE' + W0e[:, :H]^T dZe0
             de_new = de_buf[0] if de.data_ptr() != de_buf[0].data_ptr() else de_buf[1]
             mlp_bwd(E, H, 4, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
-                    [None] * 4, g[8], wpk=ke)
+                    [None] * 4, g[8], wpk=ke, Ms=Me)
             # scatter of the first-layer pre-activations' grads onto dst / src nodes
             segsum(dZe[0], topo.rowptr_dst, None, Sd)
             segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)

@@ -112,6 +112,10 @@ typedef struct {
    * (fp32-grade accuracy at 2.67x the fp32 MFMA rate); W[] / post_W[] are then not read, b[] /
    * scale still are.  wpk[0] == NULL keeps the exact-fp32 MFMA kernels. */
   const void* wpk[8];
+  /* saveM[l] ([M][4] uint32, optional, split-bf16 kernels only): sign bits of saveH[l] -- word g
+   * of row m holds bit 4*ib + r for feature 16*ib + 4*g + r (set iff the activation is > 0).
+   * The backward chain needs only these 16 bytes per row and layer, not the 512-byte fp32 row. */
+  uint32_t* saveM[MGN_MAX_LAYERS];
 } mgn_mlp_fwd_args;
 int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream);
 
@@ -147,6 +151,9 @@ typedef struct {
    * by mgn_wpack(transpose = 1 of the forward weights) in stream order WT[NL-1], ..., WT[1],
    * then WT0[0] if n_din == 1.  wpk[0] == NULL keeps the exact-fp32 MFMA kernels. */
   const void* wpk[4];
+  /* Ms[l-1] = saveM[l-1] of the forward launch (ReLU masks as bits).  Required by the split-bf16
+   * kernel (it does not read Hs); ignored by the fp32 kernels. */
+  const uint32_t* Ms[MGN_MAX_LAYERS];
 } mgn_mlp_bwd_args;
 size_t mgn_mlp_bwd_workspace_bytes(int64_t M, int H, int NL);
 int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream);

@@ -33,8 +33,9 @@ def run(wpk, save):
     m, e_new = torch.empty(E, H, **f), torch.empty(E, H, **f)
     He = [torch.empty(E, H, **f) for _ in range(3)] if save else None
     Ue, Re = (torch.empty(E, H, **f), torch.empty(E, **f)) if save else (None, None)
+    Me = [torch.empty(E, 4, dtype=torch.int32, device=dev) for _ in range(3)] if (save and wpk) else None
     fn = lambda: ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
-                             adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=wpk)
+                             adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=wpk, saveM=Me)
     fn()
     torch.cuda.synchronize()
     return m, e_new, He, Ue, fn
@@ -69,7 +70,14 @@ for name, wpk in (("fp32 MFMA", ()), ("split-bf16 x6", units)):
 # ---- backward chain: fp32 vs x6 (timing; values checked against each other)
 m, e_new, He, Ue, fn = run((), True)
 Re = torch.empty(E, **f)
-ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, m, He, Ue, Re, ldw0=3 * H, adds=[(Pd, topo.dst_s), (Ps, topo.src_s)])
+Me = [torch.empty(E, 4, dtype=torch.int32, device=dev) for _ in range(3)]
+ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, m, He, Ue, Re, ldw0=3 * H, adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units, saveM=Me)
+for l in range(3):  # mask bits against the saved activations
+    bits = (He[l].view(E, 8, 4, 4) > 0).permute(0, 2, 1, 3).reshape(E, 4, 32).long()  # [row][g][4*ib+r]
+    want = (bits << torch.arange(32, device=dev)).sum(-1)
+    got = Me[l].long() & 0xffffffff
+    assert torch.equal(got, want), f"mask bits of layer {l + 1} differ"
+print("mask bits == (saved activation > 0)")
 de, dagg = torch.randn(E, H, **f), torch.randn(N, H, **f)
 WT = [None] + [w.t().contiguous() for w in Wh]
 WT0 = W0[:, :H].t().contiguous()
@@ -80,7 +88,7 @@ res = {}
 for name, wpk in (("fp32 MFMA", ()), ("split-bf16 x6", ub)):
     dZ = [torch.empty(E, H, **f) for _ in range(4)]
     de_new, dsc = torch.empty(E, H, **f), torch.empty(H, **f)
-    fnb = lambda: ops.mlp_bwd(E, H, 4, de, dagg, topo.dst_s, H, Ue, Re, sc, He, WT, dZ, [(WT0, de, de_new)], [None] * 4, dsc, wpk=wpk)
+    fnb = lambda: ops.mlp_bwd(E, H, 4, de, dagg, topo.dst_s, H, Ue, Re, sc, He, WT, dZ, [(WT0, de, de_new)], [None] * 4, dsc, wpk=wpk, Ms=Me)
     fnb()
     torch.cuda.synchronize()
     res[name] = (dZ, de_new, dsc)
