@@ -48,6 +48,9 @@ def parse():
                          "E <= 65536 edges per GPU batch; at batch 16 eager launches are already GPU-bound and "
                          "measured 7 %% faster than replay)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
+                    help="matrix precision of the processor GEMMs: fp32 = BASELINE configs[1] (headline); bf16 = the "
+                         "reference's bf16-mixed semantic (configs[2]-style), reported with dtype bf16")
     return ap.parse_args()
 
 
@@ -77,8 +80,8 @@ def kernel_rooflines(gp, ops, eng, batch, dev, steps=3):
             return r
         return w
 
-    ops.mlp_fwd = timed("edge_fwd", orig[0], lambda a, k: a[0] == E and a[1] == H and (k.get("saveH") is not None or (len(a) > 10 and a[10] is not None)))
-    ops.mlp_bwd = timed("edge_bwd", orig[1], lambda a, k: a[0] == E and a[1] == H)
+    ops.mlp_fwd = timed("edge_fwd", orig[0], lambda a, k: a[0] == E and a[1] == H and k.get("adds") and (len(a) > 10 and a[10] is not None))
+    ops.mlp_bwd = timed("edge_bwd", orig[1], lambda a, k: a[0] == E and a[1] == H and a[4] is not None)  # dOut2 = dAgg: the processor's edge chain
     ops.wgrad = timed("wgrad", orig[2], lambda a, k: len(a[0]) >= 8)
     ops.segsum = timed("segsum", orig[3], lambda a, k: a[0].shape[0] == E and a[2] is None)
     try:
@@ -111,7 +114,7 @@ def kernel_rooflines(gp, ops, eng, batch, dev, steps=3):
         ach = terms * units / (t * 1e-3) / 1e12
         peak = PEAK_MFMA_BF16 if x6 else PEAK_MFMA_F32
         return {"mfma_achieved_tflops": round(ach, 1), "mfma_peak_tflops": peak, "mfma_frac": round(ach / peak, 4),
-                "mfma_note": ("6 bf16 MFMA terms per fp32 product (bf16x3 split operands, fp32 accumulate)" if x6 else "fp32 MFMA"),
+                "mfma_note": (f"{terms} bf16 MFMA term(s) per product, fp32 accumulate" if x6 else "fp32 MFMA"),
                 "fp32_equiv_tflops": round(units / (t * 1e-3) / 1e12, 1)}
 
     # algorithmic bytes: fp32 rows of H floats; masks 3 x 16 B, rms 4 B per row
@@ -121,12 +124,13 @@ def kernel_rooflines(gp, ops, eng, batch, dev, steps=3):
     b_wg = row * (8 * E + 12 * N)                        # 4 edge jobs (dZ, X) + 6 node jobs, 1 launch per round
     b_seg = row * (E + N) + 4.0 * (N + 1)
     t = "x6" if x6 else "lds<1>"
+    nterm = 1 if ops.get_matrix_precision() == "bf16" else 6
     roof = hbm(f"k_mlp_fwd_{t} (edge update, training mode: W_e.e + gathered node projections, 3 Linear, RMSNorm, residual, saves)",
-               ms["edge_fwd"], b_fwd, "edge_fwd_bytes", mfma(ms["edge_fwd"], 6 if x6 else 1))
+               ms["edge_fwd"], b_fwd, "edge_fwd_bytes", mfma(ms["edge_fwd"], nterm if x6 else 1))
     roof["launches_per_step"] = n["edge_fwd"]
     others = [
         hbm(f"k_mlp_bwd_{t} + k_colred (edge backward chain: RMSNorm bwd, 3 masked dgrad GEMMs, input grad)", ms["edge_bwd"], b_bwd,
-            "edge_bwd_bytes", dict(mfma(ms["edge_bwd"], 6 if x6 else 1), launches_per_step=n["edge_bwd"])),
+            "edge_bwd_bytes", dict(mfma(ms["edge_bwd"], nterm if x6 else 1), launches_per_step=n["edge_bwd"])),
         hbm(f"k_wgrad_{'x6' if x6 else 'lds'} + k_wgrad_red (weight gradients of one round: 4 edge + 6..7 node jobs)", ms["wgrad"], b_wg,
             "wgrad_bytes", {"launches_per_step": n["wgrad"]}),
     ]
@@ -190,6 +194,7 @@ def main():
     dev = torch.device("cuda", local)
 
     cfg = gp.cylinder_config(args.rounds, args.hidden)
+    cfg["training"]["enable_vram_optimizations"] = (args.precision == "bf16")
     torch.manual_seed(0)
     eng = harness.Engine(cfg, dev, learning_rate=1e-4, num_steps=10000, warmup=100)
     if world > 1:
@@ -252,8 +257,9 @@ def main():
             "metric": "training steps/sec, CylinderFlow 15-round MGN (batch 16 meshes per step)",
             "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "matrix_path": ("bf16x3 split operands, 6-term products on v_mfma_f32_16x16x32_bf16, fp32 accumulate "
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "matrix_path": ("bf16 operands (one term), fp32 accumulate / RMSNorm / residuals" if args.precision == "bf16" else
+                            "bf16x3 split operands, 6-term products on v_mfma_f32_16x16x32_bf16, fp32 accumulate "
                             "(fp32-grade accuracy: forward parity 1e-5 vs the CPU oracle)" if ops.X6_ENABLED else "fp32 MFMA"),
             "config": {"workload": f"CylinderFlow-like Delaunay meshes, {args.batch} x {args.nodes} nodes per GPU batch "
                        f"(N={N}, E={E}), {args.rounds} MP rounds, latent {args.hidden}, fp32, random-init weights; "

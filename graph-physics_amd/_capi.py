@@ -50,6 +50,7 @@ class MlpFwdArgs(C.Structure):
         ("post_W", _f32p * 2), ("post_out", _f32p * 2),
         ("wpk", C.c_void_p * 8),
         ("saveM", C.c_void_p * MAX_LAYERS),
+        ("precision", C.c_int),
     ]
 
 
@@ -74,6 +75,7 @@ class MlpBwdArgs(C.Structure):
         ("red_ws", C.c_void_p), ("red_ws_bytes", C.c_size_t),
         ("wpk", C.c_void_p * 4),
         ("Ms", C.c_void_p * MAX_LAYERS),
+        ("precision", C.c_int),
     ]
 
 
@@ -110,6 +112,7 @@ SYMBOLS = {
     "mgn_mlp_bwd": (C.c_int, [C.POINTER(MlpBwdArgs), C.c_void_p]),
     "mgn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(WgradJob)]),
     "mgn_wgrad": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_wgrad_p": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "mgn_transpose_blocks": (C.c_int, [C.c_int, C.POINTER(TBlock), C.c_int, C.c_void_p]),
     "mgn_wpack": (C.c_int, [C.c_int, C.POINTER(WpackBlock), C.c_void_p]),
 }

@@ -1724,12 +1724,16 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
   if (p.lds && fwd_x6(a)) {
     static thread_local bool attr_done = false;
     if (!attr_done) {
-      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES) != hipSuccess) return 1;
+      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<6>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES) != hipSuccess) return 1;
+      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES) != hipSuccess) return 1;
       attr_done = true;
     }
     unsigned grid = (unsigned)((a.M + 63) / 64);
     if (grid > 512) grid = 512;
-    hipLaunchKernelGGL(k_mlp_fwd_x6, dim3(grid), dim3(256), X6_FWD_LDS_BYTES, s, a);
+    if (a.precision == 1)
+      hipLaunchKernelGGL(k_mlp_fwd_x6<1>, dim3(grid), dim3(256), X6_FWD_LDS_BYTES, s, a);
+    else
+      hipLaunchKernelGGL(k_mlp_fwd_x6<6>, dim3(grid), dim3(256), X6_FWD_LDS_BYTES, s, a);
     return 0;
   }
   if (p.lds) {
@@ -1773,10 +1777,14 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
   if (p.lds && bwd_x6(a)) {
     static thread_local bool attr_done = false;
     if (!attr_done) {
-      if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6, hipFuncAttributeMaxDynamicSharedMemorySize, X6_BWD_LDS_BYTES(LDS_MAX_NL)) != hipSuccess) return 1;
+      if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_BWD_LDS_BYTES(LDS_MAX_NL)) != hipSuccess) return 1;
+      if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_BWD_LDS_BYTES(LDS_MAX_NL)) != hipSuccess) return 1;
       attr_done = true;
     }
-    hipLaunchKernelGGL(k_mlp_bwd_x6, dim3(p.grid), dim3(256), X6_BWD_LDS_BYTES(a.NL), s, a);
+    if (a.precision == 1)
+      hipLaunchKernelGGL(k_mlp_bwd_x6<1>, dim3(p.grid), dim3(256), X6_BWD_LDS_BYTES(a.NL), s, a);
+    else
+      hipLaunchKernelGGL(k_mlp_bwd_x6<6>, dim3(p.grid), dim3(256), X6_BWD_LDS_BYTES(a.NL), s, a);
     return 0;
   }
   if (p.lds) {
@@ -1869,6 +1877,9 @@ static int check_mlp_common(int H, int NL, int out_w, const char* who) {
 int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream) {
   const mgn_mlp_fwd_args& a = *args;
   if (int rc = check_mlp_common(a.H, a.NL, a.out_w, "mgn_mlp_fwd")) return rc;
+  if (a.precision != 0 && a.precision != 1) return fail(1, "mgn_mlp_fwd: precision must be 0 (fp32-grade) or 1 (bf16)");
+  if (a.precision == 1 && !(plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && fwd_x6(a)))
+    return fail(1, "mgn_mlp_fwd: bf16 matrix mode needs the packed split-bf16 path (H = 128, full widths, wpk)");
   if (a.nphase < 1 || a.nphase > MGN_MAX_PHASES) return fail(1, "mgn_mlp_fwd: nphase out of range");
   for (int p = 0; p < a.nphase; ++p)
     if (a.kw[p] < 1 || a.kw[p] > a.H) return fail(1, "mgn_mlp_fwd: phase width out of range");
@@ -1901,6 +1912,9 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   if (int rc = check_mlp_common(a.H, a.NL, a.out_w, "mgn_mlp_bwd")) return rc;
   if (a.n_din < 0 || a.n_din > MGN_MAX_PHASES) return fail(1, "mgn_mlp_bwd: n_din out of range");
   if (a.n_din > 1 && a.dZ[0] == nullptr) return fail(1, "mgn_mlp_bwd: n_din > 1 needs dZ[0]");
+  if (a.precision != 0 && a.precision != 1) return fail(1, "mgn_mlp_bwd: precision must be 0 (fp32-grade) or 1 (bf16)");
+  if (a.precision == 1 && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
+    return fail(1, "mgn_mlp_bwd: bf16 matrix mode needs the packed split-bf16 path (H = 128, full widths, wpk, Ms)");
   if (a.M == 0) return 0;
   if (a.red_ws_bytes < mgn_mlp_bwd_workspace_bytes(a.M, a.H, a.NL)) return fail(1, "mgn_mlp_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
@@ -1989,6 +2003,11 @@ static bool wgrad_job_full(const mgn_wgrad_job& j) {
 }
 
 int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, void* stream) {
+  return mgn_wgrad_p(njobs, jobs, ws, ws_bytes, 0, stream);
+}
+
+int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, int precision, void* stream) {
+  if (precision != 0 && precision != 1) return fail(1, "mgn_wgrad: precision must be 0 (fp32-grade) or 1 (bf16)");
   if (njobs < 1 || njobs > MGN_MAX_WGRAD_JOBS) return fail(1, "mgn_wgrad: njobs out of range");
   hipStream_t s = (hipStream_t)stream;
   // two launches at most: full 128x128 jobs on the LDS-staged kernel, the others generic
@@ -2023,11 +2042,15 @@ int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, v
       if (getenv("MGN_FP32_MFMA") == nullptr) {
         static thread_local bool attr6_done = false;
         if (!attr6_done) {
-          if (hipFuncSetAttribute((const void*)k_wgrad_x6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+          if (hipFuncSetAttribute((const void*)k_wgrad_x6<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+              hipFuncSetAttribute((const void*)k_wgrad_x6<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return fail(2, "mgn_wgrad: cannot reserve LDS");
           attr6_done = true;
         }
-        hipLaunchKernelGGL(k_wgrad_x6, dim3(total), dim3(256), smem, s, L);
+        if (precision == 1)
+          hipLaunchKernelGGL(k_wgrad_x6<1>, dim3(total), dim3(256), smem, s, L);
+        else
+          hipLaunchKernelGGL(k_wgrad_x6<6>, dim3(total), dim3(256), smem, s, L);
       } else {
         hipLaunchKernelGGL(k_wgrad_lds, dim3(total), dim3(256), smem, s, L);
       }

@@ -21,7 +21,8 @@ import torch
 
 from .mesh import Graph
 from .nodetype import NodeType
-from .parse_parameters import get_model, get_simulator
+from .parse_parameters import get_model, get_simulator, matrix_precision_from_config
+from . import ops as _ops
 
 
 def lr_factor(last_epoch: int, warmup: int, max_iters: int, min_lr_factor: float = 0.001) -> float:
@@ -54,6 +55,7 @@ class Engine:
     def __init__(self, param: Dict[str, Any], device: torch.device, learning_rate: float = 1e-4,
                  num_steps: int = 1000, warmup: int = 100, grad_clip: float = 1.0):
         self.param, self.device = param, device
+        _ops.set_matrix_precision(matrix_precision_from_config(param))  # bf16-mixed <=> enable_vram_optimizations
         self.model = get_model(param)
         self.sim = get_simulator(param, self.model, device)
         self.learning_rate, self.num_steps, self.warmup, self.grad_clip = learning_rate, num_steps, warmup, grad_clip

@@ -20,6 +20,24 @@ EPS = 1e-8  # RMSNorm epsilon of the reference (layers.py:80)
 #: accuracy at 2.67x the fp32 MFMA rate) unless MGN_FP32_MFMA is set (exact-fp32 MFMA kernels)
 import os as _os
 X6_ENABLED = _os.environ.get("MGN_FP32_MFMA") is None
+
+#: "fp32" (default: bf16x3 operands, 6 product terms, fp32-grade) or "bf16" (operands rounded to
+#: bf16, one term, fp32 accumulate; everything stored stays fp32) -- the processor's GEMMs only.
+#: "bf16" mirrors the reference under Lightning ``precision="bf16-mixed"`` (train.py:74-78,268-293).
+_matrix_precision = "fp32"
+
+
+def set_matrix_precision(p: str) -> None:
+    global _matrix_precision
+    if p not in ("fp32", "bf16"):
+        raise ValueError("matrix precision must be 'fp32' or 'bf16'")
+    if p == "bf16" and not X6_ENABLED:
+        raise RuntimeError("bf16 matrix mode runs on the split-bf16 kernels; unset MGN_FP32_MFMA")
+    _matrix_precision = p
+
+
+def get_matrix_precision() -> str:
+    return _matrix_precision
 SUPPORTED_H = (16, 32, 64, 128)
 
 
@@ -141,7 +159,7 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
             saveR: Optional[torch.Tensor] = None, ldw0: int = 0,
             adds: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]] = (),
             posts: Sequence[Tuple[int, torch.Tensor]] = (), post_ldw: int = 0, wpk: Sequence[int] = (),
-            saveM: Optional[Sequence[torch.Tensor]] = None):
+            saveM: Optional[Sequence[torch.Tensor]] = None, precision: int = 0):
     """``adds``: (rows[*,H], idx or None) gathered into the layer-0 pre-activation;
     ``posts``: (device address of a [H,H] weight block with leading dim ``post_ldw``, out[M,H]);
     ``wpk``: device addresses of the launch's GEMM units packed by :func:`wpack` (phases of
@@ -168,6 +186,7 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
     if saveM is not None:
         for l, t in enumerate(saveM):
             a.saveM[l] = _ptr(t)
+    a.precision = precision
     dev = out.device
     with torch.cuda.device(dev):
         rc = _capi.lib().mgn_mlp_fwd(C.byref(a), _stream(dev))
@@ -178,7 +197,7 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
             Hs: Sequence[torch.Tensor], WT: Sequence[Optional[torch.Tensor]], dZ: Sequence[Optional[torch.Tensor]],
             din: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]],
             db: Sequence[Optional[torch.Tensor]], dscale: Optional[torch.Tensor], wpk: Sequence[int] = (),
-            Ms: Optional[Sequence[torch.Tensor]] = None):
+            Ms: Optional[Sequence[torch.Tensor]] = None, precision: int = 0):
     L = _capi.lib()
     a = _capi.MlpBwdArgs()
     a.M, a.H, a.NL = M, H, NL
@@ -199,6 +218,7 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
     if Ms is not None:
         for l, t in enumerate(Ms):
             a.Ms[l] = _ptr(t)
+    a.precision = precision
     dev = dOut.device
     nbytes = L.mgn_mlp_bwd_workspace_bytes(M, H, NL)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
@@ -208,7 +228,7 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
     _capi.check(rc, "mgn_mlp_bwd")
 
 
-def wgrad(jobs, dev):
+def wgrad(jobs, dev, precision: int = 0):
     """jobs: (A, lda, nja, B, ldb, nkb, kw, dW_tensor, dW_offset_elems, ldw[, db]); M = A.shape[0].
     ``db`` (optional tensor [16*nja]) receives the column sums of A = the bias gradient."""
     L = _capi.lib()
@@ -226,7 +246,7 @@ def wgrad(jobs, dev):
         nbytes = L.mgn_wgrad_workspace_bytes(len(chunk), arr)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            rc = L.mgn_wgrad(len(chunk), arr, _ptr(ws), ws.numel(), _stream(dev))
+            rc = L.mgn_wgrad_p(len(chunk), arr, _ptr(ws), ws.numel(), precision, _stream(dev))
         _capi.check(rc, "mgn_wgrad")
 
 
@@ -379,6 +399,10 @@ class ProcessorFunction(torch.autograd.Function):
         # split-bf16 matrix path: all GEMM units of all rounds packed by one launch; per round
         # [We0|e, We1, We2, We3, Wn0|x, Wn0|agg, Wn1, Wn2, Wn3, We0|x_dst, We0|x_src]
         x6 = split and L > 0 and E > 0 and X6_ENABLED
+        prec = 1 if _matrix_precision == "bf16" else 0
+        if prec and not x6 and L > 0 and E > 0:
+            raise NotImplementedError("bf16 matrix mode needs hidden_size=128 (the packed split-bf16 kernels)")
+        prec = prec if x6 else 0
         NU = 11
         if x6:
             pk = torch.empty(L * NU * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
@@ -402,7 +426,7 @@ class ProcessorFunction(torch.autograd.Function):
             Pd, Ps = torch.empty(N, H, **f), torch.empty(N, H, **f)
             for slab, dst_t in ((1, Pd), (2, Ps)):
                 mlp_fwd(N, H, [(x, None, H)], [W0[:, slab * H:(slab + 1) * H].contiguous()], [None], None, H, None, dst_t,
-                        wpk=[unit(0, 8 + slab)] if x6 else ())
+                        wpk=[unit(0, 8 + slab)] if x6 else (), precision=prec)
         for i in range(L):
             q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
             We, be, se = [q[0], q[2], q[4], q[6]], [q[1], q[3], q[5], q[7]], q[8]
@@ -426,7 +450,7 @@ class ProcessorFunction(torch.autograd.Function):
             if split and E > 0:
                 mlp_fwd(E, H, [(e, None, H)], We, be, se, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
                         adds=[(Pd, topo.dst_s), (Ps, topo.src_s)],
-                        wpk=[unit(i, u) for u in range(4)] if x6 else (), saveM=Me)
+                        wpk=[unit(i, u) for u in range(4)] if x6 else (), saveM=Me, precision=prec)
             else:
                 mlp_fwd(E, H, [(e, None, H), (x, topo.dst_s, H), (x, topo.src_s, H)], We, be, se, H, e, e_new, m, He, Ue, Re)
             # R4: agg = segment-sum of m over dst                          (layers.py:1031-1037)
@@ -441,17 +465,17 @@ class ProcessorFunction(torch.autograd.Function):
             if x6:
                 wn = [unit(i, u) for u in range(4, 9)] + ([unit(i + 1, 9), unit(i + 1, 10)] if posts else [])
             mlp_fwd(N, H, [(x, None, H), (agg, None, H)], Wn, bn, sn, H, x, x_new, None, Hn, Un, Rn,
-                    posts=posts, post_ldw=3 * H, wpk=wn, saveM=Mn)
+                    posts=posts, post_ldw=3 * H, wpk=wn, saveM=Mn, precision=prec)
             if need:
                 saved.append((x, e, agg, He, Ue, Re, Hn, Un, Rn, Me, Mn))
             x, e = x_new, e_new
             Pd, Ps = Pd_n, Ps_n
-        ctx.topo, ctx.L, ctx.P, ctx.saved_acts = topo, L, P, saved
+        ctx.topo, ctx.L, ctx.P, ctx.saved_acts, ctx.prec = topo, L, P, saved, prec
         return x, e
 
     @staticmethod
     def backward(ctx, dx, de):
-        topo, L, P, saved = ctx.topo, ctx.L, ctx.P, ctx.saved_acts
+        topo, L, P, saved, prec = ctx.topo, ctx.L, ctx.P, ctx.saved_acts, ctx.prec
         dev = P[0].device
         N, E = topo.N, topo.E
         H = P[1].numel()
@@ -526,17 +550,17 @@ class ProcessorFunction(torch.autograd.Function):
                 kn = ke = kx = ()
             # node MLP chain: dX' -> dZn[3..0], dAgg = W0n[:,H:]^T dZn0
             mlp_bwd(N, H, 4, dx, None, None, H, Un, Rn, sn, Hn, WTn, dZn, [(WT0n_agg, None, dAgg)],
-                    [None] * 4, g[17], wpk=kn, Ms=Mn)
+                    [None] * 4, g[17], wpk=kn, Ms=Mn, precision=prec)
             # edge MLP chain: dM = dE' + dAgg[dst] -> dZe[3..0], dE = dE' + W0e[:, :H]^T dZe0
             de_new = de_buf[0] if de.data_ptr() != de_buf[0].data_ptr() else de_buf[1]
             mlp_bwd(E, H, 4, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
-                    [None] * 4, g[8], wpk=ke, Ms=Me)
+                    [None] * 4, g[8], wpk=ke, Ms=Me, precision=prec)
             # scatter of the first-layer pre-activations' grads onto dst / src nodes
             segsum(dZe[0], topo.rowptr_dst, None, Sd)
             segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)
             # dX = dX' + W0n[:, :H]^T dZn0 + W0e[:, H:2H]^T Sd + W0e[:, 2H:]^T Ss
             dx_new = dx_buf[0] if dx.data_ptr() != dx_buf[0].data_ptr() else dx_buf[1]
-            mlp_fwd(N, H, [(dZn[0], None, H), (Sd, None, H), (Ss, None, H)], [Wcat], [None], None, H, dx, dx_new, wpk=kx)
+            mlp_fwd(N, H, [(dZn[0], None, H), (Sd, None, H), (Ss, None, H)], [Wcat], [None], None, H, dx, dx_new, wpk=kx, precision=prec)
             # weight gradients: dW = dZ^T X
             # (A = dZ, B = layer input, dW slab[, db = bias gradient as a by-product])
             jobs = [
@@ -549,7 +573,7 @@ class ProcessorFunction(torch.autograd.Function):
             for l in (1, 2, 3):
                 jobs.append((dZn[l], H, nb, Hn[l - 1], H, nb, H, g[9 + 2 * l], 0, H, g[10 + 2 * l]))
                 jobs.append((dZe[l], H, nb, He[l - 1], H, nb, H, g[2 * l], 0, H, g[1 + 2 * l]))
-            wgrad(jobs, dev)
+            wgrad(jobs, dev, prec)
             grads[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)] = g
             dx, de = dx_new, de_new
         ctx.saved_acts = None

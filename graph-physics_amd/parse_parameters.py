@@ -53,6 +53,13 @@ def get_simulator(param: Dict[str, Any], model, device: torch.device) -> Simulat
     )
 
 
+def matrix_precision_from_config(param: Dict[str, Any]) -> str:
+    """``training.enable_vram_optimizations`` is the reference's switch to Lightning
+    ``precision="bf16-mixed"`` (train.py:74-78,268-293): bf16 GEMM inputs, fp32 accumulate,
+    fp32 RMSNorm / residual stream.  Here that is the engine's "bf16" matrix mode."""
+    return "bf16" if param.get("training", {}).get("enable_vram_optimizations", False) else "fp32"
+
+
 def cylinder_config(message_passing_num: int = 15, hidden_size: int = 128) -> Dict[str, Any]:
     """training_config/cylinder.json with the two benchmark overrides
     (message_passing_num 5->15, hidden_size 32->128; SURVEY.md TL;DR item 1)."""

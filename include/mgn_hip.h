@@ -116,6 +116,11 @@ typedef struct {
    * of row m holds bit 4*ib + r for feature 16*ib + 4*g + r (set iff the activation is > 0).
    * The backward chain needs only these 16 bytes per row and layer, not the 512-byte fp32 row. */
   uint32_t* saveM[MGN_MAX_LAYERS];
+  /* matrix precision of the packed path: 0 = fp32-grade (bf16x3 operands, 6 product terms);
+   * 1 = bf16 (operands rounded to bf16, ONE term, fp32 accumulate; biases, RMSNorm, residuals
+   * and every stored tensor stay fp32) -- the semantic of the reference under bf16-mixed
+   * autocast (train.py:74-78,268-293), BASELINE configs[2]. */
+  int precision;
 } mgn_mlp_fwd_args;
 int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream);
 
@@ -154,6 +159,7 @@ typedef struct {
   /* Ms[l-1] = saveM[l-1] of the forward launch (ReLU masks as bits).  Required by the split-bf16
    * kernel (it does not read Hs); ignored by the fp32 kernels. */
   const uint32_t* Ms[MGN_MAX_LAYERS];
+  int precision;                    /* as in mgn_mlp_fwd_args */
 } mgn_mlp_bwd_args;
 size_t mgn_mlp_bwd_workspace_bytes(int64_t M, int H, int NL);
 int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream);
@@ -173,6 +179,8 @@ typedef struct {
 } mgn_wgrad_job;
 size_t mgn_wgrad_workspace_bytes(int njobs, const mgn_wgrad_job* jobs);
 int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, void* stream);
+/* same with an explicit matrix precision for the full 128x128 jobs (0 / 1 as in mgn_mlp_fwd_args) */
+int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, int precision, void* stream);
 
 /* ------------------------------------------------------- batched block transpose
  * dst[k, j] = src[j, k] for n square H x H blocks (leading dimensions ld_src / ld_dst; a block

@@ -26,13 +26,35 @@ def test_header_symbols_exported():
     assert lib.mgn_last_error() == b""
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof of every argument struct as gcc lays out include/mgn_hip.h (LP64) against
+    the ctypes mirrors in _capi.py."""
+    import shutil
+    import subprocess
+
     from graph_physics_amd import _capi as c
 
-    # sizes the C compiler produces for the same field order (LP64)
-    assert ctypes.sizeof(c.MlpFwdArgs) == 8 + 12 + 4 + 24 + 24 + 12 + 4 + 64 + 64 + 8 + 8 + 24 + 64 + 16 + 8 + 32 + 8 + 32
-    assert ctypes.sizeof(c.WgradJob) == 24 + 8 + 24 + 8
+    structs = {"mgn_mlp_fwd_args": c.MlpFwdArgs, "mgn_mlp_bwd_args": c.MlpBwdArgs, "mgn_wgrad_job": c.WgradJob,
+               "mgn_tblock": c.TBlock, "mgn_wpack_block": c.WpackBlock}
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "a C compiler is part of the toolchain contract"
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "mgn_hip.h"', "int main(void) {"]
+    for name, st in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for fld, _ in st._fields_:
+            lines.append(f'printf("{name}.{fld} %zu\\n", offsetof({name}, {fld}));')
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([cc, "-I", os.path.join(REPO, "include"), "-o", str(exe), str(src)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, st in structs.items():
+        assert int(got[name]) == ctypes.sizeof(st), name
+        for fld, _ in st._fields_:
+            assert int(got[f"{name}.{fld}"]) == getattr(st, fld).offset, f"{name}.{fld}"
     assert c.MAX_LAYERS == 8 and c.MAX_PHASES == 3 and c.MAX_WGRAD_JOBS == 12
+    assert c.WPACK_BYTES == 98304
 
 
 def test_host_side_queries_need_no_gpu():

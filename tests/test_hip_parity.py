@@ -435,3 +435,124 @@ def test_partitioned_epd_hip_backend_world1(dev):
     assert rel_err(out, out_ref) < 1e-6
     for (k, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
         assert rel_err(a.grad, b.grad) < 1e-5, k
+
+
+def test_bf16_matrix_mode_vs_oracle(dev):
+    """BASELINE configs[2] semantic (reference under bf16-mixed autocast, train.py:74-78): bf16
+    GEMM inputs, fp32 accumulate, fp32 RMSNorm / residual stream.  The engine's "bf16" matrix
+    mode (one bf16 MFMA term) against (a) the fp32 oracle and (b) the oracle evaluated under CPU
+    bf16 autocast (the reference's rounding points), both within 3e-2 relative after 15 rounds
+    (SURVEY 8d states "~1e-2 rel" for this config; measured 1.3e-2 on this deep net);
+    gradients flow and stay finite; on a 2-round net they stay within 5e-2 of the fp32 path's."""
+    from graph_physics_amd import ops
+
+    L, N, seed = 15, 400, 91
+    pos, ei, ea = R.delaunay_graph(N, seed)
+    params = R.make_params(R.epd_param_shapes(L, 128, 11, 3, 2), seed)
+    x_in, e_in = R.randn((N, 11), 1), R.randn((ei.shape[1], 3), 2)
+    ref32 = O.epd_forward(x_in, e_in, ei, params, L)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ref16 = O.epd_forward(x_in, e_in, ei, params, L).float()
+    net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=128).to(dev)
+    net.load_state_dict(params)
+    g = gp.Graph(x=x_in.to(dev), edge_attr=e_in.to(dev), edge_index=ei.to(dev))
+    assert ops.get_matrix_precision() == "fp32"
+    out32 = net(g).detach()
+    ops.set_matrix_precision("bf16")
+    try:
+        out = net(g)
+        out.square().sum().backward()
+    finally:
+        ops.set_matrix_precision("fp32")
+    assert rel_err(out32, ref32) < FWD_TOL
+    e32, e16 = rel_err(out, ref32), rel_err(out, ref16)
+    BF16_TOL = 3e-2
+    assert 1e-5 < e32 < BF16_TOL, e32       # really a different (bf16) path, inside the stated tolerance
+    assert e16 < BF16_TOL, e16
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    # gradients of the bf16 path stay close to the fp32 path's (compared on a 2-round net: through
+    # 15 rounds of random weights the two gradient fields decorrelate chaotically)
+    L2 = 2
+    p2 = R.make_params(R.epd_param_shapes(L2, 128, 11, 3, 2), seed + 1)
+    grads = {}
+    for mode in ("fp32", "bf16"):
+        n2 = gp.EncodeProcessDecode(L2, 11, 3, 2, hidden_size=128).to(dev)
+        n2.load_state_dict(p2)
+        ops.set_matrix_precision(mode)
+        try:
+            n2(g).square().sum().backward()
+        finally:
+            ops.set_matrix_precision("fp32")
+        grads[mode] = {k: p.grad.clone() for k, p in n2.named_parameters()}
+    for k in grads["fp32"]:
+        a, b = grads["bf16"][k].double(), grads["fp32"][k].double()
+        assert float((a - b).norm() / b.norm()) < 5e-2, k  # Frobenius-relative: bf16 rounding noise of ~22 chained GEMMs
+
+
+def test_wpack_layout(dev):
+    """mgn_wpack against a numpy statement of the documented image: [K-slice][piece][out block]
+    [lane][8 bf16], pieces = successive bf16 roundings of the remainder, plain and transposed."""
+    from graph_physics_amd import ops, _capi
+
+    rng = np.random.default_rng(5)
+    W = (rng.standard_normal((128, 384)) * 0.07).astype(np.float32)
+    Wd = torch.from_numpy(W).to(dev)
+    out = torch.zeros(2 * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+    ops.wpack([(Wd.data_ptr() + 4 * 128, 384, False, out.data_ptr()),
+               (Wd.data_ptr() + 4 * 128, 384, True, out.data_ptr() + _capi.WPACK_BYTES)], dev)
+    img = out.cpu().numpy().view(np.uint16).reshape(2, 4, 3, 8, 64, 8)
+
+    def bf16_bits(a):  # round to nearest even, as v_cvt_pk_bf16_f32
+        u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+    def bf16_val(b):
+        return (b.astype(np.uint32) << 16).view(np.float32)
+
+    blk = W[:, 128:256]
+    for t, B in enumerate((blk, blk.T)):
+        j, ob, lane, i = np.meshgrid(np.arange(4), np.arange(8), np.arange(64), np.arange(8), indexing="ij")
+        c, g = lane & 15, lane >> 4
+        v = B[16 * ob + c, 32 * j + 16 * (i >> 2) + 4 * g + (i & 3)].astype(np.float32)
+        p1 = bf16_bits(v)
+        r1 = v - bf16_val(p1)
+        p2 = bf16_bits(r1)
+        r2 = r1 - bf16_val(p2)
+        p3 = bf16_bits(r2)
+        for piece, want in enumerate((p1, p2, p3)):
+            assert np.array_equal(img[t, :, piece], want), (t, piece)
+        assert np.abs(bf16_val(p1) + bf16_val(p2) + bf16_val(p3) - v).max() <= 2.0 ** -22 * np.abs(v).max()
+
+
+def test_split_bf16_matches_exact_fp32_kernels(dev):
+    """One training-mode block on both matrix paths of the C ABI: the packed split-bf16 kernels
+    (default) and the exact-fp32 MFMA kernels (no wpk): outputs and every gradient agree to
+    fp32 rounding level."""
+    import subprocess, sys, os, json
+    code = r"""
+import sys, json, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import recipe as R, graph_physics_amd as gp
+dev = torch.device("cuda:0")
+L, N, seed = 3, 700, 33
+pos, ei, ea = R.delaunay_graph(N, seed)
+params = R.make_params(R.epd_param_shapes(L, 128, 11, 3, 2), seed)
+net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=128).to(dev); net.load_state_dict(params)
+x_in, e_in = R.randn((N, 11), 1).to(dev), R.randn((ei.shape[1], 3), 2).to(dev)
+out = net(gp.Graph(x=x_in, edge_attr=e_in, edge_index=ei.to(dev)))
+out.square().sum().backward()
+torch.save({"out": out.detach().cpu(), **{k: p.grad.cpu() for k, p in net.named_parameters()}}, sys.argv[1])
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (root, os.path.join(root, "tests", "golden"))
+    res = {}
+    for tag, env in (("x6", {}), ("fp32", {"MGN_FP32_MFMA": "1"})):
+        path = f"/tmp/_mgn_paths_{tag}_{os.getpid()}.pt"
+        e = dict(os.environ, **env)
+        e.pop("MGN_FP32_MFMA", None) if not env else None
+        r = subprocess.run([sys.executable, "-c", code, path], env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(path)
+        os.remove(path)
+    for k in res["x6"]:
+        assert rel_err(res["x6"][k], res["fp32"][k]) < (2e-6 if k == "out" else 2e-5), k
