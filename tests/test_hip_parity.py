@@ -443,7 +443,7 @@ def test_bf16_matrix_mode_vs_oracle(dev):
     mode (one bf16 MFMA term) against (a) the fp32 oracle and (b) the oracle evaluated under CPU
     bf16 autocast (the reference's rounding points), both within 3e-2 relative after 15 rounds
     (SURVEY 8d states "~1e-2 rel" for this config; measured 1.3e-2 on this deep net);
-    gradients flow and stay finite; on a 2-round net they stay within 5e-2 of the fp32 path's."""
+    gradients flow and stay finite; on a 2-round net they stay within 0.15 (Frobenius) of the fp32 path's."""
     from graph_physics_amd import ops
 
     L, N, seed = 15, 400, 91
@@ -486,7 +486,10 @@ def test_bf16_matrix_mode_vs_oracle(dev):
         grads[mode] = {k: p.grad.clone() for k, p in n2.named_parameters()}
     for k in grads["fp32"]:
         a, b = grads["bf16"][k].double(), grads["fp32"][k].double()
-        assert float((a - b).norm() / b.norm()) < 5e-2, k  # Frobenius-relative: bf16 rounding noise of ~22 chained GEMMs
+        # Frobenius-relative.  The bf16 semantic itself is this noisy on the deepest gradients: the
+        # oracle under CPU bf16 autocast is 9.2e-2 from its fp32 self on nodes_encoder.0.weight
+        # (ReLU masks flip under bf16 rounding); the engine measures 6.2e-2 there.
+        assert float((a - b).norm() / b.norm()) < 0.15, k
 
 
 def test_wpack_layout(dev):
