@@ -240,10 +240,17 @@ def main():
 
     # rollout (second half of the metric): one mesh batch advanced autoregressively
     frames = [batch] * args.rollout_steps
-    eng.rollout(frames[:3])
+    rollout, rollout_note = eng.rollout, "eager"
+    if args.graph != "off":  # no collective in the rollout: every rank replays its own captured step
+        try:
+            eng.capture_rollout_step(batch)
+            rollout, rollout_note = eng.rollout_graphed, "hipGraph replay"
+        except Exception as ex:  # noqa: BLE001
+            print(f"[bench] hipGraph capture of the rollout step failed ({type(ex).__name__}: {ex}); eager launches", file=sys.stderr)
+    rollout(frames[:3])
     barrier()
     t0 = time.perf_counter()
-    eng.rollout(frames)
+    rollout(frames)
     barrier()
     dt_r = time.perf_counter() - t0
     if world > 1:
@@ -266,7 +273,7 @@ def main():
                        "BASELINE.json configs[1]", "global_batch_meshes": args.batch * world, "launch": graph_note,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "rollout_node_steps_per_s": round(rollout_nps, 1),
-            "rollout_ms_per_step": round(1e3 * dt_r / args.rollout_steps, 3),
+            "rollout_ms_per_step": round(1e3 * dt_r / args.rollout_steps, 3), "rollout_launch": rollout_note,
         }
         if not args.no_kernel_timing:
             roof, roof_seg, others = kernel_rooflines(gp, ops, eng, batch, dev)

@@ -1722,18 +1722,32 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
   const bool ragged = fwd_ragged(a);
   const MlpPlan p = plan_mlp(a.M, a.H, a.NL, ragged, false);
   if (p.lds && fwd_x6(a)) {
+    // 8-wave workgroups (one per CU) when every CU still gets a tile; MGN_NW=4/8 overrides
+    int nw = (a.M >= 128 * 256) ? X6_FWD_NW_LARGE : 4;
+    if (const char* e = getenv("MGN_NW")) nw = (atoi(e) == 8) ? 8 : 4;
     static thread_local bool attr_done = false;
     if (!attr_done) {
-      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<6>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES) != hipSuccess) return 1;
-      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES) != hipSuccess) return 1;
+      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<6, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(4)) != hipSuccess) return 1;
+      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(4)) != hipSuccess) return 1;
+      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(8)) != hipSuccess) return 1;
+      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(8)) != hipSuccess) return 1;
       attr_done = true;
     }
-    unsigned grid = (unsigned)((a.M + 63) / 64);
-    if (grid > 512) grid = 512;
-    if (a.precision == 1)
-      hipLaunchKernelGGL(k_mlp_fwd_x6<1>, dim3(grid), dim3(256), X6_FWD_LDS_BYTES, s, a);
-    else
-      hipLaunchKernelGGL(k_mlp_fwd_x6<6>, dim3(grid), dim3(256), X6_FWD_LDS_BYTES, s, a);
+    const int rows = 16 * nw;
+    unsigned grid = (unsigned)((a.M + rows - 1) / rows);
+    const unsigned cap = (nw == 8) ? 256u : 512u;
+    if (grid > cap) grid = cap;
+    if (nw == 8) {
+      if (a.precision == 1)
+        hipLaunchKernelGGL((k_mlp_fwd_x6<1, 8>), dim3(grid), dim3(512), X6_FWD_LDS_BYTES(8), s, a);
+      else
+        hipLaunchKernelGGL((k_mlp_fwd_x6<6, 8>), dim3(grid), dim3(512), X6_FWD_LDS_BYTES(8), s, a);
+    } else {
+      if (a.precision == 1)
+        hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+      else
+        hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+    }
     return 0;
   }
   if (p.lds) {

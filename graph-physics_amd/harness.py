@@ -172,6 +172,64 @@ class Engine:
         pred = torch.where(mask.unsqueeze(1), batch.y, pred)
         return pred
 
+    # ---------------------------------------------------------------- hipGraph rollout
+    @torch.no_grad()
+    def capture_rollout_step(self, frame: Graph, warmup: int = 2):
+        """Capture one autoregressive rollout step (lightning_module.py:375-409: feed the last
+        prediction back, Simulator forward in eval mode, re-impose the ground truth on the non
+        NORMAL/OUTFLOW nodes) in a hipGraph.  A step is ~60 launches of 5-250 us; driven from
+        Python the gaps between them cost ~25 % of the step.  Topology and shapes are frozen;
+        ``rollout_graphed`` copies each frame's x / y / edge_attr into the static tensors."""
+        dev = self.device
+        self.sim.eval()
+        st = frame.clone()
+        if getattr(frame, "mgn_topology", None) is not None:
+            st.mgn_topology = frame.mgn_topology
+        else:
+            from . import ops
+            st.mgn_topology = ops.Topology(st.edge_index, st.x.shape[0])
+        i0, i1 = self.sim.output_index_start, self.sim.output_index_end
+        last = st.x[:, i0:i1].clone()
+
+        def body():
+            b = Graph(x=st.x.clone(), y=st.y, pos=st.pos, edge_attr=st.edge_attr, edge_index=st.edge_index)
+            b.mgn_topology = st.mgn_topology
+            b.x[:, i0:i1] = last
+            mask = build_mask(b.x[:, self.sim.node_type_index])
+            _, _, pred = self.sim(b)
+            pred = torch.where(mask.unsqueeze(1), st.y, pred)
+            last.copy_(pred)
+            return pred
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._r_pred = body()
+        self._r_graph, self._r_static, self._r_last = g, st, last
+        return g
+
+    @torch.no_grad()
+    def rollout_graphed(self, frames: Sequence[Graph]) -> List[torch.Tensor]:
+        """``rollout`` through the captured step (same shapes / topology for every frame)."""
+        st, i0, i1 = self._r_static, self.sim.output_index_start, self.sim.output_index_end
+        out = []
+        for k, fr in enumerate(frames):
+            if fr is not st:
+                st.x.copy_(fr.x, non_blocking=True)
+                st.y.copy_(fr.y, non_blocking=True)
+                st.edge_attr.copy_(fr.edge_attr, non_blocking=True)
+            if k == 0:
+                self._r_last.copy_(fr.x[:, i0:i1])
+            self._r_graph.replay()
+            out.append(self._r_pred.clone())
+        return out
+
     @torch.no_grad()
     def rollout(self, frames: Sequence[Graph]) -> List[torch.Tensor]:
         last, out = None, []

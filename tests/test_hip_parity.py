@@ -560,3 +560,25 @@ torch.save({"out": out.detach().cpu(), **{k: p.grad.cpu() for k, p in net.named_
     for k in res["x6"]:
         # gradients: the suite's 1e-4-per-round criterion (a pre-activation within rounding of 0 flips its ReLU mask)
         assert rel_err(res["x6"][k], res["fp32"][k]) < (2e-6 if k == "out" else 3e-4), k
+
+
+def test_rollout_graphed_equals_eager(dev):
+    """The captured rollout step replays to the same predictions as eager launches (same kernels,
+    same order: bit-identical), over a trajectory whose frames differ."""
+    from graph_physics_amd import harness
+
+    torch.manual_seed(0)
+    eng = harness.Engine(gp.cylinder_config(3, 128), dev)
+    base = gp.cylinder_batch(2, 300, 0).to(dev)
+    frames = []
+    for k in range(4):
+        f = base.clone()
+        f.x = base.x.clone()
+        f.x[:, :2] += 0.01 * k
+        f.y = base.y + 0.02 * k
+        frames.append(f)
+    eager = eng.rollout(frames)
+    eng.capture_rollout_step(frames[0])
+    graphed = eng.rollout_graphed(frames)
+    for a, b in zip(eager, graphed):
+        assert torch.equal(a, b)
