@@ -241,7 +241,9 @@ def main():
     # rollout (second half of the metric): one mesh batch advanced autoregressively
     frames = [batch] * args.rollout_steps
     rollout, rollout_note = eng.rollout, "eager"
-    if args.graph != "off":  # no collective in the rollout: every rank replays its own captured step
+    # single process only: with a live RCCL process group its watchdog thread polls events, which is
+    # not allowed while another thread captures; at batch 16 replay and eager rollout time the same
+    if args.graph != "off" and world == 1:
         try:
             eng.capture_rollout_step(batch)
             rollout, rollout_note = eng.rollout_graphed, "hipGraph replay"
