@@ -7,5 +7,6 @@ from .processors import EncodeProcessDecode  # noqa: F401
 from .simulator import Simulator  # noqa: F401
 from .parse_parameters import get_model, get_simulator, cylinder_config, matrix_precision_from_config  # noqa: F401
 from .ops import set_matrix_precision, get_matrix_precision  # noqa: F401
+from . import preprocess  # noqa: F401
 
 __version__ = "0.1.0"

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _REPO = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_CSRC, "libmgn_hip.so")
-SOURCES = [os.path.join(_CSRC, "mgn_kernels.hip")]
+SOURCES = [os.path.join(_CSRC, "mgn_kernels.hip"), os.path.join(_CSRC, "mgn_prep.hip")]
 DEPS = [os.path.join(_CSRC, "mgn_x6.inc")]  # included by the source
 HEADER = os.path.join(_REPO, "include", "mgn_hip.h")
 
@@ -96,6 +96,20 @@ class WpackBlock(C.Structure):
 WPACK_BYTES = 98304
 
 
+class SimDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int64), ("E", C.c_int64),
+        ("x", _f32p), ("x_w", C.c_int),
+        ("y", _f32p), ("y_w", C.c_int),
+        ("edge_attr", _f32p), ("edge_w", C.c_int),
+        ("feat_start", C.c_int), ("feat_end", C.c_int), ("out_start", C.c_int), ("out_w", C.c_int), ("type_idx", C.c_int),
+        ("acc_sum", _f32p * 3), ("acc_sumsq", _f32p * 3), ("acc_count", _f32p * 3), ("num_acc", _f32p * 3),
+        ("accumulate", C.c_int * 3),
+        ("std_eps", C.c_float),
+        ("node_out", _f32p), ("target_out", _f32p), ("edge_out", _f32p),
+    ]
+
+
 class TBlock(C.Structure):
     _fields_ = [("src", _f32p), ("dst", _f32p), ("ld_src", C.c_int), ("ld_dst", C.c_int)]
 
@@ -115,6 +129,15 @@ SYMBOLS = {
     "mgn_wgrad_p": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "mgn_transpose_blocks": (C.c_int, [C.c_int, C.POINTER(TBlock), C.c_int, C.c_void_p]),
     "mgn_wpack": (C.c_int, [C.c_int, C.POINTER(WpackBlock), C.c_void_p]),
+    "mgn_faces_to_edges_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "mgn_faces_to_edges": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_edge_features": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "mgn_sim_workspace_bytes": (C.c_size_t, []),
+    "mgn_sim_pre": (C.c_int, [C.POINTER(SimDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_sim_post": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "mgn_prep_last_error": (C.c_char_p, []),
 }
 
 _lib = None
@@ -182,7 +205,7 @@ def lib():
     return _lib
 
 
-def check(rc: int, what: str):
+def check(rc: int, what: str, prep: bool = False):
     if rc != 0:
-        msg = lib().mgn_last_error().decode("utf-8", "replace")
+        msg = (lib().mgn_prep_last_error() if prep else lib().mgn_last_error()).decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,309 @@
+// MI355X (gfx950) kernels either side of the message-passing path: on-device input construction
+// (faces -> symmetric coalesced edges, Cartesian / Distance edge features) and the Simulator's
+// pre / post processing (one-hot + slice + concat + online normalisers, delta target,
+// inverse-normalise + ground-truth re-imposition).  All of it is HBM-bound integer / elementwise
+// work: one pass per tensor, coalesced rows, no atomics (two-stage column statistics).
+// Second translation unit of libmgn_hip.so; the sort / unique primitives are rocPRIM (header-only).
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <stdint.h>
+#include <stdio.h>
+#include "mgn_hip.h"
+
+static thread_local char g_perr[256] = "";
+extern "C" const char* mgn_prep_last_error(void) { return g_perr; }
+static int pfail(int code, const char* msg) {
+  snprintf(g_perr, sizeof(g_perr), "%s", msg);
+  return code;
+}
+static int pcheck(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_perr, sizeof(g_perr), "%s: %s", what, hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
+// ===================================================================== faces -> edges
+// T.FaceToEdge(remove_faces=False) + to_undirected (reference dataset/preprocessing.py:421-424;
+// torch-geometric 2.6.1): every pair of corners of a face in both directions, coalesced =
+// sorted by (src, dst), duplicates removed; self loops of degenerate faces dropped.
+// key = src * N + dst; invalid corner (outside [0,N)) -> err flag, key = all ones (sorts last).
+__global__ void k_face_keys(const int64_t* __restrict__ face, int K, long F, long N, uint64_t* __restrict__ keys, int* __restrict__ err) {
+  const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  int64_t v[4];
+  bool ok = true;
+  for (int k = 0; k < K; ++k) {
+    v[k] = face[(size_t)k * F + f];
+    ok = ok && v[k] >= 0 && v[k] < N;
+  }
+  if (!ok) *err = 1;
+  const int npair = K * (K - 1) / 2;
+  int p = 0;
+  for (int a = 0; a < K; ++a)
+    for (int b = a + 1; b < K; ++b, ++p) {
+      const bool keep = ok && v[a] != v[b];
+      keys[(size_t)p * F + f] = keep ? (uint64_t)v[a] * (uint64_t)N + (uint64_t)v[b] : ~0ull;
+      keys[(size_t)(npair + p) * F + f] = keep ? (uint64_t)v[b] * (uint64_t)N + (uint64_t)v[a] : ~0ull;
+    }
+}
+
+__global__ void k_decode_keys(const uint64_t* __restrict__ uniq, const size_t* __restrict__ n_uniq, long N, long cap,
+                              int64_t* __restrict__ src, int64_t* __restrict__ dst, int64_t* __restrict__ n_edges) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t n = *n_uniq;
+  if (n > 0 && uniq[n - 1] == ~0ull) --n;  // the dropped pairs collapse into one trailing key
+  if (i == 0) *n_edges = (int64_t)n;
+  if (i >= cap || (size_t)i >= n) return;
+  const uint64_t k = uniq[i];
+  src[i] = (int64_t)(k / (uint64_t)N);
+  dst[i] = (int64_t)(k % (uint64_t)N);
+}
+
+struct F2EPlan {
+  size_t keys, sorted, uniq, count, err, tmp, tmp_bytes, total;
+};
+static F2EPlan f2e_plan(int64_t F, int K) {
+  F2EPlan p;
+  const size_t n = (size_t)F * K * (K - 1);
+  size_t t1 = 0, t2 = 0;
+  rocprim::radix_sort_keys(nullptr, t1, (uint64_t*)nullptr, (uint64_t*)nullptr, n, 0, 64, (hipStream_t)0);
+  rocprim::unique(nullptr, t2, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t*)nullptr, n, rocprim::equal_to<uint64_t>(), (hipStream_t)0);
+  p.tmp_bytes = (t1 > t2 ? t1 : t2) + 256;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  p.keys = 0;
+  p.sorted = al(p.keys + n * 8);
+  p.uniq = al(p.sorted + n * 8);
+  p.count = al(p.uniq + n * 8);
+  p.err = p.count + 64;
+  p.tmp = al(p.err + 64);
+  p.total = p.tmp + p.tmp_bytes;
+  return p;
+}
+
+extern "C" size_t mgn_faces_to_edges_workspace_bytes(int64_t F, int K) {
+  if (F < 0 || (K != 3 && K != 4)) return 0;
+  return f2e_plan(F, K).total + 256;
+}
+
+extern "C" int mgn_faces_to_edges(const int64_t* face, int K, int64_t F, int64_t N, int64_t* src, int64_t* dst,
+                                  int64_t* n_edges, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (K != 3 && K != 4) return pfail(1, "mgn_faces_to_edges: faces must have 3 or 4 corners");
+  if (F < 0 || N < 1 || N > 3037000499LL) return pfail(1, "mgn_faces_to_edges: size out of range (N*N must fit 63 bits)");
+  const F2EPlan p = f2e_plan(F, K);
+  const size_t base = ((size_t)ws + 255) & ~(size_t)255;
+  if (ws_bytes < (base - (size_t)ws) + p.total) return pfail(1, "mgn_faces_to_edges: workspace too small");
+  char* w = (char*)base;
+  uint64_t *keys = (uint64_t*)(w + p.keys), *sorted = (uint64_t*)(w + p.sorted), *uniq = (uint64_t*)(w + p.uniq);
+  size_t* count = (size_t*)(w + p.count);
+  int* err = (int*)(w + p.err);
+  const size_t n = (size_t)F * K * (K - 1);
+  if (hipMemsetAsync(count, 0, 128, s) != hipSuccess) return pfail(2, "mgn_faces_to_edges: memset");
+  if (n == 0) {
+    if (hipMemsetAsync(n_edges, 0, sizeof(int64_t), s) != hipSuccess) return pfail(2, "mgn_faces_to_edges: memset");
+    return 0;
+  }
+  hipLaunchKernelGGL(k_face_keys, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, s, face, K, (long)F, (long)N, keys, err);
+  size_t tb = p.tmp_bytes;
+  if (rocprim::radix_sort_keys(w + p.tmp, tb, keys, sorted, n, 0, 64, s) != hipSuccess) return pfail(2, "mgn_faces_to_edges: sort");
+  tb = p.tmp_bytes;
+  if (rocprim::unique(w + p.tmp, tb, sorted, uniq, count, n, rocprim::equal_to<uint64_t>(), s) != hipSuccess)
+    return pfail(2, "mgn_faces_to_edges: unique");
+  hipLaunchKernelGGL(k_decode_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, uniq, count, (long)N, (long)n, src, dst, n_edges);
+  if (int rc = pcheck("mgn_faces_to_edges")) return rc;
+  int herr = 0;
+  if (hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return pfail(2, "mgn_faces_to_edges: memcpy");
+  if (hipStreamSynchronize(s) != hipSuccess) return pfail(2, "mgn_faces_to_edges: sync failed");
+  if (herr) return pfail(3, "mgn_faces_to_edges: face corner outside [0, N)");
+  return 0;
+}
+
+// ==================================================================== edge features
+// T.Cartesian(norm=False) then T.Distance(norm=False) (preprocessing.py:16-23):
+//   edge_attr[e] = [ pos[src] - pos[dst] (D values), || pos[dst] - pos[src] ||_2 ]
+template <int D>
+__global__ void k_edge_features(const float* __restrict__ pos, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                long E, float* __restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float* ps = pos + src[e] * D;
+  const float* pd = pos + dst[e] * D;
+  float ss = 0.f;
+  float* o = out + e * (D + 1);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float c = ps[d] - pd[d];
+    const float r = pd[d] - ps[d];
+    o[d] = c;
+    ss = __fadd_rn(ss, __fmul_rn(r, r));  // plain mul / add like torch.norm's sum of squares (no fma contraction)
+  }
+  o[D] = sqrtf(ss);
+}
+
+extern "C" int mgn_edge_features(const float* pos, int D, const int64_t* src, const int64_t* dst, int64_t E, float* edge_attr, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (D != 2 && D != 3) return pfail(1, "mgn_edge_features: positions must be 2-D or 3-D");
+  if (E <= 0) return 0;
+  const unsigned grid = (unsigned)((E + 255) / 256);
+  if (D == 2)
+    hipLaunchKernelGGL(k_edge_features<2>, dim3(grid), dim3(256), 0, s, pos, src, dst, (long)E, edge_attr);
+  else
+    hipLaunchKernelGGL(k_edge_features<3>, dim3(grid), dim3(256), 0, s, pos, src, dst, (long)E, edge_attr);
+  return pcheck("mgn_edge_features");
+}
+
+// ========================================================= Simulator pre / post (N1)
+// Reference: Simulator._build_input_graph / build_outputs (models/simulator.py:112-191) and
+// Normalizer (models/layers.py:331-391).  One description struct for the three normalised
+// streams of a step:
+//   node features  v = cat[x[:, fs:fe], one_hot(x[:, type_idx], 9)]        width Wn = (fe-fs) + 9
+//   target delta   v = y[:, 0:O] - x[:, os:oe]                              width O
+//   edge features  v = edge_attr                                            width We
+// Statistics (training, while the normaliser still accumulates): column sums and sums of squares
+// of v, two-stage and atomics-free: k_stats_partial writes one partial per workgroup and column,
+// k_stats_final adds them in a fixed order into the running buffers (acc_sum, acc_sum_squared,
+// acc_count, num_accumulations) -- before the normalisation, as Normalizer.forward does.
+// Normalisation:  (v - mean) / max(std, eps),  mean = sum / max(count, 1),
+//                 std = sqrt(max(sumsq / max(count,1) - mean^2, 0)).
+#define SIM_MAXW 32
+#define SIM_PART 256  // partial workgroups per stream
+
+__device__ __forceinline__ float sim_value(const mgn_sim_desc& d, int stream, long row, int col) {
+  if (stream == 0) {
+    const int nf = d.feat_end - d.feat_start;
+    if (col < nf) return d.x[row * d.x_w + d.feat_start + col];
+    const float t = d.x[row * d.x_w + d.type_idx];
+    return ((int)(long)t == col - nf) ? 1.f : 0.f;  // one_hot(node_type.long(), 9)
+  }
+  if (stream == 1) return d.y[row * d.y_w + col] - d.x[row * d.x_w + d.out_start + col];
+  return d.edge_attr[row * d.edge_w + col];
+}
+__device__ __forceinline__ int sim_width(const mgn_sim_desc& d, int stream) {
+  return stream == 0 ? (d.feat_end - d.feat_start) + MGN_NODE_TYPES : stream == 1 ? d.out_w : d.edge_w;
+}
+__device__ __forceinline__ long sim_rows(const mgn_sim_desc& d, int stream) { return stream == 2 ? d.E : d.N; }
+
+// grid (SIM_PART, 3): workgroup b of stream s sums rows b, b+SIM_PART*R, ... ; thread = (row lane, column)
+__global__ void __launch_bounds__(256) k_stats_partial(const mgn_sim_desc d, float* __restrict__ part) {
+  const int stream = blockIdx.y;
+  if (!d.accumulate[stream]) return;
+  const int W = sim_width(d, stream);
+  const long M = sim_rows(d, stream);
+  __shared__ float s1[256], s2[256];
+  const int col = threadIdx.x % SIM_MAXW, rl = threadIdx.x / SIM_MAXW;  // 32 columns x 8 row lanes
+  float a = 0.f, b = 0.f;
+  if (col < W)
+    for (long r = (long)blockIdx.x * 8 + rl; r < M; r += (long)SIM_PART * 8) {
+      const float v = sim_value(d, stream, r, col);
+      a += v;
+      b = fmaf(v, v, b);
+    }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = b;
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < 8; ++k) {
+      a += s1[k * SIM_MAXW + col];
+      b += s2[k * SIM_MAXW + col];
+    }
+    float* p = part + ((size_t)(stream * SIM_PART + blockIdx.x) * 2) * SIM_MAXW;
+    p[col] = a;
+    p[SIM_MAXW + col] = b;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_stats_final(const mgn_sim_desc d, const float* __restrict__ part) {
+  const int stream = blockIdx.x;
+  if (!d.accumulate[stream]) return;
+  const int W = sim_width(d, stream);
+  const int col = threadIdx.x % SIM_MAXW, which = threadIdx.x / SIM_MAXW;  // 0: sum, 1: sum of squares
+  if (col < W) {
+    float t = 0.f;
+    for (int b = 0; b < SIM_PART; ++b) t += part[((size_t)(stream * SIM_PART + b) * 2 + which) * SIM_MAXW + col];
+    float* dst = which == 0 ? d.acc_sum[stream] : d.acc_sumsq[stream];
+    dst[col] += t;
+  }
+  if (threadIdx.x == 0) {
+    *d.acc_count[stream] += (float)sim_rows(d, stream);
+    *d.num_acc[stream] += 1.f;
+  }
+}
+
+// grid.y = stream; one thread per output element
+__global__ void __launch_bounds__(256) k_sim_normalize(const mgn_sim_desc d) {
+  const int stream = blockIdx.y;
+  const int W = sim_width(d, stream);
+  const long M = sim_rows(d, stream);
+  float* out = stream == 0 ? d.node_out : stream == 1 ? d.target_out : d.edge_out;
+  if (out == nullptr) return;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * W) return;
+  const long row = i / W;
+  const int col = (int)(i % W);
+  const float cnt = fmaxf(*d.acc_count[stream], 1.0f);
+  const float mean = d.acc_sum[stream][col] / cnt;
+  const float var = d.acc_sumsq[stream][col] / cnt - mean * mean;
+  const float sd = fmaxf(sqrtf(fmaxf(var, 0.f)), d.std_eps);
+  out[i] = (sim_value(d, stream, row, col) - mean) / sd;
+}
+
+extern "C" size_t mgn_sim_workspace_bytes(void) { return (size_t)3 * SIM_PART * 2 * SIM_MAXW * sizeof(float); }
+
+extern "C" int mgn_sim_pre(const mgn_sim_desc* desc, void* ws, size_t ws_bytes, void* stream) {
+  const mgn_sim_desc& d = *desc;
+  hipStream_t s = (hipStream_t)stream;
+  const int Wn = (d.feat_end - d.feat_start) + MGN_NODE_TYPES;
+  if (d.feat_end < d.feat_start || Wn > SIM_MAXW || d.out_w < 1 || d.out_w > SIM_MAXW || d.edge_w > SIM_MAXW)
+    return pfail(1, "mgn_sim_pre: feature widths out of range (<= 32 columns per stream)");
+  if (d.N < 0 || d.E < 0 || d.x == nullptr) return pfail(1, "mgn_sim_pre: bad arguments");
+  if (d.target_out != nullptr && d.y == nullptr) return pfail(1, "mgn_sim_pre: target requested without y");
+  if (d.accumulate[0] || d.accumulate[1] || d.accumulate[2]) {
+    if (ws_bytes < mgn_sim_workspace_bytes()) return pfail(1, "mgn_sim_pre: workspace too small");
+    hipLaunchKernelGGL(k_stats_partial, dim3(SIM_PART, 3), dim3(256), 0, s, d, (float*)ws);
+    hipLaunchKernelGGL(k_stats_final, dim3(3), dim3(64), 0, s, d, (const float*)ws);
+  }
+  long mx = d.N * Wn;
+  if (d.N * d.out_w > mx) mx = d.N * d.out_w;
+  if (d.E * d.edge_w > mx) mx = d.E * d.edge_w;
+  if (mx > 0) hipLaunchKernelGGL(k_sim_normalize, dim3((unsigned)((mx + 255) / 256), 3), dim3(256), 0, s, d);
+  return pcheck("mgn_sim_pre");
+}
+
+// build_outputs + the rollout's ground-truth re-imposition (simulator.py:186-191,
+// lightning_module.py:27-35,375-409):  pred = x[:, os:oe] + net_out * std + mean, and where the
+// node type is not NORMAL / OUTFLOW the ground truth y is written instead (mask_truth != 0).
+__global__ void __launch_bounds__(256) k_sim_post(const float* __restrict__ x, int x_w, int out_start, int type_idx,
+                                                  const float* __restrict__ y, int y_w, const float* __restrict__ net_out, int O,
+                                                  const float* __restrict__ acc_sum, const float* __restrict__ acc_sumsq,
+                                                  const float* __restrict__ acc_count, float std_eps, int mask_truth,
+                                                  long N, float* __restrict__ pred) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * O) return;
+  const long row = i / O;
+  const int col = (int)(i % O);
+  const float cnt = fmaxf(*acc_count, 1.0f);
+  const float mean = acc_sum[col] / cnt;
+  const float var = acc_sumsq[col] / cnt - mean * mean;
+  const float sd = fmaxf(sqrtf(fmaxf(var, 0.f)), std_eps);
+  float p = x[row * x_w + out_start + col] + (net_out[i] * sd + mean);
+  if (mask_truth) {
+    const int t = (int)(long)x[row * x_w + type_idx];
+    if (!(t == MGN_NODE_NORMAL || t == MGN_NODE_OUTFLOW)) p = y[row * y_w + col];
+  }
+  pred[i] = p;
+}
+
+extern "C" int mgn_sim_post(const float* x, int x_w, int out_start, int type_idx, const float* y, int y_w, const float* net_out,
+                            int O, const float* acc_sum, const float* acc_sumsq, const float* acc_count, float std_eps,
+                            int mask_truth, int64_t N, float* pred, void* stream) {
+  if (O < 1 || O > SIM_MAXW || N < 0) return pfail(1, "mgn_sim_post: bad arguments");
+  if (mask_truth && y == nullptr) return pfail(1, "mgn_sim_post: ground-truth re-imposition needs y");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_sim_post, dim3((unsigned)((N * O + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_w, out_start, type_idx, y,
+                     y_w, net_out, O, acc_sum, acc_sumsq, acc_count, std_eps, mask_truth, (long)N, pred);
+  return pcheck("mgn_sim_post");
+}

@@ -167,10 +167,8 @@ class Engine:
         i0, i1 = self.sim.output_index_start, self.sim.output_index_end
         if last_prediction is not None:
             batch.x[:, i0:i1] = last_prediction
-        mask = build_mask(batch.x[:, self.sim.node_type_index])
-        _, _, pred = self.sim(batch)
-        pred = torch.where(mask.unsqueeze(1), batch.y, pred)
-        return pred
+        graph, _ = self.sim._build_input_graph(batch, False)
+        return self.sim.predict(batch, self.sim.model(graph), mask_truth=True)
 
     # ---------------------------------------------------------------- hipGraph rollout
     @torch.no_grad()
@@ -195,9 +193,8 @@ class Engine:
             b = Graph(x=st.x.clone(), y=st.y, pos=st.pos, edge_attr=st.edge_attr, edge_index=st.edge_index)
             b.mgn_topology = st.mgn_topology
             b.x[:, i0:i1] = last
-            mask = build_mask(b.x[:, self.sim.node_type_index])
-            _, _, pred = self.sim(b)
-            pred = torch.where(mask.unsqueeze(1), st.y, pred)
+            graph, _ = self.sim._build_input_graph(b, False)
+            pred = self.sim.predict(b, self.sim.model(graph), mask_truth=True)
             last.copy_(pred)
             return pred
 

@@ -133,6 +133,7 @@ class Normalizer(nn.Module):
         self.name, self.device = name, device
         self._max_accumulations = max_accumulations
         self._std_epsilon = torch.tensor(std_epsilon, dtype=torch.float32, requires_grad=False, device=device)
+        self._std_epsilon_value = float(torch.tensor(std_epsilon, dtype=torch.float32))  # host copy for the fused kernels
         self.register_buffer("_acc_count", torch.tensor(0.0, device=device))
         self.register_buffer("_num_accumulations", torch.tensor(0.0, device=device))
         self.register_buffer("_acc_sum", torch.zeros((1, size), dtype=torch.float32, device=device))

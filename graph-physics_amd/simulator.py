@@ -1,6 +1,13 @@
 """``Simulator`` boundary wrapper (graphphysics/models/simulator.py:13-217):
-normalisers, one-hot node type, delta target, inverse normalisation.  Cheap
-elementwise code that brackets the hot path; kept in PyTorch-ROCm."""
+normalisers, one-hot node type, delta target, inverse normalisation.
+
+On the MI355X the whole pre-processing of a step (one-hot + slice + concat, the three online
+normalisers incl. their running statistics, the delta target) is ONE call into the engine
+(``mgn_sim_pre``: 2-3 launches instead of ~40 small torch kernels), and the post-processing
+(inverse normalisation, optional ground-truth re-imposition of the rollout) another
+(``mgn_sim_post``) -- SURVEY.md section 8f row N1.  The torch statement of the same arithmetic
+below stays as the module-level reference semantic for tensors the fused path does not take
+(CPU tensors in host-side tests, more than 32 feature columns)."""
 from __future__ import annotations
 
 from typing import Optional, Tuple
@@ -8,6 +15,7 @@ from typing import Optional, Tuple
 import torch
 import torch.nn as nn
 
+from . import _capi
 from .layers import Normalizer
 from .mesh import Graph
 from .nodetype import NodeType
@@ -31,6 +39,94 @@ class Simulator(nn.Module):
         self._edge_normalizer = (Normalizer(size=edge_input_size, name="edge_normalizer", device=device)
                                  if self.edge_input_size is not None else None)
         self.device = device
+        self.fused = True  # engine kernels for the pre / post processing of CUDA tensors
+        self._ws = None
+
+    # ------------------------------------------------------------------ fused path (N1)
+    def _can_fuse(self, inputs) -> bool:
+        x = inputs.x
+        return (self.fused and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+                and self.node_input_size <= 32 and self.output_size <= 32
+                and (self.edge_input_size or 0) <= 32
+                and (inputs.edge_attr is None or inputs.edge_attr.dtype == torch.float32)
+                and (getattr(inputs, "y", None) is None or inputs.y.dtype == torch.float32))
+
+    def _desc(self, inputs, is_training: bool):
+        d = _capi.SimDesc()
+        x = inputs.x.contiguous()
+        y = getattr(inputs, "y", None)
+        y = y.contiguous() if y is not None else None
+        ea = inputs.edge_attr.contiguous() if (self._edge_normalizer is not None and inputs.edge_attr is not None) else None
+        keep = [x, y, ea]
+        d.N, d.E = x.shape[0], (ea.shape[0] if ea is not None else 0)
+        d.x, d.x_w = x.data_ptr(), x.shape[1]
+        d.y, d.y_w = (y.data_ptr() if y is not None else None), (y.shape[1] if y is not None else 0)
+        d.edge_attr, d.edge_w = (ea.data_ptr() if ea is not None else None), (ea.shape[1] if ea is not None else 0)
+        d.feat_start, d.feat_end = self.feature_index_start, self.feature_index_end
+        d.out_start, d.out_w, d.type_idx = self.output_index_start, self.output_size, self.node_type_index
+        norms = (self._node_normalizer, self._output_normalizer, self._edge_normalizer)
+        present = (True, y is not None, ea is not None)
+        for s, (nz, here) in enumerate(zip(norms, present)):
+            if nz is None:
+                nz = self._node_normalizer  # never dereferenced: edge_w == 0
+            d.acc_sum[s], d.acc_sumsq[s] = nz._acc_sum.data_ptr(), nz._acc_sum_squared.data_ptr()
+            d.acc_count[s], d.num_acc[s] = nz._acc_count.data_ptr(), nz._num_accumulations.data_ptr()
+            acc = False
+            if is_training and here and norms[s] is not None:
+                if nz._host_num_acc is None:
+                    nz._host_num_acc = int(nz._num_accumulations.item())
+                if nz._host_num_acc < nz._max_accumulations:  # Normalizer.forward, layers.py:345-349
+                    acc = True
+                    nz._host_num_acc += 1
+            d.accumulate[s] = int(acc)
+        d.std_eps = float(self._output_normalizer._std_epsilon_value)
+        return d, keep, (x, y, ea)
+
+    def _build_input_graph_fused(self, inputs, is_training: bool):
+        dev = inputs.x.device
+        d, keep, (x, y, ea) = self._desc(inputs, is_training)
+        Wn = (self.feature_index_end - self.feature_index_start) + NodeType.SIZE
+        xn = torch.empty(x.shape[0], Wn, dtype=torch.float32, device=dev)
+        tgt = torch.empty(x.shape[0], self.output_size, dtype=torch.float32, device=dev) if y is not None else None
+        en = torch.empty_like(ea) if ea is not None else inputs.edge_attr
+        d.node_out, d.target_out = xn.data_ptr(), (tgt.data_ptr() if tgt is not None else None)
+        d.edge_out = en.data_ptr() if ea is not None else None
+        L = _capi.lib()
+        if self._ws is None or self._ws.device != dev:
+            self._ws = torch.empty(L.mgn_sim_workspace_bytes(), dtype=torch.uint8, device=dev)
+        import ctypes as C
+        with torch.cuda.device(dev):
+            rc = L.mgn_sim_pre(C.byref(d), self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+        _capi.check(rc, "mgn_sim_pre", prep=True)
+        graph = Graph(x=xn, pos=inputs.pos, edge_attr=en, edge_index=inputs.edge_index)
+        topo = getattr(inputs, "mgn_topology", None)
+        if topo is not None:
+            graph.mgn_topology = topo
+        return graph, tgt
+
+    def predict(self, inputs, network_output: torch.Tensor, mask_truth: bool = False) -> torch.Tensor:
+        """``build_outputs`` (simulator.py:178-191); with ``mask_truth`` the rollout's re-imposition
+        of the ground truth on the nodes that are not NORMAL / OUTFLOW (lightning_module.py:27-35)."""
+        if not (self._can_fuse(inputs) and network_output.is_cuda):
+            pred = self.build_outputs(inputs, network_output)
+            if mask_truth:
+                t = inputs.x[:, self.node_type_index]
+                keep = torch.logical_or(t == int(NodeType.NORMAL), t == int(NodeType.OUTFLOW))
+                pred = torch.where(keep.unsqueeze(1), pred, inputs.y)
+            return pred
+        x = inputs.x.contiguous()
+        y = inputs.y.contiguous() if (mask_truth and inputs.y is not None) else None
+        no = network_output.detach().to(torch.float32).contiguous()
+        nz = self._output_normalizer
+        pred = torch.empty(x.shape[0], self.output_size, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _capi.lib().mgn_sim_post(x.data_ptr(), x.shape[1], self.output_index_start, self.node_type_index,
+                                          (y.data_ptr() if y is not None else None), (y.shape[1] if y is not None else 0),
+                                          no.data_ptr(), self.output_size, nz._acc_sum.data_ptr(), nz._acc_sum_squared.data_ptr(),
+                                          nz._acc_count.data_ptr(), float(nz._std_epsilon_value), int(bool(mask_truth)), x.shape[0],
+                                          pred.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+        _capi.check(rc, "mgn_sim_post", prep=True)
+        return pred
 
     def _get_pre_target(self, inputs) -> torch.Tensor:
         return inputs.x[:, self.output_index_start: self.output_index_end]
@@ -47,6 +143,8 @@ class Simulator(nn.Module):
         return torch.cat([features, one_hot_type], dim=1)
 
     def _build_input_graph(self, inputs, is_training: bool):
+        if self._can_fuse(inputs):
+            return self._build_input_graph_fused(inputs, is_training)
         target_delta_normalized = self._get_target_normalized(inputs, is_training)
         node_features = self._build_node_features(inputs, self._get_one_hot_type(inputs))
         node_features_normalized = self._node_normalizer(node_features, is_training)
@@ -61,6 +159,8 @@ class Simulator(nn.Module):
         return graph, target_delta_normalized
 
     def build_outputs(self, inputs, network_output: torch.Tensor) -> torch.Tensor:
+        if self._can_fuse(inputs) and network_output.is_cuda and not torch.is_grad_enabled():
+            return self.predict(inputs, network_output, mask_truth=False)
         return self._get_pre_target(inputs) + self._output_normalizer.inverse(network_output)
 
     def forward(self, inputs) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:

@@ -205,6 +205,61 @@ typedef struct {
 } mgn_wpack_block;
 int mgn_wpack(int n, const mgn_wpack_block* blocks, void* stream);
 
+/* ================================================================================
+ * Either side of the path -- csrc/mgn_prep.hip
+ * ================================================================================ */
+
+/* ------------------------------------------------------------- faces -> edges (N2)
+ * T.FaceToEdge(remove_faces=False) + to_undirected of the reference's preprocessing
+ * (graphphysics/dataset/preprocessing.py:421-424; torch-geometric==2.6.1): face is [K,F]
+ * int64 (K = 3 triangles / 4 tetrahedra, PyG layout); every pair of corners in both directions,
+ * coalesced = sorted by (src,dst), duplicates and self loops removed.  src / dst have capacity
+ * F*K*(K-1); *n_edges (device) receives E.  Synchronises `stream`; returns 3 on a corner
+ * outside [0,N).  Needs N*N < 2^63. */
+size_t mgn_faces_to_edges_workspace_bytes(int64_t F, int K);
+int mgn_faces_to_edges(const int64_t* face, int K, int64_t F, int64_t N, int64_t* src, int64_t* dst,
+                       int64_t* n_edges, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------- edge features (N2)
+ * T.Cartesian(norm=False) + T.Distance(norm=False) (preprocessing.py:16-23):
+ * edge_attr[e] = [pos[src]-pos[dst] (D values), ||pos[dst]-pos[src]||_2],  D = 2 or 3. */
+int mgn_edge_features(const float* pos, int D, const int64_t* src, const int64_t* dst, int64_t E,
+                      float* edge_attr, void* stream);
+
+/* ------------------------------------------------- Simulator pre / post processing (N1)
+ * Simulator._build_input_graph / build_outputs (graphphysics/models/simulator.py:112-191) with
+ * the three Normalizers (models/layers.py:331-391) in one pass per tensor.  Streams:
+ *   0 node features  cat[x[:, feat_start:feat_end], one_hot(x[:, type_idx], 9)]
+ *   1 target delta   y[:, 0:out_w] - x[:, out_start:out_start+out_w]
+ *   2 edge features  edge_attr
+ * accumulate[s] != 0: first add this batch's column sums / sums of squares / row count to the
+ * running buffers (two-stage, atomics-free), then normalise with the updated statistics --
+ * Normalizer.forward's order.  out pointers may be NULL (stream skipped). */
+#define MGN_NODE_TYPES 9     /* NodeType.SIZE (graphphysics/utils/nodetype.py) */
+#define MGN_NODE_NORMAL 0
+#define MGN_NODE_OUTFLOW 5
+typedef struct {
+  int64_t N, E;
+  const float* x; int x_w;
+  const float* y; int y_w;
+  const float* edge_attr; int edge_w;
+  int feat_start, feat_end, out_start, out_w, type_idx;
+  float* acc_sum[3]; float* acc_sumsq[3]; float* acc_count[3]; float* num_acc[3];
+  int accumulate[3];
+  float std_eps;
+  float* node_out; float* target_out; float* edge_out;
+} mgn_sim_desc;
+size_t mgn_sim_workspace_bytes(void);
+int mgn_sim_pre(const mgn_sim_desc* desc, void* ws, size_t ws_bytes, void* stream);
+/* pred = x[:, out_start:+O] + (net_out * std + mean) of the output normaliser; mask_truth != 0
+ * re-imposes y on the nodes whose type is not NORMAL / OUTFLOW (rollout,
+ * training/lightning_module.py:27-35,375-409). */
+int mgn_sim_post(const float* x, int x_w, int out_start, int type_idx, const float* y, int y_w,
+                 const float* net_out, int O, const float* acc_sum, const float* acc_sumsq,
+                 const float* acc_count, float std_eps, int mask_truth, int64_t N, float* pred, void* stream);
+/* text of the last error of the entry points in this section */
+const char* mgn_prep_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

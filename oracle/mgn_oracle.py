@@ -293,3 +293,37 @@ def csr_by_key(key: torch.Tensor, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
     rowptr = torch.zeros(n + 1, dtype=torch.int64)
     rowptr[1:] = torch.cumsum(counts, 0)
     return rowptr.to(torch.int32), perm.to(torch.int32)
+
+
+# --------------------------------------------------------------------------- R0 / N2
+def faces_to_edges_oracle(face, num_nodes: int):
+    """T.FaceToEdge(remove_faces=False) (+ its to_undirected) of the reference's preprocessing
+    (graphphysics/dataset/preprocessing.py:421-424; torch-geometric==2.6.1, not installed here:
+    restated from its published behaviour): face [K,F] -> edge_index [2,E] int64 holding every
+    pair of corners in both directions, coalesced = sorted by (src,dst) without duplicates; self
+    loops of degenerate faces dropped.  The reference's tests pin no values for
+    this transform; the anchor is its own test mesh tests/mock_vtu/cylinder_0.vtu (1923 nodes,
+    3612 triangles -> 11 070 directed edges, SURVEY 8 header)."""
+    import numpy as np
+
+    f = np.asarray(face, dtype=np.int64)
+    K = f.shape[0]
+    src, dst = [], []
+    for a in range(K):
+        for b in range(a + 1, K):
+            src += [f[a], f[b]]
+            dst += [f[b], f[a]]
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    keep = src != dst
+    key = np.unique(src[keep] * np.int64(num_nodes) + dst[keep])
+    return np.stack([key // num_nodes, key % num_nodes], axis=0)
+
+
+def edge_features_oracle(pos: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+    """T.Cartesian(norm=False) then T.Distance(norm=False) (preprocessing.py:16-23):
+    cart = pos[row] - pos[col] with (row, col) = edge_index; dist = ||pos[col] - pos[row]||_2
+    appended as the last column."""
+    row, col = edge_index[0], edge_index[1]
+    cart = pos[row] - pos[col]
+    dist = torch.norm(pos[col] - pos[row], p=2, dim=-1).view(-1, 1)
+    return torch.cat([cart, dist], dim=-1)

@@ -8,6 +8,8 @@ Tolerances (fp32 path):
   * gradients .................................... <= 1e-4 relative (the reference's own
     CPU gradients are not bit-reproducible; see tests/golden/make_golden.py)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -582,3 +584,95 @@ def test_rollout_graphed_equals_eager(dev):
     graphed = eng.rollout_graphed(frames)
     for a, b in zip(eager, graphed):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ N2: input construction
+def _mesh_fixture():
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cylinder_vtu_mesh.npz"))
+    return d["pos"], d["face"].astype(np.int64)
+
+
+def test_faces_to_edges_vs_oracle(dev):
+    """mgn_faces_to_edges: bit-exact against the oracle on the reference's test mesh (11 070
+    edges), on tetrahedra, with duplicate and degenerate faces, on an empty face list; a corner
+    outside [0,N) raises like the CSR build."""
+    from graph_physics_amd import preprocess as P
+
+    pos, face = _mesh_fixture()
+    N = pos.shape[0]
+    ei = P.faces_to_edges(torch.from_numpy(face).to(dev), N)
+    assert ei.shape == (2, 11070) and ei.dtype == torch.int64
+    assert np.array_equal(ei.cpu().numpy(), O.faces_to_edges_oracle(face, N))
+    rng = np.random.default_rng(3)
+    tets = rng.integers(0, 500, size=(4, 3000))
+    tets[:, :50] = tets[:, 50:100]          # duplicate cells
+    tets[1, 100:130] = tets[0, 100:130]     # degenerate: repeated corner
+    got = P.faces_to_edges(torch.from_numpy(tets).to(dev), 500)
+    assert np.array_equal(got.cpu().numpy(), O.faces_to_edges_oracle(tets, 500))
+    assert P.faces_to_edges(torch.zeros(3, 0, dtype=torch.int64, device=dev), 10).shape == (2, 0)
+    big = np.stack([np.arange(0, 300000), np.arange(1, 300001), np.arange(2, 300002)]) % 200000
+    got = P.faces_to_edges(torch.from_numpy(big).to(dev), 200000)
+    assert np.array_equal(got.cpu().numpy(), O.faces_to_edges_oracle(big, 200000))
+    bad = face.copy()
+    bad[1, 7] = N
+    with pytest.raises(IndexError):
+        P.faces_to_edges(torch.from_numpy(bad).to(dev), N)
+
+
+def test_edge_features_vs_oracle(dev):
+    """mgn_edge_features against Cartesian + Distance of the oracle: 2-D (reference mesh) and 3-D.
+    Differences and the sum of squares are the same fp32 operations; sqrt may differ by an ulp."""
+    from graph_physics_amd import preprocess as P
+
+    pos, face = _mesh_fixture()
+    ei = torch.from_numpy(O.faces_to_edges_oracle(face, pos.shape[0]))
+    ref = O.edge_features_oracle(torch.from_numpy(pos), ei)
+    got = P.edge_features(torch.from_numpy(pos).to(dev), ei.to(dev)).cpu()
+    assert torch.equal(got[:, :2], ref[:, :2])
+    assert (got[:, 2] - ref[:, 2]).abs().max() <= 1.2e-7 * ref[:, 2].abs().max()
+    p3 = R.randn((400, 3), 9)
+    e3 = torch.from_numpy(np.random.default_rng(1).integers(0, 400, size=(2, 5000)))
+    ref3 = O.edge_features_oracle(p3, e3)
+    got3 = P.edge_features(p3.to(dev), e3.to(dev)).cpu()
+    assert torch.equal(got3[:, :3], ref3[:, :3]) and rel_err(got3[:, 3], ref3[:, 3]) < 2e-7
+
+
+# ------------------------------------------------------------ N1: Simulator pre / post
+def test_fused_simulator_pre_post_vs_oracle(dev):
+    """mgn_sim_pre / mgn_sim_post (one-hot + concat + online normalisers + delta target;
+    inverse normalisation + ground-truth re-imposition) against the SimulatorOracle: two training
+    calls (statistics accumulate BEFORE normalising, Normalizer.forward), then eval."""
+    cfg = gp.cylinder_config(2, 128)
+    ix = cfg["index"]
+    g1, g2 = gp.cylinder_mesh(600, 1), gp.cylinder_mesh(600, 2)
+    model = gp.get_model(cfg).to(dev)
+    sim = gp.get_simulator(cfg, model, dev)
+    assert sim.fused
+    orc = O.SimulatorOracle(ix, 11, 3, 2)
+    sim.train()
+    for g in (g1, g2):
+        xn_r, en_r, tg_r = orc.build_input(g.x, g.y, g.edge_attr, True)
+        graph, tgt = sim._build_input_graph(g.to(dev), True)
+        assert rel_err(graph.x, xn_r) < 2e-6 and rel_err(graph.edge_attr, en_r) < 2e-6 and rel_err(tgt, tg_r) < 2e-6
+    for nz, st in ((sim._node_normalizer, orc.node_norm), (sim._output_normalizer, orc.out_norm), (sim._edge_normalizer, orc.edge_norm)):
+        assert float(nz._num_accumulations) == 2.0 and float(nz._acc_count) == float(st.acc_count)
+        assert rel_err(nz._acc_sum, st.acc_sum) < 1e-6 and rel_err(nz._acc_sum_squared, st.acc_sum_squared) < 1e-6
+    sim.eval()
+    gd = g2.to(dev)
+    graph, tgt = sim._build_input_graph(gd, False)
+    xn_r, en_r, tg_r = orc.build_input(g2.x, g2.y, g2.edge_attr, False)
+    assert rel_err(graph.x, xn_r) < 2e-6 and rel_err(tgt, tg_r) < 2e-6
+    assert float(sim._node_normalizer._num_accumulations) == 2.0   # eval does not accumulate
+    net_out = R.randn((g2.x.shape[0], 2), 4)
+    ref = orc.build_outputs(g2.x, net_out)
+    got = sim.predict(gd, net_out.to(dev), mask_truth=False)
+    assert rel_err(got, ref) < 2e-6
+    t = g2.x[:, ix["node_type_index"]]
+    keep = (t == 0) | (t == 5)
+    want = torch.where(keep.unsqueeze(1), ref, g2.y)
+    got = sim.predict(gd, net_out.to(dev), mask_truth=True)
+    assert rel_err(got, want) < 2e-6 and torch.equal(got.cpu()[~keep], g2.y[~keep])
+    # the torch statement of the same arithmetic (module-level semantic) agrees
+    sim.fused = False
+    g_t, tgt_t = sim._build_input_graph(gd, False)
+    assert rel_err(g_t.x, graph.x) < 2e-6 and rel_err(tgt_t, tgt) < 2e-6

@@ -1,6 +1,8 @@
 """CPU: the oracle (oracle/mgn_oracle.py) against the golden vectors minted from the
 reference (tests/golden/make_golden.py).  Forward results are bit-exact; gradients
 carry a tolerance because CPU index_put_(accumulate) is order-nondeterministic."""
+import os
+
 import numpy as np
 import torch
 
@@ -108,3 +110,24 @@ def test_csr_oracle():
     rowptr, perm = O.csr_by_key(key, 5)
     assert rowptr.tolist() == [0, 2, 3, 6, 6, 7]
     assert perm.tolist() == [1, 4, 3, 0, 2, 5, 6]
+
+
+def test_faces_to_edges_oracle_on_reference_mesh():
+    """The reference's own test mesh (tests/mock_vtu/cylinder_0.vtu, minted into
+    golden/cylinder_vtu_mesh.npz by make_mesh_fixture.py): 1923 nodes, 3612 triangles ->
+    11 070 directed edges (Euler count with one hole), symmetric, sorted by
+    (src, dst), no duplicates, no self loops; and the host-side mesh builder agrees."""
+    import numpy as np
+    from graph_physics_amd import mesh
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cylinder_vtu_mesh.npz"))
+    face, N = d["face"].astype(np.int64), d["pos"].shape[0]
+    ei = O.faces_to_edges_oracle(face, N)
+    assert N == 1923 and face.shape == (3, 3612) and ei.shape == (2, 11070)
+    key = ei[0] * N + ei[1]
+    assert (np.diff(key) > 0).all() and (ei[0] != ei[1]).all()
+    assert np.array_equal(np.sort(ei[1] * N + ei[0]), key)  # symmetric closure
+    assert np.array_equal(mesh.faces_to_edges(face.T, N), ei)
+    ea = O.edge_features_oracle(torch.from_numpy(d["pos"]), torch.from_numpy(ei))
+    assert ea.shape == (11070, 3) and torch.allclose(ea[:, 2], ea[:, :2].norm(dim=1))
+    assert torch.equal(ea, mesh.edge_features(torch.from_numpy(d["pos"]), torch.from_numpy(ei)))
