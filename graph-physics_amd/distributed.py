@@ -115,7 +115,7 @@ class HipBackend:
     def block(self, block, x, e, ctx):
         from . import ops
         from .layers import _block_params
-        return ops.ProcessorFunction.apply(x, e, ctx, 1, *_block_params(block))
+        return ops.processor_apply(x, e, ctx, 1, *_block_params(block))
 
 
 class PartitionedEPD(torch.nn.Module):

@@ -63,7 +63,7 @@ class MLP(nn.Sequential):
             params += [m.weight, m.bias]
         if norm is not None:
             params.append(norm.scale)
-        return ops.MlpFunction.apply(x, norm is not None, *params)
+        return ops.mlp_apply(x, norm is not None, *params)
 
 
 def build_mlp(in_size: int, hidden_size: int, out_size: int, nb_of_layers: int = 4,
@@ -119,7 +119,7 @@ class GraphNetBlock(nn.Module):
                 ) -> Tuple[torch.Tensor, torch.Tensor]:
         topo = ops.get_topology(edge_index, x.shape[0])
         e_sorted = edge_attr[topo.perm_dst.long()]
-        x_new, e_new = ops.ProcessorFunction.apply(x, e_sorted, topo, 1, *_block_params(self))
+        x_new, e_new = ops.processor_apply(x, e_sorted, topo, 1, *_block_params(self))
         return x_new, e_new[topo.inv_perm]
 
 

@@ -275,6 +275,38 @@ def transpose_blocks(blocks: Sequence[Tuple[int, int, int, int]], H: int, dev):
     _capi.check(rc, "mgn_transpose_blocks")
 
 
+# ``ctx.needs_input_grad`` mirrors ``tensor.requires_grad`` even under ``torch.no_grad()``, and
+# grad mode is always off INSIDE ``Function.forward`` -- so whether activations must be saved for
+# a backward pass has to be read BEFORE ``apply``.  Without this an inference forward ran the
+# training-mode kernels (4 extra 512-byte stores per row and layer) and kept every round's
+# activations alive (270 GB on the 1M-node mesh).
+import threading as _threading
+
+_call = _threading.local()
+
+
+def _saving() -> bool:
+    return getattr(_call, "grad", True)
+
+
+def mlp_apply(*args):
+    """MlpFunction.apply with the caller's grad mode recorded."""
+    _call.grad = torch.is_grad_enabled()
+    try:
+        return MlpFunction.apply(*args)
+    finally:
+        _call.grad = True
+
+
+def processor_apply(*args):
+    """ProcessorFunction.apply with the caller's grad mode recorded."""
+    _call.grad = torch.is_grad_enabled()
+    try:
+        return ProcessorFunction.apply(*args)
+    finally:
+        _call.grad = True
+
+
 # ------------------------------------------------------------ generic MLP (R2)
 class MlpFunction(torch.autograd.Function):
     """build_mlp forward/backward on the engine (encoders, decoder, stand-alone MLPs).
@@ -310,7 +342,7 @@ class MlpFunction(torch.autograd.Function):
             bl = torch.nn.functional.pad(bl, (0, op - out_w))
         Wk = [W0] + Ws[1:-1] + [Wl]
         bk = bs[:-1] + [bl]
-        need = any(ctx.needs_input_grad)
+        need = any(ctx.needs_input_grad) and _saving()
         y = torch.empty(M, out_w, dtype=torch.float32, device=dev)
         saveH = [torch.empty(M, H, dtype=torch.float32, device=dev) for _ in range(NL - 1)] if need else None
         U = torch.empty(M, H, dtype=torch.float32, device=dev) if (need and has_norm) else None
@@ -386,7 +418,7 @@ class ProcessorFunction(torch.autograd.Function):
             raise ValueError("x / edge_attr do not match the topology")
         dev = x.device
         P = [_f32c(p) for p in params]
-        need = any(ctx.needs_input_grad)
+        need = any(ctx.needs_input_grad) and _saving()
         f = dict(dtype=torch.float32, device=dev)
         m = torch.empty(E, H, **f)
         saved = []

@@ -59,7 +59,7 @@ class EncodeProcessDecode(nn.Module):
         params = []
         for block in self.processor_list:
             params += _block_params(block)
-        x, _ = ops.ProcessorFunction.apply(x, e, topo, len(self.processor_list), *params)
+        x, _ = ops.processor_apply(x, e, topo, len(self.processor_list), *params)
         if self.only_processor:
             return x
         return self.decode_module(x)

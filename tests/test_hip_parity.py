@@ -676,3 +676,31 @@ def test_fused_simulator_pre_post_vs_oracle(dev):
     sim.fused = False
     g_t, tgt_t = sim._build_input_graph(gd, False)
     assert rel_err(g_t.x, graph.x) < 2e-6 and rel_err(tgt_t, tgt) < 2e-6
+
+
+def test_inference_forward_saves_nothing(dev):
+    """Under torch.no_grad() (rollout) no launch is asked to save activations, although the
+    parameters require grad (ctx.needs_input_grad cannot tell); with grad enabled every
+    processor launch is."""
+    net = gp.EncodeProcessDecode(3, 11, 3, 2, hidden_size=128).to(dev)
+    _, ei, ea = R.delaunay_graph(300, 5)
+    g = gp.Graph(x=R.randn((300, 11), 1).to(dev), edge_attr=R.randn((ei.shape[1], 3), 2).to(dev), edge_index=ei.to(dev))
+    seen = []
+    orig = ops.mlp_fwd
+
+    def spy(*a, **k):
+        saveH = k.get("saveH", a[10] if len(a) > 10 else None)
+        seen.append(saveH is not None)
+        return orig(*a, **k)
+
+    ops.mlp_fwd = spy
+    try:
+        with torch.no_grad():
+            out0 = net(g)
+        assert seen and not any(seen)
+        seen.clear()
+        out1 = net(g)
+        assert sum(seen) >= 2 * 3 + 3  # edge + node launch per round, encoders / decoder
+    finally:
+        ops.mlp_fwd = orig
+    assert torch.equal(out0, out1.detach())
