@@ -51,6 +51,7 @@ class MlpFwdArgs(C.Structure):
         ("wpk", C.c_void_p * 8),
         ("saveM", C.c_void_p * MAX_LAYERS),
         ("precision", C.c_int),
+        ("out_relu", C.c_int),
     ]
 
 

@@ -340,6 +340,14 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_ml
 #pragma unroll
       for (int ib = 0; ib < HB; ++ib) acc[t][ib] = in[t][ib] + acc[t][ib];
   }
+  if (a.out_relu) {  // stand-alone first layer of an encoder: the activation feeding the packed kernel
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][ib][r] = fmaxf(acc[t][ib][r], 0.f);
+  }
   store_tl<HB, MT, RAGGED>(a.out, acc, a.out_w, mm, valid, g);
 }
 
@@ -1892,6 +1900,9 @@ int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream) {
   const mgn_mlp_fwd_args& a = *args;
   if (int rc = check_mlp_common(a.H, a.NL, a.out_w, "mgn_mlp_fwd")) return rc;
   if (a.precision != 0 && a.precision != 1) return fail(1, "mgn_mlp_fwd: precision must be 0 (fp32-grade) or 1 (bf16)");
+  if (a.out_relu && (a.scale != nullptr || a.resid != nullptr || a.y_out != nullptr || a.wpk[0] != nullptr ||
+                     plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds))
+    return fail(1, "mgn_mlp_fwd: out_relu is for a plain ragged-input launch (no norm / residual / packed path)");
   if (a.precision == 1 && !(plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && fwd_x6(a)))
     return fail(1, "mgn_mlp_fwd: bf16 matrix mode needs the packed split-bf16 path (H = 128, full widths, wpk)");
   if (a.nphase < 1 || a.nphase > MGN_MAX_PHASES) return fail(1, "mgn_mlp_fwd: nphase out of range");

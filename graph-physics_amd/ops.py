@@ -159,7 +159,7 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
             saveR: Optional[torch.Tensor] = None, ldw0: int = 0,
             adds: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]] = (),
             posts: Sequence[Tuple[int, torch.Tensor]] = (), post_ldw: int = 0, wpk: Sequence[int] = (),
-            saveM: Optional[Sequence[torch.Tensor]] = None, precision: int = 0):
+            saveM: Optional[Sequence[torch.Tensor]] = None, precision: int = 0, out_relu: bool = False):
     """``adds``: (rows[*,H], idx or None) gathered into the layer-0 pre-activation;
     ``posts``: (device address of a [H,H] weight block with leading dim ``post_ldw``, out[M,H]);
     ``wpk``: device addresses of the launch's GEMM units packed by :func:`wpack` (phases of
@@ -187,6 +187,7 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
         for l, t in enumerate(saveM):
             a.saveM[l] = _ptr(t)
     a.precision = precision
+    a.out_relu = int(out_relu)
     dev = out.device
     with torch.cuda.device(dev):
         rc = _capi.lib().mgn_mlp_fwd(C.byref(a), _stream(dev))
@@ -347,7 +348,18 @@ class MlpFunction(torch.autograd.Function):
         saveH = [torch.empty(M, H, dtype=torch.float32, device=dev) for _ in range(NL - 1)] if need else None
         U = torch.empty(M, H, dtype=torch.float32, device=dev) if (need and has_norm) else None
         R = torch.empty(M, dtype=torch.float32, device=dev) if (need and has_norm) else None
-        mlp_fwd(M, H, [(x, None, kin)], Wk, bk, scale, out_w, None, y, None, saveH, U, R)
+        if H == 128 and kin < H and out_w == H and NL >= 3 and NL - 1 <= 4 and X6_ENABLED and M > 0:
+            # encoder: narrow first layer stand-alone (h1 = relu(W0 x + b0), the activation the
+            # backward needs anyway), the full-width layers on the packed split-bf16 path
+            h1 = saveH[0] if need else torch.empty(M, H, dtype=torch.float32, device=dev)
+            mlp_fwd(M, H, [(x, None, kin)], [Wk[0]], [bk[0]], None, H, None, h1, out_relu=True)
+            pk = torch.empty((NL - 1) * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+            units = [pk.data_ptr() + u * _capi.WPACK_BYTES for u in range(NL - 1)]
+            wpack([(Wk[l + 1].data_ptr(), H, False, units[l]) for l in range(NL - 1)], dev)
+            mlp_fwd(M, H, [(h1, None, H)], Wk[1:], bk[1:], scale, out_w, None, y, None,
+                    saveH[1:] if need else None, U, R, wpk=units)
+        else:
+            mlp_fwd(M, H, [(x, None, kin)], Wk, bk, scale, out_w, None, y, None, saveH, U, R)
         ctx.meta = (NL, H, kin, out_w, has_norm)
         ctx.saved = (x, Wk, scale, saveH, U, R)
         return y

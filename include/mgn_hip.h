@@ -121,6 +121,9 @@ typedef struct {
    * and every stored tensor stay fp32) -- the semantic of the reference under bf16-mixed
    * autocast (train.py:74-78,268-293), BASELINE configs[2]. */
   int precision;
+  /* out = relu(z) instead of z (generic ragged-input kernel only; no norm / residual): lets an
+   * encoder run its narrow first layer stand-alone and the three full layers on the packed path. */
+  int out_relu;
 } mgn_mlp_fwd_args;
 int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream);
 
