@@ -84,12 +84,14 @@ def kernel_rooflines(gp, ops, eng, batch, dev, steps=3):
     ops.mlp_bwd = timed("edge_bwd", orig[1], lambda a, k: a[0] == E and a[1] == H and a[4] is not None)  # dOut2 = dAgg: the processor's edge chain
     ops.wgrad = timed("wgrad", orig[2], lambda a, k: len(a[0]) >= 8)
     ops.segsum = timed("segsum", orig[3], lambda a, k: a[0].shape[0] == E and a[2] is None)
+    sync, eng.grad_sync = eng.grad_sync, None  # rank 0 steps alone here: no collective (the timed region is over)
     try:
         for _ in range(steps):
             eng.train_step(batch)
         torch.cuda.synchronize()
     finally:
         ops.mlp_fwd, ops.mlp_bwd, ops.wgrad, ops.segsum = orig
+        eng.grad_sync = sync
     ms = {t: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None) for t, v in rec.items()}
     n = {t: len(v) // steps for t, v in rec.items()}
     traffic = {}
