@@ -1537,6 +1537,44 @@ __global__ void __launch_bounds__(256) k_segsum(const float* __restrict__ src, c
   st4(out + node * H + 4 * l, s);
 }
 
+// Two segment sums of the SAME source in one launch (the backward scatter of the first-layer
+// gradients onto destination and source nodes): workgroups [0, half) run job 0, the rest job 1.
+template <int HB>
+__global__ void __launch_bounds__(256) k_segsum2(const float* __restrict__ src, const int32_t* __restrict__ rowptr0,
+                                                 const int32_t* __restrict__ perm0, float* __restrict__ out0,
+                                                 const int32_t* __restrict__ rowptr1, const int32_t* __restrict__ perm1,
+                                                 float* __restrict__ out1, long N, unsigned half) {
+  constexpr int H = 16 * HB;
+  constexpr int LPR = H / 4;
+  const bool second = blockIdx.x >= half;
+  const int32_t* rowptr = second ? rowptr1 : rowptr0;
+  const int32_t* perm = second ? perm1 : perm0;
+  float* out = second ? out1 : out0;
+  const long node = ((long)(blockIdx.x - (second ? half : 0)) * 256 + threadIdx.x) / LPR;
+  const int l = threadIdx.x % LPR;
+  if (node >= N) return;
+  const int beg = rowptr[node], end = rowptr[node + 1];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const float* base = src + 4 * l;
+  for (int k = beg; k < end; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = k + u;
+      if (kk < end) {
+        const long row = perm ? (long)perm[kk] : (long)kk;
+        v[u] = ld4(base + row * H);
+      } else {
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k + u < end) s += v[u];
+  }
+  st4(out + node * H + 4 * l, s);
+}
+
 // ================================================================ batched transpose
 struct TBlocks {
   mgn_tblock b[TB_MAX];
@@ -1885,6 +1923,16 @@ int mgn_segsum(const float* src, const int32_t* rowptr, const int32_t* perm, flo
     default: return fail(1, "mgn_segsum: H must be 16, 32, 64 or 128");
   }
   return check_launch("mgn_segsum");
+}
+
+int mgn_segsum2(const float* src, const int32_t* rowptr0, const int32_t* perm0, float* out0, const int32_t* rowptr1,
+                const int32_t* perm1, float* out1, int64_t N, int H, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) return 0;
+  if (H != 128) return fail(1, "mgn_segsum2: H must be 128");
+  const unsigned half = (unsigned)((N * (H / 4) + 255) / 256);
+  hipLaunchKernelGGL(k_segsum2<8>, dim3(2 * half), dim3(256), 0, s, src, rowptr0, perm0, out0, rowptr1, perm1, out1, (long)N, half);
+  return check_launch("mgn_segsum2");
 }
 
 static int check_mlp_common(int H, int NL, int out_w, const char* who) {

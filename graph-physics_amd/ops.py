@@ -151,6 +151,15 @@ def segsum(src: torch.Tensor, rowptr: torch.Tensor, perm: Optional[torch.Tensor]
     return out
 
 
+def segsum2(src: torch.Tensor, rowptr0, perm0, out0, rowptr1, perm1, out1):
+    """two segment sums of the same source rows in one launch (H = 128)"""
+    n = rowptr0.numel() - 1
+    with torch.cuda.device(src.device):
+        rc = _capi.lib().mgn_segsum2(_ptr(src), _ptr(rowptr0), _ptr(perm0), _ptr(out0), _ptr(rowptr1), _ptr(perm1), _ptr(out1),
+                                     n, src.shape[1], _stream(src.device))
+    _capi.check(rc, "mgn_segsum2")
+
+
 # ----------------------------------------------------------------- raw launches
 def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], int]],
             Ws: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]], scale: Optional[torch.Tensor],
@@ -600,8 +609,11 @@ class ProcessorFunction(torch.autograd.Function):
             mlp_bwd(E, H, 4, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
                     [None] * 4, g[8], wpk=ke, Ms=Me, precision=prec)
             # scatter of the first-layer pre-activations' grads onto dst / src nodes
-            segsum(dZe[0], topo.rowptr_dst, None, Sd)
-            segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)
+            if H == 128:
+                segsum2(dZe[0], topo.rowptr_dst, None, Sd, topo.rowptr_src, topo.perm_src, Ss)
+            else:
+                segsum(dZe[0], topo.rowptr_dst, None, Sd)
+                segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)
             # dX = dX' + W0n[:, :H]^T dZn0 + W0e[:, H:2H]^T Sd + W0e[:, 2H:]^T Ss
             dx_new = dx_buf[0] if dx.data_ptr() != dx_buf[0].data_ptr() else dx_buf[1]
             mlp_fwd(N, H, [(dZn[0], None, H), (Sd, None, H), (Ss, None, H)], [Wcat], [None], None, H, dx, dx_new, wpk=kx, precision=prec)

@@ -62,6 +62,11 @@ int mgn_csr_build(const int64_t* key, int64_t E, int64_t N, int32_t* rowptr, int
 int mgn_segsum(const float* src, const int32_t* rowptr, const int32_t* perm, float* out,
                int64_t N, int H, void* stream);
 
+/* Two segment sums of the same source in one launch (H = 128): out0 over (rowptr0, perm0), out1
+ * over (rowptr1, perm1) -- the backward scatter onto destination and source nodes. */
+int mgn_segsum2(const float* src, const int32_t* rowptr0, const int32_t* perm0, float* out0,
+                const int32_t* rowptr1, const int32_t* perm1, float* out1, int64_t N, int H, void* stream);
+
 /* ------------------------------------------------------------ fused MLP forward
  * For each row m in [0,M):
  *   in  = cat_p src[p][ idx[p] ? idx[p][m] : m , 0:kw[p] ]      (p < nphase)
