@@ -13,3 +13,15 @@ for name, calls, tot, avg, pct in db.execute("select name,total_calls,total_dura
     if len(short) > 90:
         short = short[:87] + "..."
     print(f"\"{short}\",{calls},{tot:.1f},{avg:.3f},{pct:.2f}")
+
+# per launch shape (grid size in workgroups) for the engine kernels: the edge-row launches
+# (512 persistent workgroups) and the node-row launches of the same kernel differ 5x in duration
+if len(sys.argv) > 3 and sys.argv[3] == "by-grid":
+    print()
+    print("kernel,workgroups,calls,avg_us,min_us,max_us")
+    q = ("select name, grid_x/workgroup_x, count(*), avg(duration)/1000., min(duration)/1000., max(duration)/1000. "
+         "from kernels where name like '%k_mlp_%' or name like '%k_wgrad%' or name like '%k_segsum%' "
+         "group by name, grid_x/workgroup_x order by 4*count(*) desc")
+    for name, wgs, calls, avg, mn, mx in db.execute(q):
+        short = name.split("(")[0].replace("void ", "")
+        print(f"\"{short}\",{wgs},{calls},{avg:.3f},{mn:.3f},{mx:.3f}")
