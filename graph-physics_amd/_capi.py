@@ -74,9 +74,13 @@ class MlpBwdArgs(C.Structure):
         ("db", _f32p * MAX_LAYERS),
         ("dscale", _f32p),
         ("red_ws", C.c_void_p), ("red_ws_bytes", C.c_size_t),
-        ("wpk", C.c_void_p * 4),
+        ("wpk", C.c_void_p * 8),
         ("Ms", C.c_void_p * MAX_LAYERS),
         ("precision", C.c_int),
+        ("n_front", C.c_int),
+        ("front_src", _f32p * MAX_PHASES),
+        ("front_resid", _f32p),
+        ("front_out", _f32p),
     ]
 
 

@@ -1822,8 +1822,9 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
 
 static bool bwd_x6(const mgn_mlp_bwd_args& a) {
   if (a.wpk[0] == nullptr || getenv("MGN_FP32_MFMA") != nullptr) return false;
-  const int G = a.NL - 1 + a.n_din;
-  if (G > 4 || G < 1) return false;
+  const int G = a.n_front + a.NL - 1 + a.n_din;
+  if (G > 8 || G < 1 || a.n_front < 0 || a.n_front > MGN_MAX_PHASES) return false;
+  if (a.n_front > 0 && a.dOut2 != nullptr) return false;
   for (int u = 0; u < G; ++u)
     if (a.wpk[u] == nullptr) return false;
   for (int l = 1; l < a.NL; ++l)
@@ -1837,14 +1838,27 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
   if (p.lds && bwd_x6(a)) {
     static thread_local bool attr_done = false;
     if (!attr_done) {
-      if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_BWD_LDS_BYTES(LDS_MAX_NL)) != hipSuccess) return 1;
-      if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_BWD_LDS_BYTES(LDS_MAX_NL)) != hipSuccess) return 1;
+      const int lds = X6_BWD_LDS_BYTES(LDS_MAX_NL);
+      if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return 1;
       attr_done = true;
     }
-    if (a.precision == 1)
-      hipLaunchKernelGGL(k_mlp_bwd_x6<1>, dim3(p.grid), dim3(256), X6_BWD_LDS_BYTES(a.NL), s, a);
-    else
-      hipLaunchKernelGGL(k_mlp_bwd_x6<6>, dim3(p.grid), dim3(256), X6_BWD_LDS_BYTES(a.NL), s, a);
+    const size_t lds = X6_BWD_LDS_BYTES(a.NL);
+    const bool front = a.n_front > 0;
+    if (a.precision == 1) {
+      if (front)
+        hipLaunchKernelGGL((k_mlp_bwd_x6<1, true>), dim3(p.grid), dim3(256), lds, s, a);
+      else
+        hipLaunchKernelGGL((k_mlp_bwd_x6<1, false>), dim3(p.grid), dim3(256), lds, s, a);
+    } else {
+      if (front)
+        hipLaunchKernelGGL((k_mlp_bwd_x6<6, true>), dim3(p.grid), dim3(256), lds, s, a);
+      else
+        hipLaunchKernelGGL((k_mlp_bwd_x6<6, false>), dim3(p.grid), dim3(256), lds, s, a);
+    }
     return 0;
   }
   if (p.lds) {
@@ -1986,6 +2000,8 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   if (a.n_din < 0 || a.n_din > MGN_MAX_PHASES) return fail(1, "mgn_mlp_bwd: n_din out of range");
   if (a.n_din > 1 && a.dZ[0] == nullptr) return fail(1, "mgn_mlp_bwd: n_din > 1 needs dZ[0]");
   if (a.precision != 0 && a.precision != 1) return fail(1, "mgn_mlp_bwd: precision must be 0 (fp32-grade) or 1 (bf16)");
+  if (a.n_front != 0 && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
+    return fail(1, "mgn_mlp_bwd: the front stage needs the packed split-bf16 path (H = 128, full widths, wpk, Ms, no dOut2)");
   if (a.precision == 1 && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
     return fail(1, "mgn_mlp_bwd: bf16 matrix mode needs the packed split-bf16 path (H = 128, full widths, wpk, Ms)");
   if (a.M == 0) return 0;

@@ -207,7 +207,9 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
             Hs: Sequence[torch.Tensor], WT: Sequence[Optional[torch.Tensor]], dZ: Sequence[Optional[torch.Tensor]],
             din: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]],
             db: Sequence[Optional[torch.Tensor]], dscale: Optional[torch.Tensor], wpk: Sequence[int] = (),
-            Ms: Optional[Sequence[torch.Tensor]] = None, precision: int = 0):
+            Ms: Optional[Sequence[torch.Tensor]] = None, precision: int = 0, front=None):
+    """``front`` = (rows[<=3] each [M,H], resid[M,H] or None, out[M,H] or None): the fused front
+    stage of the packed kernel, dY = resid + sum_p wpk[p] . rows[p] (then ``dOut`` is ignored)."""
     L = _capi.lib()
     a = _capi.MlpBwdArgs()
     a.M, a.H, a.NL = M, H, NL
@@ -229,6 +231,12 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
         for l, t in enumerate(Ms):
             a.Ms[l] = _ptr(t)
     a.precision = precision
+    if front is not None:
+        rows, fres, fout = front
+        a.n_front = len(rows)
+        for p_, t in enumerate(rows):
+            a.front_src[p_] = _ptr(t)
+        a.front_resid, a.front_out = _ptr(fres), _ptr(fout)
     dev = dOut.device
     nbytes = L.mgn_mlp_bwd_workspace_bytes(M, H, NL)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
@@ -582,18 +590,31 @@ class ProcessorFunction(torch.autograd.Function):
                 tb.append((We0 + 4 * H, 3 * H, cat + 4 * H, 3 * H))                          # (W0e[:, H:2H])^T
                 tb.append((We0 + 8 * H, 3 * H, cat + 8 * H, 3 * H))                          # (W0e[:, 2H:])^T
             transpose_blocks(tb, H, dev)
+        gs = [[torch.empty_like(t) for t in P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]] for i in range(L)]
+        # packed path: the dX launch of round i and the node chain of round i-1 work on the same
+        # rows -> one launch (front stage of mgn_mlp_bwd); dZn double buffered across rounds
+        # (measured neutral at N = 30k rows -- 88 us fused vs 57 + 30 us: a launch costs as many tile
+        # times as it has GEMM units -- so it is opt-in: MGN_FRONT=1; tests/test_hip_parity.py covers it)
+        fuse = x6 and _os.environ.get("MGN_FRONT") is not None
+        dZn_sets = [dZn, [torch.empty(N, H, **f) for _ in range(4)] if fuse and L > 1 else dZn]
+        node_done = False
+
+        def units(i):
+            return [unit(i, u) for u in range(4)], [unit(i, u) for u in range(4, 8)], [unit(i, u) for u in range(8, 11)]
+
         for i in reversed(range(L)):
             q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
             We, se = [q[0], q[2], q[4], q[6]], q[8]
             Wn, sn = [q[9], q[11], q[13], q[15]], q[17]
             x, e, agg, He, Ue, Re, Hn, Un, Rn, Me, Mn = saved[i]
-            g = [torch.empty_like(t) for t in q]
+            g = gs[i]
+            dZn = dZn_sets[i & 1]
             if x6:
                 # never dereferenced on the packed path: any valid [H,H] / [H,3H] tensors do
                 WTn = WTe = [None, q[2], q[2], q[2]]
                 WT0n_agg = WT0e_e = q[2]
                 Wcat = q[0]
-                kn, ke, kx = [unit(i, u) for u in range(4)], [unit(i, u) for u in range(4, 8)], [unit(i, u) for u in range(8, 11)]
+                kn, ke, kx = units(i)
             else:
                 w = wt[i]
                 WTn = [None, w[0], w[1], w[2]]
@@ -601,9 +622,11 @@ class ProcessorFunction(torch.autograd.Function):
                 WT0n_agg, WT0e_e = w[6], w[7]
                 Wcat = w[8:11].reshape(H, 3 * H)
                 kn = ke = kx = ()
-            # node MLP chain: dX' -> dZn[3..0], dAgg = W0n[:,H:]^T dZn0
-            mlp_bwd(N, H, 4, dx, None, None, H, Un, Rn, sn, Hn, WTn, dZn, [(WT0n_agg, None, dAgg)],
-                    [None] * 4, g[17], wpk=kn, Ms=Mn, precision=prec)
+            # node MLP chain: dX' -> dZn[3..0], dAgg = W0n[:,H:]^T dZn0  (already done by the
+            # previous iteration's fused launch except for the last round)
+            if not node_done:
+                mlp_bwd(N, H, 4, dx, None, None, H, Un, Rn, sn, Hn, WTn, dZn, [(WT0n_agg, None, dAgg)],
+                        [None] * 4, g[17], wpk=kn, Ms=Mn, precision=prec)
             # edge MLP chain: dM = dE' + dAgg[dst] -> dZe[3..0], dE = dE' + W0e[:, :H]^T dZe0
             de_new = de_buf[0] if de.data_ptr() != de_buf[0].data_ptr() else de_buf[1]
             mlp_bwd(E, H, 4, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
@@ -614,9 +637,6 @@ class ProcessorFunction(torch.autograd.Function):
             else:
                 segsum(dZe[0], topo.rowptr_dst, None, Sd)
                 segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)
-            # dX = dX' + W0n[:, :H]^T dZn0 + W0e[:, H:2H]^T Sd + W0e[:, 2H:]^T Ss
-            dx_new = dx_buf[0] if dx.data_ptr() != dx_buf[0].data_ptr() else dx_buf[1]
-            mlp_fwd(N, H, [(dZn[0], None, H), (Sd, None, H), (Ss, None, H)], [Wcat], [None], None, H, dx, dx_new, wpk=kx, precision=prec)
             # weight gradients: dW = dZ^T X
             # (A = dZ, B = layer input, dW slab[, db = bias gradient as a by-product])
             jobs = [
@@ -630,6 +650,19 @@ class ProcessorFunction(torch.autograd.Function):
                 jobs.append((dZn[l], H, nb, Hn[l - 1], H, nb, H, g[9 + 2 * l], 0, H, g[10 + 2 * l]))
                 jobs.append((dZe[l], H, nb, He[l - 1], H, nb, H, g[2 * l], 0, H, g[1 + 2 * l]))
             wgrad(jobs, dev, prec)
+            # dX = dX' + W0n[:, :H]^T dZn0 + W0e[:, H:2H]^T Sd + W0e[:, 2H:]^T Ss
+            dx_new = dx_buf[0] if dx.data_ptr() != dx_buf[0].data_ptr() else dx_buf[1]
+            if fuse and i > 0:  # ... fused with the node chain of round i-1 (same rows)
+                qp = P[PARAMS_PER_BLOCK * (i - 1): PARAMS_PER_BLOCK * i]
+                _, _, _, _, _, _, Hn_p, Un_p, Rn_p, _, Mn_p = saved[i - 1]
+                kn_p, _, _ = units(i - 1)
+                mlp_bwd(N, H, 4, dx, None, None, H, Un_p, Rn_p, qp[17], Hn_p, WTn, dZn_sets[(i - 1) & 1],
+                        [(WT0n_agg, None, dAgg)], [None] * 4, gs[i - 1][17], wpk=kx + kn_p, Ms=Mn_p, precision=prec,
+                        front=([dZn[0], Sd, Ss], dx, dx_new))
+                node_done = True
+            else:
+                mlp_fwd(N, H, [(dZn[0], None, H), (Sd, None, H), (Ss, None, H)], [Wcat], [None], None, H, dx, dx_new, wpk=kx, precision=prec)
+                node_done = False
             grads[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)] = g
             dx, de = dx_new, de_new
         ctx.saved_acts = None

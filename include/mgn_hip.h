@@ -162,12 +162,22 @@ typedef struct {
   void* red_ws; size_t red_ws_bytes;
   /* split-bf16 matrix path (H = 128, full widths, n_din <= 1): the launch's GEMM units packed
    * by mgn_wpack(transpose = 1 of the forward weights) in stream order WT[NL-1], ..., WT[1],
-   * then WT0[0] if n_din == 1.  wpk[0] == NULL keeps the exact-fp32 MFMA kernels. */
-  const void* wpk[4];
+   * then WT0[0] if n_din == 1 (preceded by the n_front front units, see below).  wpk[0] == NULL
+   * keeps the exact-fp32 MFMA kernels. */
+  const void* wpk[8];
   /* Ms[l-1] = saveM[l-1] of the forward launch (ReLU masks as bits).  Required by the split-bf16
    * kernel (it does not read Hs); ignored by the fp32 kernels. */
   const uint32_t* Ms[MGN_MAX_LAYERS];
   int precision;                    /* as in mgn_mlp_fwd_args */
+  /* Optional front stage (split-bf16 kernel only; dOut / dOut2 are then ignored):
+   *   dY[m] = (front_resid ? front_resid[m] : 0) + sum_{p < n_front} Wf_p . front_src[p][m]
+   * with Wf_p = wpk[p] (packed, [H,H]); dY is stored to front_out (if not NULL) and feeds the
+   * chain.  It fuses "dX = dX' + Wcat . [dZn0; Sd; Ss]" of round i with the node chain of
+   * round i-1: same rows, one launch, no round trip of dX through HBM before its first use. */
+  int n_front;
+  const float* front_src[MGN_MAX_PHASES];
+  const float* front_resid;
+  float* front_out;
 } mgn_mlp_bwd_args;
 size_t mgn_mlp_bwd_workspace_bytes(int64_t M, int H, int NL);
 int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream);

@@ -551,10 +551,12 @@ torch.save({"out": out.detach().cpu(), **{k: p.grad.cpu() for k, p in net.named_
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = code % (root, os.path.join(root, "tests", "golden"))
     res = {}
-    for tag, env in (("x6", {}), ("fp32", {"MGN_FP32_MFMA": "1"})):
+    for tag, env in (("x6", {}), ("fp32", {"MGN_FP32_MFMA": "1"}), ("front", {"MGN_FRONT": "1"})):
         path = f"/tmp/_mgn_paths_{tag}_{os.getpid()}.pt"
         e = dict(os.environ, **env)
-        e.pop("MGN_FP32_MFMA", None) if not env else None
+        for k_ in ("MGN_FP32_MFMA", "MGN_FRONT"):
+            if k_ not in env:
+                e.pop(k_, None)
         r = subprocess.run([sys.executable, "-c", code, path], env=e, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = torch.load(path)
@@ -562,6 +564,8 @@ torch.save({"out": out.detach().cpu(), **{k: p.grad.cpu() for k, p in net.named_
     for k in res["x6"]:
         # gradients: the suite's 1e-4-per-round criterion (a pre-activation within rounding of 0 flips its ReLU mask)
         assert rel_err(res["x6"][k], res["fp32"][k]) < (2e-6 if k == "out" else 3e-4), k
+        # the fused "dX of round i + node chain of round i-1" launch (MGN_FRONT=1) is the same arithmetic
+        assert rel_err(res["front"][k], res["x6"][k]) < (1e-7 if k == "out" else 2e-5), k
 
 
 def test_rollout_graphed_equals_eager(dev):

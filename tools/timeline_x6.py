@@ -23,6 +23,7 @@ try:
     Pd, Ps = x @ W0[:, H:2 * H].t(), x @ W0[:, 2 * H:].t()
     m, e_new = torch.empty(E, H, **f), torch.empty(E, H, **f)
     save = len(sys.argv) > 1 and sys.argv[1] == "save"
+    node = len(sys.argv) > 1 and sys.argv[1] == "node"
     He = [torch.empty(E, H, **f) for _ in range(3)] if save else None
     Ue, Re = (torch.empty(E, H, **f), torch.empty(E, **f)) if save else (None, None)
     pk = torch.empty(4 * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
@@ -31,9 +32,24 @@ try:
     L = _capi.lib()
     L.mgn_debug_timeline.restype = C.c_int
     buf = (C.c_ulonglong * (8 * 512))(); pos = (C.c_int * 8)()
+    if node:  # node update shape: N rows, phases (x, agg), 4 layers, two post-products
+        pkn = torch.empty(7 * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+        un = [pkn.data_ptr() + u * _capi.WPACK_BYTES for u in range(7)]
+        Wn0 = torch.randn(H, 2 * H, **f) * 0.05
+        ops.wpack([(Wn0.data_ptr(), 2 * H, False, un[0]), (Wn0.data_ptr() + 4 * H, 2 * H, False, un[1])] +
+                  [(Wh[l].data_ptr(), H, False, un[2 + l]) for l in range(3)] +
+                  [(W0.data_ptr() + 4 * H, 3 * H, False, un[5]), (W0.data_ptr() + 8 * H, 3 * H, False, un[6])], dev)
+        agg, x_new = torch.randn(N, H, **f), torch.empty(N, H, **f)
+        Hn = [torch.empty(N, H, **f) for _ in range(3)]
+        Un, Rn = torch.empty(N, H, **f), torch.empty(N, **f)
+        Pdn, Psn = torch.empty(N, H, **f), torch.empty(N, H, **f)
     for it in range(3):
-        ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
-                    adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units)
+        if node:
+            ops.mlp_fwd(N, H, [(x, None, H), (agg, None, H)], [Wn0] + Wh, bs, sc, H, x, x_new, None, Hn, Un, Rn,
+                        posts=[(W0.data_ptr() + 4 * H, Pdn), (W0.data_ptr() + 8 * H, Psn)], post_ldw=3 * H, wpk=un)
+        else:
+            ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
+                        adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units)
         torch.cuda.synchronize()
         L.mgn_debug_timeline(buf, pos)
     names = {1: "T", 3: "pre", 4: "bar", 5: "gemm", 6: "drain", 7: "epi", 8: "end"}
