@@ -52,6 +52,7 @@ class MlpFwdArgs(C.Structure):
         ("saveM", C.c_void_p * MAX_LAYERS),
         ("precision", C.c_int),
         ("out_relu", C.c_int),
+        ("seg_key", C.c_void_p), ("seg_rowptr", C.c_void_p), ("seg_out", _f32p), ("seg_part", _f32p),
     ]
 
 
@@ -126,6 +127,7 @@ SYMBOLS = {
     "mgn_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "mgn_csr_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_segsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "mgn_seg_fix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mgn_segsum2": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_void_p]),
     "mgn_mlp_fwd": (C.c_int, [C.POINTER(MlpFwdArgs), C.c_void_p]),
     "mgn_mlp_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),

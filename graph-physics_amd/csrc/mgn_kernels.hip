@@ -1575,6 +1575,26 @@ __global__ void __launch_bounds__(256) k_segsum2(const float* __restrict__ src, 
   st4(out + node * H + 4 * l, s);
 }
 
+// Completes the segment sum fused into the split-bf16 edge kernel: segments cut by a 16-row
+// wave-tile boundary are assembled from the per-tile partials in tile order; empty segments
+// (nodes without incoming edges) are zeroed; segments inside one tile were written by the kernel.
+__global__ void __launch_bounds__(256) k_seg_fix(const int32_t* __restrict__ rowptr, const float* __restrict__ part,
+                                                 float* __restrict__ out, long N) {
+  constexpr int H = 128, LPR = 32;
+  const long node = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const int l = threadIdx.x % LPR;
+  if (node >= N) return;
+  const int b = rowptr[node], e = rowptr[node + 1];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (b < e) {
+    const int t0 = b >> 4, t1 = (e - 1) >> 4;
+    if (t0 == t1) return;
+    s = ld4(part + ((size_t)t0 * 2 + 1) * H + 4 * l);
+    for (int t = t0 + 1; t <= t1; ++t) s += ld4(part + ((size_t)t * 2) * H + 4 * l);
+  }
+  st4(out + node * H + 4 * l, s);
+}
+
 // ================================================================ batched transpose
 struct TBlocks {
   mgn_tblock b[TB_MAX];
@@ -1758,6 +1778,7 @@ static bool fwd_x6(const mgn_mlp_fwd_args& a) {
   if (G > X6_MAX_UNITS || a.NL > LDS_MAX_NL) return false;
   // register sharing inside the kernel: gathered adds ride in the next-phase buffer
   if (a.n_add > 0 && (a.nphase != 1 || (a.NL == 1 && a.resid != nullptr))) return false;
+  if (a.seg_out != nullptr && (a.seg_key == nullptr || a.seg_rowptr == nullptr || a.seg_part == nullptr || a.n_post > 0)) return false;
   for (int u = 0; u < G; ++u)
     if (a.wpk[u] == nullptr) return false;
   return true;
@@ -1771,6 +1792,7 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
     // 8-wave workgroups (one per CU) when every CU still gets a tile; MGN_NW=4/8 overrides
     int nw = (a.M >= 128 * 256) ? X6_FWD_NW_LARGE : 4;
     if (const char* e = getenv("MGN_NW")) nw = (atoi(e) == 8) ? 8 : 4;
+    if (a.seg_out != nullptr) nw = 4;  // the partials are indexed by 4-wave tiles
     static thread_local bool attr_done = false;
     if (!attr_done) {
       if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<6, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(4)) != hipSuccess) return 1;
@@ -1939,6 +1961,12 @@ int mgn_segsum(const float* src, const int32_t* rowptr, const int32_t* perm, flo
   return check_launch("mgn_segsum");
 }
 
+int mgn_seg_fix(const int32_t* rowptr, const float* part, float* out, int64_t N, void* stream) {
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_seg_fix, dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rowptr, part, out, (long)N);
+  return check_launch("mgn_seg_fix");
+}
+
 int mgn_segsum2(const float* src, const int32_t* rowptr0, const int32_t* perm0, float* out0, const int32_t* rowptr1,
                 const int32_t* perm1, float* out1, int64_t N, int H, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -1962,6 +1990,8 @@ int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream) {
   const mgn_mlp_fwd_args& a = *args;
   if (int rc = check_mlp_common(a.H, a.NL, a.out_w, "mgn_mlp_fwd")) return rc;
   if (a.precision != 0 && a.precision != 1) return fail(1, "mgn_mlp_fwd: precision must be 0 (fp32-grade) or 1 (bf16)");
+  if (a.seg_out != nullptr && !(plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && fwd_x6(a)))
+    return fail(1, "mgn_mlp_fwd: the fused segment sum needs the packed split-bf16 path (and seg_key / seg_rowptr / seg_part, no post-products)");
   if (a.out_relu && (a.scale != nullptr || a.resid != nullptr || a.y_out != nullptr || a.wpk[0] != nullptr ||
                      plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds))
     return fail(1, "mgn_mlp_fwd: out_relu is for a plain ragged-input launch (no norm / residual / packed path)");

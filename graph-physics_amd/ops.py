@@ -151,6 +151,13 @@ def segsum(src: torch.Tensor, rowptr: torch.Tensor, perm: Optional[torch.Tensor]
     return out
 
 
+def seg_fix(rowptr: torch.Tensor, part: torch.Tensor, out: torch.Tensor):
+    """second stage of the segment sum fused into ``mlp_fwd(seg=...)``"""
+    with torch.cuda.device(out.device):
+        rc = _capi.lib().mgn_seg_fix(_ptr(rowptr), _ptr(part), _ptr(out), rowptr.numel() - 1, _stream(out.device))
+    _capi.check(rc, "mgn_seg_fix")
+
+
 def segsum2(src: torch.Tensor, rowptr0, perm0, out0, rowptr1, perm1, out1):
     """two segment sums of the same source rows in one launch (H = 128)"""
     n = rowptr0.numel() - 1
@@ -168,8 +175,11 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
             saveR: Optional[torch.Tensor] = None, ldw0: int = 0,
             adds: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]] = (),
             posts: Sequence[Tuple[int, torch.Tensor]] = (), post_ldw: int = 0, wpk: Sequence[int] = (),
-            saveM: Optional[Sequence[torch.Tensor]] = None, precision: int = 0, out_relu: bool = False):
-    """``adds``: (rows[*,H], idx or None) gathered into the layer-0 pre-activation;
+            saveM: Optional[Sequence[torch.Tensor]] = None, precision: int = 0, out_relu: bool = False,
+            seg=None):
+    """``seg`` = (key[M] int32 sorted, rowptr[n+1] int32, out[n,H], part[ceil(M/16),2,H]): fused
+    segment sum of y (finish with :func:`seg_fix`).
+    ``adds``: (rows[*,H], idx or None) gathered into the layer-0 pre-activation;
     ``posts``: (device address of a [H,H] weight block with leading dim ``post_ldw``, out[M,H]);
     ``wpk``: device addresses of the launch's GEMM units packed by :func:`wpack` (phases of
     layer 0, layers 1.., post-products) -- selects the split-bf16 kernels."""
@@ -197,6 +207,8 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
             a.saveM[l] = _ptr(t)
     a.precision = precision
     a.out_relu = int(out_relu)
+    if seg is not None:
+        a.seg_key, a.seg_rowptr, a.seg_out, a.seg_part = (_ptr(t) for t in seg)
     dev = out.device
     with torch.cuda.device(dev):
         rc = _capi.lib().mgn_mlp_fwd(C.byref(a), _stream(dev))
@@ -449,8 +461,10 @@ class ProcessorFunction(torch.autograd.Function):
         P = [_f32c(p) for p in params]
         need = any(ctx.needs_input_grad) and _saving()
         f = dict(dtype=torch.float32, device=dev)
-        m = torch.empty(E, H, **f)
         saved = []
+        fuse_agg = (H == 128) and X6_ENABLED and E > 0 and _os.environ.get("MGN_NO_FUSED_AGG") is None
+        m = None if fuse_agg else torch.empty(E, H, **f)
+        part = torch.empty((E + 15) // 16, 2, H, **f) if fuse_agg else None
         # H = 128: algebraic split of the first edge layer (W0 = [W_e | W_d | W_s]):
         #   W0.[e, x_dst, x_src] = W_e.e + (x W_d^T)[dst] + (x W_s^T)[src]
         # the two node-level projections of round i+1 are post-products of round i's node
@@ -511,11 +525,15 @@ class ProcessorFunction(torch.autograd.Function):
             if split and E > 0:
                 mlp_fwd(E, H, [(e, None, H)], We, be, se, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
                         adds=[(Pd, topo.dst_s), (Ps, topo.src_s)],
-                        wpk=[unit(i, u) for u in range(4)] if x6 else (), saveM=Me, precision=prec)
+                        wpk=[unit(i, u) for u in range(4)] if x6 else (), saveM=Me, precision=prec,
+                        seg=(topo.dst_s, topo.rowptr_dst, agg, part) if (fuse_agg and x6) else None)
             else:
                 mlp_fwd(E, H, [(e, None, H), (x, topo.dst_s, H), (x, topo.src_s, H)], We, be, se, H, e, e_new, m, He, Ue, Re)
             # R4: agg = segment-sum of m over dst                          (layers.py:1031-1037)
-            segsum(m, topo.rowptr_dst, None, agg)
+            if fuse_agg and x6 and split:
+                seg_fix(topo.rowptr_dst, part, agg)   # the edge kernel summed inside its wave tiles
+            else:
+                segsum(m, topo.rowptr_dst, None, agg)
             # R5: x' = x + node_block(cat[x, agg])                         (layers.py:1100-1101,1040)
             posts, Pd_n, Ps_n = (), None, None
             if split and E > 0 and i + 1 < L:

@@ -62,6 +62,9 @@ int mgn_csr_build(const int64_t* key, int64_t E, int64_t N, int32_t* rowptr, int
 int mgn_segsum(const float* src, const int32_t* rowptr, const int32_t* perm, float* out,
                int64_t N, int H, void* stream);
 
+/* Second stage of the segment sum fused into mgn_mlp_fwd (seg_out / seg_part): N keys. */
+int mgn_seg_fix(const int32_t* rowptr, const float* part, float* out, int64_t N, void* stream);
+
 /* Two segment sums of the same source in one launch (H = 128): out0 over (rowptr0, perm0), out1
  * over (rowptr1, perm1) -- the backward scatter onto destination and source nodes. */
 int mgn_segsum2(const float* src, const int32_t* rowptr0, const int32_t* perm0, float* out0,
@@ -129,6 +132,17 @@ typedef struct {
   /* out = relu(z) instead of z (generic ragged-input kernel only; no norm / residual): lets an
    * encoder run its narrow first layer stand-alone and the three full layers on the packed path. */
   int out_relu;
+  /* Fused segment sum (split-bf16 kernel, no post-products): rows are sorted by seg_key[m] (the
+   * CSR order), seg_rowptr[k] .. seg_rowptr[k+1] is the row range of key k.  The kernel adds up
+   * y (before the residual) over each run of equal keys inside a 16-row wave tile; finished
+   * segments go to seg_out[k,:], runs cut by a tile boundary to seg_part[tile][0|1][H]
+   * (ceil(M/16) tiles) and mgn_seg_fix assembles those and zeroes the empty segments.  With it
+   * the messages need not be written at all (y_out = NULL).  Fixed summation order (a 16-lane
+   * scan, then tile order): deterministic, but not the sequential k-order of mgn_segsum. */
+  const int32_t* seg_key;
+  const int32_t* seg_rowptr;
+  float* seg_out;
+  float* seg_part;
 } mgn_mlp_fwd_args;
 int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream);
 

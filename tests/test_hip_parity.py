@@ -708,3 +708,52 @@ def test_inference_forward_saves_nothing(dev):
     finally:
         ops.mlp_fwd = orig
     assert torch.equal(out0, out1.detach())
+
+
+def test_fused_segment_sum_in_edge_kernel(dev):
+    """The aggregation fused into the split-bf16 edge kernel (segmented scan inside the 16-row wave
+    tiles + mgn_seg_fix across tile boundaries) against the stand-alone k-ordered segment sum of the
+    same messages: Delaunay graphs, and a multigraph with an isolated node, self loops, duplicate
+    edges and hub nodes whose segments span several wave tiles and workgroup tiles."""
+    from graph_physics_amd import _capi
+
+    H = 128
+    f = dict(dtype=torch.float32, device=dev)
+    graphs = [R.delaunay_graph(24, 11)[1], R.delaunay_graph(3000, 7)[1]]
+    rng = np.random.default_rng(12)
+    N = 700
+    dst = np.concatenate([rng.integers(0, N - 1, 4000), np.full(45, 3), np.full(200, 500), np.full(17, 650)])  # node N-1 isolated
+    src = rng.integers(0, N, dst.size)
+    src[:50] = dst[:50]  # self loops
+    graphs.append(torch.from_numpy(np.stack([np.concatenate([src, src[:300]]), np.concatenate([dst, dst[:300]])])))
+    for gi, ei in enumerate(graphs):
+        n = int(ei.max()) + 1 if gi < 2 else N
+        topo = ops.Topology(ei.to(dev), n)
+        E = topo.E
+        torch.manual_seed(gi)
+        x, e = torch.randn(n, H, **f), torch.randn(E, H, **f)
+        W0 = torch.randn(H, 3 * H, **f) * 0.05
+        Wh = [torch.randn(H, H, **f) * 0.09 for _ in range(3)]
+        bs = [torch.randn(H, **f) * 0.1 for _ in range(4)]
+        sc = torch.rand(H, **f) + 0.5
+        Pd, Ps = x @ W0[:, H:2 * H].t(), x @ W0[:, 2 * H:].t()
+        pk = torch.empty(4 * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+        units = [pk.data_ptr() + u * _capi.WPACK_BYTES for u in range(4)]
+        ops.wpack([(W0.data_ptr(), 3 * H, False, units[0])] + [(Wh[l].data_ptr(), H, False, units[l + 1]) for l in range(3)], dev)
+        m, e_new = torch.empty(E, H, **f), torch.empty(E, H, **f)
+        agg = torch.full((n, H), float("nan"), **f)
+        part = torch.full(((E + 15) // 16, 2, H), float("nan"), **f)
+        ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, m, ldw0=3 * H, adds=[(Pd, topo.dst_s), (Ps, topo.src_s)],
+                    wpk=units, seg=(topo.dst_s, topo.rowptr_dst, agg, part))
+        ops.seg_fix(topo.rowptr_dst, part, agg)
+        ref = ops.segsum(m, topo.rowptr_dst, None)
+        assert not torch.isnan(agg).any()
+        assert rel_err(agg, ref) < 1e-6, gi
+        if gi == 2:
+            assert torch.equal(agg[N - 1], torch.zeros(H, device=dev))  # isolated node
+        # run-to-run bit determinism (fixed summation order, no atomics)
+        agg2 = torch.empty_like(agg)
+        ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, None, ldw0=3 * H, adds=[(Pd, topo.dst_s), (Ps, topo.src_s)],
+                    wpk=units, seg=(topo.dst_s, topo.rowptr_dst, agg2, part))
+        ops.seg_fix(topo.rowptr_dst, part, agg2)
+        assert torch.equal(agg, agg2)
