@@ -66,7 +66,7 @@ def kernel_rooflines(gp, ops, eng, batch, dev, steps=3):
     topo = batch.mgn_topology
     N, E, H = topo.N, topo.E, eng.model.hidden_size
     rec = {"edge_fwd": [], "edge_bwd": [], "wgrad": [], "segsum": []}
-    orig = (ops.mlp_fwd, ops.mlp_bwd, ops.wgrad, ops.segsum)
+    orig = (ops.mlp_fwd, ops.mlp_bwd, ops.wgrad, ops.segsum2)
 
     def timed(tag, fn, pred):
         def w(*a, **k):
@@ -83,14 +83,14 @@ def kernel_rooflines(gp, ops, eng, batch, dev, steps=3):
     ops.mlp_fwd = timed("edge_fwd", orig[0], lambda a, k: a[0] == E and a[1] == H and k.get("adds") and (len(a) > 10 and a[10] is not None))
     ops.mlp_bwd = timed("edge_bwd", orig[1], lambda a, k: a[0] == E and a[1] == H and a[4] is not None)  # dOut2 = dAgg: the processor's edge chain
     ops.wgrad = timed("wgrad", orig[2], lambda a, k: len(a[0]) >= 8)
-    ops.segsum = timed("segsum", orig[3], lambda a, k: a[0].shape[0] == E and a[2] is None)
+    ops.segsum2 = timed("segsum", orig[3], lambda a, k: a[0].shape[0] == E)
     sync, eng.grad_sync = eng.grad_sync, None  # rank 0 steps alone here: no collective (the timed region is over)
     try:
         for _ in range(steps):
             eng.train_step(batch)
         torch.cuda.synchronize()
     finally:
-        ops.mlp_fwd, ops.mlp_bwd, ops.wgrad, ops.segsum = orig
+        ops.mlp_fwd, ops.mlp_bwd, ops.wgrad, ops.segsum2 = orig
         eng.grad_sync = sync
     ms = {t: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None) for t, v in rec.items()}
     n = {t: len(v) // steps for t, v in rec.items()}
@@ -121,13 +121,13 @@ def kernel_rooflines(gp, ops, eng, batch, dev, steps=3):
 
     # algorithmic bytes: fp32 rows of H floats; masks 3 x 16 B, rms 4 B per row
     row = 4.0 * H
-    b_fwd = row * (7 * E + 2 * N) + 52.0 * E + 8.0 * E   # e, e', m, H1-3, U | Pd, Ps | rms + masks | dst/src idx
+    b_fwd = row * (6 * E + 3 * N) + 52.0 * E + 8.0 * E   # e, e', H1-3, U | Pd, Ps, agg | rms + masks | dst/src idx
     b_bwd = row * (7 * E + N) + 52.0 * E + 4.0 * E       # dE', U, dZ0-3 (w), dE (w) | dAgg | rms + masks | dst idx
     b_wg = row * (8 * E + 12 * N)                        # 4 edge jobs (dZ, X) + 6 node jobs, 1 launch per round
-    b_seg = row * (E + N) + 4.0 * (N + 1)
+    b_seg = 2 * row * (E + N) + 4.0 * E + 8.0 * (N + 1)  # two sums of dZ0: read E rows twice, write 2N rows, perm, 2 rowptr
     t = "x6" if x6 else "lds<1>"
     nterm = 1 if ops.get_matrix_precision() == "bf16" else 6
-    roof = hbm(f"k_mlp_fwd_{t} (edge update, training mode: W_e.e + gathered node projections, 3 Linear, RMSNorm, residual, saves)",
+    roof = hbm(f"k_mlp_fwd_{t} (edge update, training mode: W_e.e + gathered node projections, 3 Linear, RMSNorm, residual, saves, fused aggregation)",
                ms["edge_fwd"], b_fwd, "edge_fwd_bytes", mfma(ms["edge_fwd"], nterm if x6 else 1))
     roof["launches_per_step"] = n["edge_fwd"]
     others = [
@@ -136,7 +136,8 @@ def kernel_rooflines(gp, ops, eng, batch, dev, steps=3):
         hbm(f"k_wgrad_{'x6' if x6 else 'lds'} + k_wgrad_red (weight gradients of one round: 4 edge + 6..7 node jobs)", ms["wgrad"], b_wg,
             "wgrad_bytes", {"launches_per_step": n["wgrad"]}),
     ]
-    roof_seg = hbm("k_segsum<8> (CSR segment-sum of edge messages)", ms["segsum"], b_seg, "segsum_bytes",
+    roof_seg = hbm("k_segsum2<8> (CSR segment sums = the scatter-add of the backward pass onto destination and source nodes; "
+                   "the forward aggregation is fused into the edge kernel's epilogue)", ms["segsum"], b_seg, "segsum_bytes",
                    {"launches_per_step": n["segsum"]})
     return roof, roof_seg, others
 

@@ -8,7 +8,7 @@ from collections import defaultdict
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fd, wd, tag = sys.argv[1:4]
 KEYS = {("k_mlp_fwd_x6", 512): "edge_fwd", ("k_mlp_bwd_x6", 512): "edge_bwd", ("k_wgrad_x6", 512): "wgrad",
-        ("k_segsum<8>", None): "segsum", ("__amd_rocclr_copyBuffer", None): "calibration_copy"}
+        ("k_segsum2<8>", None): "segsum", ("__amd_rocclr_copyBuffer", None): "calibration_copy"}
 def collect(d, counter):
     acc = defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -21,8 +21,6 @@ def collect(d, counter):
                 if name.startswith(k) and (g is None or wgs == g):
                     if key == "calibration_copy" and float(r["Counter_Value"]) < 400000:
                         continue  # small copies are not the calibration
-                    if key == "segsum" and wgs < 3000:
-                        continue
                     acc[key].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 F, W = collect(fd, "FETCH_SIZE"), collect(wd, "WRITE_SIZE")
