@@ -25,8 +25,11 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MGN_DIST_BACKEND=gloo: rehearsal of the multi-process path on a box with fewer GPUs than ranks
+            backend = os.environ.get("MGN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if os.environ.get("MGN_SHARE_GPU") and torch.cuda.is_available():
+        local = local % torch.cuda.device_count()  # rehearsal only: several ranks on one device (not with RCCL)
     return rank, world, local
 
 
