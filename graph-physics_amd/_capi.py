@@ -140,6 +140,9 @@ SYMBOLS = {
     "mgn_faces_to_edges_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "mgn_faces_to_edges": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_world_edges_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "mgn_add_world_edges": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_edge_features": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mgn_sim_workspace_bytes": (C.c_size_t, []),
     "mgn_sim_pre": (C.c_int, [C.POINTER(SimDesc), C.c_void_p, C.c_size_t, C.c_void_p]),

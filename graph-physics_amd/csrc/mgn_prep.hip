@@ -122,6 +122,134 @@ extern "C" int mgn_faces_to_edges(const int64_t* face, int K, int64_t F, int64_t
   return 0;
 }
 
+// ======================================================================= world edges
+// add_world_edges of the reference (dataset/preprocessing.py:92-140): all node pairs whose WORLD
+// positions are within `radius` (scipy cKDTree.query_pairs: Euclidean distance <= r, evaluated in
+// double on the float32 coordinates) with one end OBSTACLE and the other NORMAL, added to the mesh
+// edges in both directions and coalesced.  The candidate set is (#OBSTACLE x #NORMAL), a few 1e5
+// pairs on the plate meshes, so this is a tiled all-pairs kernel: NORMAL nodes stream through LDS,
+// every thread owns one node i and tests it against the tile when it is an OBSTACLE.  Matches are
+// appended through one atomic counter (order irrelevant: the keys are sorted afterwards).
+#define WE_TILE 256
+template <int D>
+__global__ void __launch_bounds__(WE_TILE) k_world_pairs(const float* __restrict__ x, int x_w, int pos0, int type_idx, long N, double r2,
+                                                        uint64_t* __restrict__ keys, unsigned long long* __restrict__ count, unsigned long long cap) {
+  __shared__ double tp[WE_TILE][D];
+  __shared__ int tt[WE_TILE];
+  const long i = (long)blockIdx.x * WE_TILE + threadIdx.x;
+  double pi[D];
+  int ti = -1;
+  if (i < N) {
+    ti = (int)(long)x[i * x_w + type_idx];
+#pragma unroll
+    for (int d = 0; d < D; ++d) pi[d] = (double)x[i * x_w + pos0 + d];
+  }
+  for (long j0 = 0; j0 < N; j0 += WE_TILE) {
+    const long j = j0 + threadIdx.x;
+    __syncthreads();
+    tt[threadIdx.x] = (j < N) ? (int)(long)x[j * x_w + type_idx] : -1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) tp[threadIdx.x][d] = (j < N) ? (double)x[j * x_w + pos0 + d] : 0.0;
+    __syncthreads();
+    if (ti == MGN_NODE_OBSTACLE) {
+      for (int k = 0; k < WE_TILE; ++k) {
+        if (tt[k] != MGN_NODE_NORMAL) continue;
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const double df = pi[d] - tp[k][d];
+          s += df * df;
+        }
+        if (s <= r2) {
+          const unsigned long long at = atomicAdd(count, 2ull);
+          if (at + 1 < cap) {
+            const uint64_t jj = (uint64_t)(j0 + k);
+            keys[at] = (uint64_t)i * (uint64_t)N + jj;
+            keys[at + 1] = jj * (uint64_t)N + (uint64_t)i;
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void k_edge_keys(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, long E, long N, uint64_t* __restrict__ keys, int* __restrict__ err) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t a = src[e], b = dst[e];
+  if (a < 0 || a >= N || b < 0 || b >= N) {
+    *err = 1;
+    keys[e] = keys[E + e] = ~0ull;
+    return;
+  }
+  keys[e] = (uint64_t)a * (uint64_t)N + (uint64_t)b;      // to_undirected: both directions
+  keys[E + e] = (uint64_t)b * (uint64_t)N + (uint64_t)a;
+}
+
+// ws layout: [keys cap][sorted cap][uniq cap][count, err][rocPRIM temp]
+struct WEPlan {
+  size_t keys, sorted, uniq, count, tmp, tmp_bytes, total;
+};
+static WEPlan we_plan(size_t cap) {
+  WEPlan p;
+  size_t t1 = 0, t2 = 0;
+  rocprim::radix_sort_keys(nullptr, t1, (uint64_t*)nullptr, (uint64_t*)nullptr, cap, 0, 64, (hipStream_t)0);
+  rocprim::unique(nullptr, t2, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t*)nullptr, cap, rocprim::equal_to<uint64_t>(), (hipStream_t)0);
+  p.tmp_bytes = (t1 > t2 ? t1 : t2) + 256;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  p.keys = 0;
+  p.sorted = al(cap * 8);
+  p.uniq = al(p.sorted + cap * 8);
+  p.count = al(p.uniq + cap * 8);
+  p.tmp = al(p.count + 256);
+  p.total = p.tmp + p.tmp_bytes;
+  return p;
+}
+
+extern "C" size_t mgn_world_edges_workspace_bytes(int64_t E, int64_t max_world_pairs) {
+  if (E < 0 || max_world_pairs < 0) return 0;
+  return we_plan(2 * (size_t)E + 2 * (size_t)max_world_pairs + 1).total + 256;
+}
+
+extern "C" int mgn_add_world_edges(const float* x, int x_w, int pos_start, int D, int type_idx, int64_t N, double radius,
+                                   const int64_t* src_in, const int64_t* dst_in, int64_t E, int64_t max_world_pairs,
+                                   int64_t* src, int64_t* dst, int64_t* n_edges, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (D != 2 && D != 3) return pfail(1, "mgn_add_world_edges: world positions must be 2-D or 3-D");
+  if (N < 1 || N > 3037000499LL || E < 0 || max_world_pairs < 0) return pfail(1, "mgn_add_world_edges: size out of range");
+  const size_t cap = 2 * (size_t)E + 2 * (size_t)max_world_pairs + 1;
+  const WEPlan p = we_plan(cap);
+  const size_t base = ((size_t)ws + 255) & ~(size_t)255;
+  if (ws_bytes < (base - (size_t)ws) + p.total) return pfail(1, "mgn_add_world_edges: workspace too small");
+  char* w = (char*)base;
+  uint64_t *keys = (uint64_t*)(w + p.keys), *sorted = (uint64_t*)(w + p.sorted), *uniq = (uint64_t*)(w + p.uniq);
+  unsigned long long* count = (unsigned long long*)(w + p.count);  // [0] world keys appended, [1] unique count (size_t), [2] err
+  size_t* n_uniq = (size_t*)(count + 1);
+  int* err = (int*)(count + 2);
+  if (hipMemsetAsync(count, 0, 64, s) != hipSuccess) return pfail(2, "mgn_add_world_edges: memset");
+  if (hipMemsetAsync(keys, 0xff, cap * 8, s) != hipSuccess) return pfail(2, "mgn_add_world_edges: memset");  // unused slots sort last
+  if (E > 0) hipLaunchKernelGGL(k_edge_keys, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, src_in, dst_in, (long)E, (long)N, keys, err);
+  const unsigned grid = (unsigned)((N + WE_TILE - 1) / WE_TILE);
+  const unsigned long long wcap = 2ull * (unsigned long long)max_world_pairs;
+  if (D == 2)
+    hipLaunchKernelGGL(k_world_pairs<2>, dim3(grid), dim3(WE_TILE), 0, s, x, x_w, pos_start, type_idx, (long)N, radius * radius, keys + 2 * E, count, wcap);
+  else
+    hipLaunchKernelGGL(k_world_pairs<3>, dim3(grid), dim3(WE_TILE), 0, s, x, x_w, pos_start, type_idx, (long)N, radius * radius, keys + 2 * E, count, wcap);
+  size_t tb = p.tmp_bytes;
+  if (rocprim::radix_sort_keys(w + p.tmp, tb, keys, sorted, cap, 0, 64, s) != hipSuccess) return pfail(2, "mgn_add_world_edges: sort");
+  tb = p.tmp_bytes;
+  if (rocprim::unique(w + p.tmp, tb, sorted, uniq, n_uniq, cap, rocprim::equal_to<uint64_t>(), s) != hipSuccess)
+    return pfail(2, "mgn_add_world_edges: unique");
+  hipLaunchKernelGGL(k_decode_keys, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, uniq, n_uniq, (long)N, (long)cap, src, dst, n_edges);
+  if (int rc = pcheck("mgn_add_world_edges")) return rc;
+  unsigned long long h[3] = {0, 0, 0};
+  if (hipMemcpyAsync(h, count, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess) return pfail(2, "mgn_add_world_edges: memcpy");
+  if (hipStreamSynchronize(s) != hipSuccess) return pfail(2, "mgn_add_world_edges: sync failed");
+  if (*(int*)&h[2]) return pfail(3, "mgn_add_world_edges: edge index outside [0, N)");
+  if (h[0] > wcap) return pfail(4, "mgn_add_world_edges: more world pairs than max_world_pairs");
+  return 0;
+}
+
 // ==================================================================== edge features
 // T.Cartesian(norm=False) then T.Distance(norm=False) (preprocessing.py:16-23):
 //   edge_attr[e] = [ pos[src] - pos[dst] (D values), || pos[dst] - pos[src] ||_2 ]

@@ -252,6 +252,19 @@ size_t mgn_faces_to_edges_workspace_bytes(int64_t F, int K);
 int mgn_faces_to_edges(const int64_t* face, int K, int64_t F, int64_t N, int64_t* src, int64_t* dst,
                        int64_t* n_edges, void* ws, size_t ws_bytes, void* stream);
 
+/* --------------------------------------------------------------- world edges (N2)
+ * add_world_edges (preprocessing.py:92-140): node pairs whose world positions
+ * x[:, pos_start:pos_start+D] are within `radius` (<=, evaluated in double like scipy's
+ * cKDTree.query_pairs) with one end OBSTACLE and the other NORMAL, in both directions, merged
+ * with the given edges -- taken in both directions, as to_undirected does -- and coalesced (sorted
+ * by (src,dst), unique).  src / dst have capacity 2*E + 2*max_world_pairs + 1; returns 4 if more pairs than max_world_pairs match, 3 on an edge index
+ * outside [0,N).  Synchronises `stream`. */
+#define MGN_NODE_OBSTACLE 1
+size_t mgn_world_edges_workspace_bytes(int64_t E, int64_t max_world_pairs);
+int mgn_add_world_edges(const float* x, int x_w, int pos_start, int D, int type_idx, int64_t N, double radius,
+                        const int64_t* src_in, const int64_t* dst_in, int64_t E, int64_t max_world_pairs,
+                        int64_t* src, int64_t* dst, int64_t* n_edges, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------- edge features (N2)
  * T.Cartesian(norm=False) + T.Distance(norm=False) (preprocessing.py:16-23):
  * edge_attr[e] = [pos[src]-pos[dst] (D values), ||pos[dst]-pos[src]||_2],  D = 2 or 3. */

@@ -327,3 +327,26 @@ def edge_features_oracle(pos: torch.Tensor, edge_index: torch.Tensor) -> torch.T
     cart = pos[row] - pos[col]
     dist = torch.norm(pos[col] - pos[row], p=2, dim=-1).view(-1, 1)
     return torch.cat([cart, dist], dim=-1)
+
+
+def add_world_edges_oracle(x, edge_index, world_pos_index_start: int, world_pos_index_end: int, node_type_index: int,
+                           radius: float = 0.03):
+    """add_world_edges, graphphysics/dataset/preprocessing.py:92-140: cKDTree.query_pairs(radius)
+    on the world positions (all i<j with Euclidean distance <= radius, double arithmetic on the
+    float32 coordinates), kept when one end is OBSTACLE (1) and the other NORMAL (0), concatenated
+    with the mesh edges and passed through to_undirected (symmetrise + coalesce)."""
+    import numpy as np
+
+    xn = np.asarray(x, dtype=np.float32)
+    N = xn.shape[0]
+    wp = xn[:, world_pos_index_start:world_pos_index_end].astype(np.float64)
+    t = xn[:, node_type_index].astype(np.int64)
+    obs, nor = np.nonzero(t == 1)[0], np.nonzero(t == 0)[0]
+    d2 = ((wp[obs][:, None, :] - wp[nor][None, :, :]) ** 2).sum(-1)
+    io, jn = np.nonzero(d2 <= float(radius) ** 2)
+    a, b = obs[io], nor[jn]
+    ei = np.asarray(edge_index, dtype=np.int64)
+    src = np.concatenate([a, b, ei[0], ei[1]])
+    dst = np.concatenate([b, a, ei[1], ei[0]])
+    key = np.unique(src * np.int64(N) + dst)
+    return np.stack([key // N, key % N], axis=0)

@@ -757,3 +757,29 @@ def test_fused_segment_sum_in_edge_kernel(dev):
                     wpk=units, seg=(topo.dst_s, topo.rowptr_dst, agg2, part))
         ops.seg_fix(topo.rowptr_dst, part, agg2)
         assert torch.equal(agg, agg2)
+
+
+def test_add_world_edges_vs_oracle(dev):
+    """mgn_add_world_edges (plate-like: 3-D world positions, OBSTACLE / NORMAL node types) bit-exact
+    against the oracle (brute-force cKDTree.query_pairs semantics in double); too small a pair
+    bound raises."""
+    from graph_physics_amd import preprocess as P
+    from scipy.spatial import Delaunay
+
+    rng = np.random.default_rng(17)
+    N = 1300
+    pts = rng.random((N, 3)).astype(np.float32) * np.array([1.0, 0.3, 0.3], dtype=np.float32)
+    types = np.where(pts[:, 0] < 0.25, 1.0, 0.0).astype(np.float32)   # a block of OBSTACLE nodes next to NORMAL ones
+    types[rng.integers(0, N, 40)] = 3.0                                # some HANDLE nodes: never linked
+    x = np.concatenate([pts, types[:, None], rng.random((N, 2)).astype(np.float32)], axis=1)  # [world pos | type | other]
+    ei = O.faces_to_edges_oracle(Delaunay(pts).simplices.T, N)
+    want = O.add_world_edges_oracle(x, ei, 0, 3, 3, radius=0.1)
+    assert want.shape[1] > ei.shape[1] + 100  # the case really adds world edges
+    got = P.add_world_edges(torch.from_numpy(x).to(dev), torch.from_numpy(ei).to(dev), 0, 3, 3, radius=0.1)
+    assert np.array_equal(got.cpu().numpy(), want)
+    # asymmetric input edges are symmetrised like to_undirected does
+    half = ei[:, ei[0] < ei[1]]
+    got2 = P.add_world_edges(torch.from_numpy(x).to(dev), torch.from_numpy(half).to(dev), 0, 3, 3, radius=0.1)
+    assert np.array_equal(got2.cpu().numpy(), want)
+    with pytest.raises(RuntimeError):
+        P.add_world_edges(torch.from_numpy(x).to(dev), torch.from_numpy(ei).to(dev), 0, 3, 3, radius=0.1, max_world_pairs=10)
