@@ -116,6 +116,10 @@ class SimDesc(C.Structure):
     ]
 
 
+class OptTensor(C.Structure):
+    _fields_ = [("p", _f32p), ("g", _f32p), ("m", _f32p), ("v", _f32p), ("n", C.c_int64)]
+
+
 class TBlock(C.Structure):
     _fields_ = [("src", _f32p), ("dst", _f32p), ("ld_src", C.c_int), ("ld_dst", C.c_int)]
 
@@ -148,6 +152,9 @@ SYMBOLS = {
     "mgn_sim_pre": (C.c_int, [C.POINTER(SimDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_sim_post": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "mgn_clip_adamw_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(OptTensor)]),
+    "mgn_clip_adamw": (C.c_int, [C.c_int, C.POINTER(OptTensor), C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_prep_last_error": (C.c_char_p, []),
 }
 

@@ -435,3 +435,138 @@ extern "C" int mgn_sim_post(const float* x, int x_w, int out_start, int type_idx
                      y_w, net_out, O, acc_sum, acc_sumsq, acc_count, std_eps, mask_truth, (long)N, pred);
   return pcheck("mgn_sim_post");
 }
+
+// =============================================== fused gradient clipping + AdamW (R8)
+// The optimiser tail of the reference's training step (Trainer(gradient_clip_val=1.0), train.py:288;
+// AdamW(lr, betas=(0.9,0.95), weight_decay=1e-4), training/lightning_module.py:494-511) for ~300
+// small tensors: torch needs ~25 multi-tensor launches (norms, clip scaling, 9 x fused AdamW);
+// here the tensors travel as kernel arguments (<= 96 per launch) and the whole tail is
+//   k_sumsq_partial  per-block sums of squares of every gradient chunk (+ step counter += 1)
+//   k_clip_adamw     every block re-adds the partials in a fixed order -> total norm -> clip
+//                    coefficient min(1, max_norm / (norm + 1e-6)); grads scaled in place (as
+//                    clip_grad_norm_ does), then the AdamW update of its chunk.
+// lr and the step counter live on the device so that a hipGraph replay sees their current values.
+#define OPT_MAX_T 96
+#define OPT_CHUNK 4096  // elements per workgroup
+struct OptLaunch {
+  int n;                       // tensors in this launch
+  int blk0[OPT_MAX_T + 1];     // first workgroup of each tensor (within this launch)
+  int part0;                   // index of this launch's first partial
+  int n_part_total;            // partials of all launches
+  float* p[OPT_MAX_T];
+  float* g[OPT_MAX_T];
+  float* m[OPT_MAX_T];
+  float* v[OPT_MAX_T];
+  int len[OPT_MAX_T];
+};
+
+__device__ __forceinline__ int opt_find(const OptLaunch& L, int b) {
+  int lo = 0, hi = L.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (L.blk0[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256) k_sumsq_partial(const OptLaunch L, float* __restrict__ part, float* __restrict__ step, int bump) {
+  __shared__ float red[256];
+  const int t = opt_find(L, blockIdx.x);
+  const long i0 = (long)(blockIdx.x - L.blk0[t]) * OPT_CHUNK;
+  const float* g = L.g[t];
+  const int n = L.len[t];
+  float s = 0.f;
+  for (long i = i0 + threadIdx.x; i < i0 + OPT_CHUNK && i < n; i += 256) s = fmaf(g[i], g[i], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[L.part0 + blockIdx.x] = red[0];
+    if (bump && blockIdx.x == 0) *step += 1.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_clip_adamw(const OptLaunch L, const float* __restrict__ part, const float* __restrict__ lr_p,
+                                                    const float* __restrict__ step_p, float beta1, float beta2, float eps, float wd,
+                                                    float max_norm, float* __restrict__ norm_out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < L.n_part_total; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  const float norm = sqrtf(red[0]);
+  if (norm_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && L.part0 == 0) *norm_out = norm;
+  float coef = 1.f;
+  if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);  // clip_grad_norm_
+  const float lr = *lr_p, step = *step_p;
+  const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  const int t = opt_find(L, blockIdx.x);
+  const long i0 = (long)(blockIdx.x - L.blk0[t]) * OPT_CHUNK;
+  float *p = L.p[t], *g = L.g[t], *m = L.m[t], *v = L.v[t];
+  const int n = L.len[t];
+  for (long i = i0 + threadIdx.x; i < i0 + OPT_CHUNK && i < n; i += 256) {
+    const float gi = g[i] * coef;
+    g[i] = gi;
+    float pi = p[i] * (1.f - lr * wd);           // decoupled weight decay
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    p[i] = pi;
+  }
+}
+
+static int opt_blocks(int64_t n) { return (int)((n + OPT_CHUNK - 1) / OPT_CHUNK) > 0 ? (int)((n + OPT_CHUNK - 1) / OPT_CHUNK) : 1; }
+
+extern "C" size_t mgn_clip_adamw_workspace_bytes(int n, const mgn_opt_tensor* t) {
+  size_t blocks = 0;
+  for (int i = 0; i < n; ++i) blocks += (size_t)opt_blocks(t[i].n);
+  return (blocks + 64) * sizeof(float);
+}
+
+extern "C" int mgn_clip_adamw(int n, const mgn_opt_tensor* t, float max_norm, const float* lr, float* step, float beta1, float beta2,
+                              float eps, float weight_decay, float* grad_norm_out, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n < 1 || lr == nullptr || step == nullptr) return pfail(1, "mgn_clip_adamw: bad arguments");
+  if (ws_bytes < mgn_clip_adamw_workspace_bytes(n, t)) return pfail(1, "mgn_clip_adamw: workspace too small");
+  int total_parts = 0;
+  for (int i = 0; i < n; ++i) {
+    if (t[i].p == nullptr || t[i].g == nullptr || t[i].m == nullptr || t[i].v == nullptr || t[i].n < 0 || t[i].n > 2147483647LL)
+      return pfail(1, "mgn_clip_adamw: null tensor / size out of range");
+    total_parts += opt_blocks(t[i].n);
+  }
+  float* part = (float*)ws;
+  for (int pass = 0; pass < 2; ++pass) {
+    int part0 = 0;
+    for (int i0 = 0; i0 < n; i0 += OPT_MAX_T) {
+      OptLaunch L;
+      L.n = (n - i0 < OPT_MAX_T) ? n - i0 : OPT_MAX_T;
+      int b = 0;
+      for (int k = 0; k < L.n; ++k) {
+        const mgn_opt_tensor& q = t[i0 + k];
+        L.blk0[k] = b;
+        L.p[k] = q.p, L.g[k] = q.g, L.m[k] = q.m, L.v[k] = q.v, L.len[k] = (int)q.n;
+        b += opt_blocks(q.n);
+      }
+      L.blk0[L.n] = b;
+      L.part0 = part0;
+      L.n_part_total = total_parts;
+      if (pass == 0)
+        hipLaunchKernelGGL(k_sumsq_partial, dim3(b), dim3(256), 0, s, L, part, step, (int)(i0 == 0));
+      else
+        hipLaunchKernelGGL(k_clip_adamw, dim3(b), dim3(256), 0, s, L, (const float*)part, lr, (const float*)step, beta1, beta2, eps,
+                           weight_decay, max_norm, grad_norm_out);
+      part0 += b;
+    }
+  }
+  return pcheck("mgn_clip_adamw");
+}

@@ -49,6 +49,63 @@ def build_mask(node_type: torch.Tensor) -> torch.Tensor:
     return torch.logical_not(keep)
 
 
+class FusedClipAdamW:
+    """clip_grad_norm_(max_norm) + AdamW(lr, betas, eps, weight_decay) of the reference's training
+    step (train.py:288, lightning_module.py:494-511) as ONE engine call (``mgn_clip_adamw``: two
+    launches per 96 tensors instead of ~25 multi-tensor launches).  ``lr`` and the step counter are
+    device scalars, so the same object works under hipGraph replay.  After ``step()`` the ``.grad``
+    tensors hold the clipped gradients, as after ``clip_grad_norm_``."""
+
+    def __init__(self, params, lr: float, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-4,
+                 max_norm: float = 1.0):
+        from . import _capi
+        self._capi = _capi
+        self.params = [p for p in params if p.requires_grad]
+        dev = self.params[0].device
+        self.device = dev
+        self.betas, self.eps, self.weight_decay, self.max_norm = betas, eps, weight_decay, max_norm
+        self.exp_avg = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
+        self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self.lr_t = torch.tensor(float(lr), dtype=torch.float32, device=dev)
+        self.norm_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self.param_groups = [{"lr": float(lr)}]
+        self._ws = None
+
+    def set_lr(self, lr: float):
+        self.param_groups[0]["lr"] = float(lr)
+        self.lr_t.fill_(float(lr))
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        C = self._capi
+        live = [(p, m, v) for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq) if p.grad is not None]
+        arr = (C.OptTensor * len(live))()
+        for i, (p, m, v) in enumerate(live):
+            if not p.grad.is_contiguous():  # e.g. the un-padded slice of an encoder's first-layer gradient
+                p.grad = p.grad.contiguous()
+            if not p.data.is_contiguous():
+                raise RuntimeError("FusedClipAdamW needs contiguous parameters")
+            arr[i].p, arr[i].g, arr[i].m, arr[i].v, arr[i].n = p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+        L = C.lib()
+        need = L.mgn_clip_adamw_workspace_bytes(len(live), arr)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.mgn_clip_adamw(len(live), arr, float(self.max_norm), self.lr_t.data_ptr(), self.step_t.data_ptr(),
+                                  float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                                  self.norm_t.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                  torch.cuda.current_stream(self.device).cuda_stream)
+        C.check(rc, "mgn_clip_adamw", prep=True)
+
+
 class Engine:
     """Model + simulator + optimiser for one device."""
 
@@ -70,6 +127,12 @@ class Engine:
         supports it (one kernel instead of ~15 foreach launches over 296 tensors)."""
         kw = dict(lr=lr, weight_decay=0.0001, betas=(0.9, 0.95))
         params = list(self.sim.parameters())
+        import os as _os
+        if params and params[0].is_cuda and all(p.dtype == torch.float32 for p in params) and _os.environ.get("MGN_TORCH_ADAMW") is None:
+            if getattr(self, "opt", None) is not None and isinstance(self.opt, FusedClipAdamW):
+                return self.opt  # already device-resident state: nothing to rebuild for graph capture
+            return FusedClipAdamW(params, float(lr) if not torch.is_tensor(lr) else float(lr.item()), betas=kw["betas"],
+                                  weight_decay=kw["weight_decay"], max_norm=self.grad_clip)
         if params and params[0].is_cuda:
             try:
                 return torch.optim.AdamW(params, fused=True, capturable=capturable, **kw)
@@ -79,8 +142,13 @@ class Engine:
 
     def train_step(self, batch: Graph) -> torch.Tensor:
         self.sim.train()
-        for g in self.opt.param_groups:
-            g["lr"] = self.learning_rate * lr_factor(self.step_count, self.warmup, self.num_steps)
+        lr_now = self.learning_rate * lr_factor(self.step_count, self.warmup, self.num_steps)
+        fused = isinstance(self.opt, FusedClipAdamW)
+        if fused:
+            self.opt.set_lr(lr_now)
+        else:
+            for g in self.opt.param_groups:
+                g["lr"] = lr_now
         node_type = batch.x[:, self.sim.node_type_index]
         net_out, target, _ = self.sim(batch)
         loss = l2_loss(net_out, target, node_type)
@@ -88,8 +156,12 @@ class Engine:
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync(self.sim.parameters())
-        self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.sim.parameters(), self.grad_clip)
-        self.opt.step()
+        if fused:  # clip + AdamW in one engine call
+            self.opt.step()
+            self.last_grad_norm = self.opt.norm_t
+        else:
+            self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.sim.parameters(), self.grad_clip)
+            self.opt.step()
         self.step_count += 1
         return loss.detach()
 
@@ -114,8 +186,11 @@ class Engine:
         for mod in self.sim.modules():  # host mirrors of the accumulation counters: no .item() under capture
             if isinstance(mod, Normalizer) and mod._host_num_acc is None:
                 mod._host_num_acc = int(mod._num_accumulations.item())
-        self._lr_t = torch.tensor(self.learning_rate, dtype=torch.float32, device=dev)
-        self.opt = self._make_optimizer(self._lr_t, capturable=True)
+        if isinstance(self.opt, FusedClipAdamW):
+            self._lr_t = self.opt.lr_t  # lr and step already live on the device
+        else:
+            self._lr_t = torch.tensor(self.learning_rate, dtype=torch.float32, device=dev)
+            self.opt = self._make_optimizer(self._lr_t, capturable=True)
         self._static = batch.clone()
         if getattr(batch, "mgn_topology", None) is not None:
             self._static.mgn_topology = batch.mgn_topology
@@ -129,8 +204,12 @@ class Engine:
             loss = l2_loss(net_out, target, node_type)
             self.opt.zero_grad(set_to_none=True)
             loss.backward()
-            gn = torch.nn.utils.clip_grad_norm_(self.sim.parameters(), self.grad_clip)
-            self.opt.step()
+            if isinstance(self.opt, FusedClipAdamW):
+                self.opt.step()
+                gn = self.opt.norm_t
+            else:
+                gn = torch.nn.utils.clip_grad_norm_(self.sim.parameters(), self.grad_clip)
+                self.opt.step()
             return loss.detach(), gn
 
         side = torch.cuda.Stream(device=dev)

@@ -302,6 +302,23 @@ int mgn_sim_pre(const mgn_sim_desc* desc, void* ws, size_t ws_bytes, void* strea
 int mgn_sim_post(const float* x, int x_w, int out_start, int type_idx, const float* y, int y_w,
                  const float* net_out, int O, const float* acc_sum, const float* acc_sumsq,
                  const float* acc_count, float std_eps, int mask_truth, int64_t N, float* pred, void* stream);
+/* ------------------------------------------- fused gradient clipping + AdamW (harness, R8)
+ * Trainer(gradient_clip_val=1.0) (train.py:288) + AdamW(betas=(0.9,0.95), weight_decay=1e-4)
+ * (training/lightning_module.py:494-511) over n tensors in 2 * ceil(n/96) launches:
+ *   norm = sqrt(sum_t ||g_t||^2);  g *= min(1, max_norm / (norm + 1e-6))   (max_norm <= 0: no clip)
+ *   *step += 1;  p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *   p -= (lr / (1 - b1^step)) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)
+ * lr and step are DEVICE scalars (a hipGraph replay reads their current values); *grad_norm_out
+ * (device, optional) receives the pre-clip norm.  The tensor table is a HOST array. */
+typedef struct {
+  float* p; float* g; float* m; float* v;
+  int64_t n;
+} mgn_opt_tensor;
+size_t mgn_clip_adamw_workspace_bytes(int n, const mgn_opt_tensor* tensors);
+int mgn_clip_adamw(int n, const mgn_opt_tensor* tensors, float max_norm, const float* lr, float* step,
+                   float beta1, float beta2, float eps, float weight_decay, float* grad_norm_out,
+                   void* ws, size_t ws_bytes, void* stream);
+
 /* text of the last error of the entry points in this section */
 const char* mgn_prep_last_error(void);
 
