@@ -15,13 +15,17 @@ for name, calls, tot, avg, pct in db.execute("select name,total_calls,total_dura
     print(f"\"{short}\",{calls},{tot:.1f},{avg:.3f},{pct:.2f}")
 
 # per launch shape (grid size in workgroups) for the engine kernels: the edge-row launches
-# (512 persistent workgroups) and the node-row launches of the same kernel differ 5x in duration
+# (512 persistent workgroups) and the node-row launches of the same kernel differ 5x in duration;
+# the median separates the training-mode launches (the majority) from the few inference-mode
+# launches of the rollout part of the same command
 if len(sys.argv) > 3 and sys.argv[3] == "by-grid":
+    import statistics
     print()
-    print("kernel,workgroups,calls,avg_us,min_us,max_us")
-    q = ("select name, grid_x/workgroup_x, count(*), avg(duration)/1000., min(duration)/1000., max(duration)/1000. "
-         "from kernels where name like '%k_mlp_%' or name like '%k_wgrad%' or name like '%k_segsum%' "
-         "group by name, grid_x/workgroup_x order by 4*count(*) desc")
-    for name, wgs, calls, avg, mn, mx in db.execute(q):
-        short = name.split("(")[0].replace("void ", "")
-        print(f"\"{short}\",{wgs},{calls},{avg:.3f},{mn:.3f},{mx:.3f}")
+    print("kernel,workgroups,calls,avg_us,median_us,min_us,max_us")
+    groups = {}
+    q = ("select name, grid_x/workgroup_x, duration/1000. from kernels where name like '%k_mlp_%' or name like '%k_wgrad%' "
+         "or name like '%k_segsum%' or name like '%k_seg_fix%' or name like '%k_clip_adamw%' or name like '%k_sumsq%'")
+    for name, wgs, d in db.execute(q):
+        groups.setdefault((name.split("(")[0].replace("void ", ""), wgs), []).append(d)
+    for (short, wgs), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+        print(f"\"{short}\",{wgs},{len(v)},{sum(v)/len(v):.3f},{statistics.median(v):.3f},{min(v):.3f},{max(v):.3f}")
