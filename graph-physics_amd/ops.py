@@ -480,19 +480,26 @@ class ProcessorFunction(torch.autograd.Function):
         prec = prec if x6 else 0
         NU = 11
         if x6:
-            pk = torch.empty(L * NU * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+            # per round [We0|e, We1, We2, We3 | Wn0|x, Wn0|agg, Wn1, Wn2, Wn3, NEXT round's We0|x_dst, We0|x_src]:
+            # the units of every launch lie back to back (edge 0..3, node 4..8 + its two post-products 9..10);
+            # round 0's own projections sit in two extra slots at the end
+            pk = torch.empty((L * NU + 2) * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
             pk0 = pk.data_ptr()
             blocks = []
             for i in range(L):
                 q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
                 We0, Wn0 = q[0].data_ptr(), q[9].data_ptr()
                 srcs = [(We0, 3 * H), (q[2].data_ptr(), H), (q[4].data_ptr(), H), (q[6].data_ptr(), H),
-                        (Wn0, 2 * H), (Wn0 + 4 * H, 2 * H), (q[11].data_ptr(), H), (q[13].data_ptr(), H), (q[15].data_ptr(), H),
-                        (We0 + 4 * H, 3 * H), (We0 + 8 * H, 3 * H)]
+                        (Wn0, 2 * H), (Wn0 + 4 * H, 2 * H), (q[11].data_ptr(), H), (q[13].data_ptr(), H), (q[15].data_ptr(), H)]
+                if i + 1 < L:
+                    Wnx = P[PARAMS_PER_BLOCK * (i + 1)].data_ptr()
+                    srcs += [(Wnx + 4 * H, 3 * H), (Wnx + 8 * H, 3 * H)]
                 for u, (sa, ld) in enumerate(srcs):
                     blocks.append((sa, ld, False, pk0 + (i * NU + u) * _capi.WPACK_BYTES))
+            W00 = P[0].data_ptr()
+            blocks.append((W00 + 4 * H, 3 * H, False, pk0 + (L * NU) * _capi.WPACK_BYTES))
+            blocks.append((W00 + 8 * H, 3 * H, False, pk0 + (L * NU + 1) * _capi.WPACK_BYTES))
             wpack(blocks, dev)
-            ctx_pk = pk  # keeps the buffer alive until the launches below are enqueued
 
             def unit(i, u):
                 return pk0 + (i * NU + u) * _capi.WPACK_BYTES
@@ -501,7 +508,7 @@ class ProcessorFunction(torch.autograd.Function):
             Pd, Ps = torch.empty(N, H, **f), torch.empty(N, H, **f)
             for slab, dst_t in ((1, Pd), (2, Ps)):
                 mlp_fwd(N, H, [(x, None, H)], [W0[:, slab * H:(slab + 1) * H].contiguous()], [None], None, H, None, dst_t,
-                        wpk=[unit(0, 8 + slab)] if x6 else (), precision=prec)
+                        wpk=[unit(L, slab - 1)] if x6 else (), precision=prec)
         for i in range(L):
             q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
             We, be, se = [q[0], q[2], q[4], q[6]], [q[1], q[3], q[5], q[7]], q[8]
@@ -542,7 +549,7 @@ class ProcessorFunction(torch.autograd.Function):
                 posts = [(W0n.data_ptr() + 4 * H, Pd_n), (W0n.data_ptr() + 8 * H, Ps_n)]
             wn = ()
             if x6:
-                wn = [unit(i, u) for u in range(4, 9)] + ([unit(i + 1, 9), unit(i + 1, 10)] if posts else [])
+                wn = [unit(i, u) for u in range(4, 9)] + ([unit(i, 9), unit(i, 10)] if posts else [])
             mlp_fwd(N, H, [(x, None, H), (agg, None, H)], Wn, bn, sn, H, x, x_new, None, Hn, Un, Rn,
                     posts=posts, post_ldw=3 * H, wpk=wn, saveM=Mn, precision=prec)
             if need:
