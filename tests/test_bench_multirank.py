@@ -1,0 +1,38 @@
+"""GPU: rehearsal of the multi-process bench path the driver launches for N > 1
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`).  A 1-GPU box cannot
+run RCCL with two ranks on one device, so the two ranks share the device and talk over gloo
+(MGN_DIST_BACKEND / MGN_SHARE_GPU, graph_physics_amd/distributed.py): same code path for parameter
+broadcast, gradient all-reduce, the max-over-ranks timing and the rank-0-only sections (kernel
+timing must not enter a collective)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_bench_line():
+    env = dict(os.environ, MGN_DIST_BACKEND="gloo", MGN_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "2", "--nodes", "400", "--rounds", "3", "--rollout-steps", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch_meshes"] == 4
+    assert "roofline" in d and d["roofline"]["bound"] == "hbm"
