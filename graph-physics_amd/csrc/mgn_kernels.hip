@@ -1817,6 +1817,9 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
     unsigned grid = (unsigned)((a.M + rows - 1) / rows);
     const unsigned cap = (nw == 8) ? 256u : 512u;
     if (grid > cap) grid = cap;
+    if (const char* e = getenv("MGN_GRID")) {  // occupancy experiments: fewer persistent workgroups
+      if (atoi(e) > 0 && (unsigned)atoi(e) < grid) grid = (unsigned)atoi(e);
+    }
     if (nw == 8) {
       if (a.precision == 1)
         hipLaunchKernelGGL((k_mlp_fwd_x6<1, 8>), dim3(grid), dim3(512), X6_FWD_LDS_BYTES(8), s, a);
