@@ -82,7 +82,13 @@ class MlpBwdArgs(C.Structure):
         ("front_src", _f32p * MAX_PHASES),
         ("front_resid", _f32p),
         ("front_out", _f32p),
+        ("defer_reduce", C.c_int),
     ]
+
+
+class ColredJob(C.Structure):
+    _fields_ = [("red_ws", C.c_void_p), ("M", C.c_int64), ("H", C.c_int), ("NL", C.c_int), ("out_w", C.c_int), ("n_din", C.c_int),
+                ("db", _f32p * MAX_LAYERS), ("dscale", _f32p)]
 
 
 class WgradJob(C.Structure):
@@ -136,6 +142,7 @@ SYMBOLS = {
     "mgn_mlp_fwd": (C.c_int, [C.POINTER(MlpFwdArgs), C.c_void_p]),
     "mgn_mlp_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "mgn_mlp_bwd": (C.c_int, [C.POINTER(MlpBwdArgs), C.c_void_p]),
+    "mgn_colred_batch": (C.c_int, [C.c_int, C.POINTER(ColredJob), C.c_void_p]),
     "mgn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(WgradJob)]),
     "mgn_wgrad": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_wgrad_p": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),

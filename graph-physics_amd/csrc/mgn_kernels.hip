@@ -563,6 +563,37 @@ __global__ void __launch_bounds__(1024) k_colred(const float* __restrict__ ws, i
   }
 }
 
+// The same for up to CR_MAX deferred launches at once (grid.y = job): the per-launch reduce is a
+// 7 us latency-bound launch, 30 of them per training step.
+#define CR_MAX 32
+struct ColredJob {
+  const float* ws;
+  int nblocks, nslot, H;
+  ColredOuts outs;
+};
+struct ColredBatch {
+  ColredJob j[CR_MAX];
+};
+__global__ void __launch_bounds__(1024) k_colred_batch(const ColredBatch B) {
+  __shared__ float red[32][33];
+  const ColredJob J = B.j[blockIdx.y];
+  const int ncol = J.nslot * J.H;
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int rl = threadIdx.x >> 5;
+  float s = 0.f;
+  if (col < ncol && J.outs.o[col / J.H] != nullptr)
+    for (int b = rl; b < J.nblocks; b += 32) s += J.ws[(size_t)b * ncol + col];
+  red[rl][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rl == 0 && col < ncol) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
+    float* o = J.outs.o[col / J.H];
+    if (o != nullptr) o[col % J.H] = t;
+  }
+}
+
 // ======================================================== LDS-weight kernels (H = 128)
 // Probe result (tools/gemm_probe.hip): with every wave streaming its own weight
 // fragments from L2 the per-CU vector-memory path saturates and the fp32 MFMA pipe
@@ -2073,10 +2104,35 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   }
   outs.o[a.NL] = (a.scale != nullptr) ? a.dscale : nullptr;
   any |= outs.o[a.NL] != nullptr;
-  if (!any) return 0;
+  if (!any || a.defer_reduce) return 0;  // deferred: the caller finishes with mgn_colred_batch
   const int n = nslot * a.H;
   hipLaunchKernelGGL(k_colred, dim3((n + 31) / 32), dim3(1024), 0, s, (const float*)a.red_ws, (int)grid, nslot, a.H, outs);
   return check_launch("mgn_mlp_bwd/colred");
+}
+
+int mgn_colred_batch(int n, const mgn_colred_job* jobs, void* stream) {
+  if (n < 0) return fail(1, "mgn_colred_batch: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n; i0 += CR_MAX) {
+    ColredBatch B;
+    const int m = (n - i0 < CR_MAX) ? n - i0 : CR_MAX;
+    int maxcol = 0;
+    for (int i = 0; i < m; ++i) {
+      const mgn_colred_job& q = jobs[i0 + i];
+      if (q.red_ws == nullptr || q.NL < 1 || q.NL > MGN_MAX_LAYERS) return fail(1, "mgn_colred_batch: bad job");
+      ColredJob& J = B.j[i];
+      J.ws = (const float*)q.red_ws;
+      J.nblocks = (int)plan_mlp(q.M, q.H, q.NL, q.out_w != q.H || q.n_din > 1, true).grid;
+      J.nslot = q.NL + 1;
+      J.H = q.H;
+      for (int l = 0; l <= MGN_MAX_LAYERS; ++l) J.outs.o[l] = nullptr;
+      for (int l = 0; l < q.NL; ++l) J.outs.o[l] = q.db[l];
+      J.outs.o[q.NL] = q.dscale;
+      if (J.nslot * J.H > maxcol) maxcol = J.nslot * J.H;
+    }
+    hipLaunchKernelGGL(k_colred_batch, dim3((maxcol + 31) / 32, m), dim3(1024), 0, s, B);
+  }
+  return check_launch("mgn_colred_batch");
 }
 
 static int wgrad_plan(int njobs, const mgn_wgrad_job* jobs, int* wg0, bool lds) {

@@ -219,7 +219,7 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
             Hs: Sequence[torch.Tensor], WT: Sequence[Optional[torch.Tensor]], dZ: Sequence[Optional[torch.Tensor]],
             din: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]],
             db: Sequence[Optional[torch.Tensor]], dscale: Optional[torch.Tensor], wpk: Sequence[int] = (),
-            Ms: Optional[Sequence[torch.Tensor]] = None, precision: int = 0, front=None):
+            Ms: Optional[Sequence[torch.Tensor]] = None, precision: int = 0, front=None, defer: Optional[list] = None):
     """``front`` = (rows[<=3] each [M,H], resid[M,H] or None, out[M,H] or None): the fused front
     stage of the packed kernel, dY = resid + sum_p wpk[p] . rows[p] (then ``dOut`` is ignored)."""
     L = _capi.lib()
@@ -253,9 +253,28 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
     nbytes = L.mgn_mlp_bwd_workspace_bytes(M, H, NL)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     a.red_ws, a.red_ws_bytes = _ptr(ws), ws.numel()
+    if defer is not None:  # column sums finished later, many launches at once (colred_batch)
+        a.defer_reduce = 1
+        defer.append((ws, M, H, NL, out_w, len(din), list(db), dscale if scale is not None else None))
     with torch.cuda.device(dev):
         rc = L.mgn_mlp_bwd(C.byref(a), _stream(dev))
     _capi.check(rc, "mgn_mlp_bwd")
+
+
+def colred_batch(deferred: list, dev):
+    """finish the column sums (bias / scale gradients) of ``mlp_bwd(..., defer=deferred)`` launches"""
+    if not deferred:
+        return
+    arr = (_capi.ColredJob * len(deferred))()
+    for i, (ws, M, H, NL, out_w, n_din, db, dscale) in enumerate(deferred):
+        arr[i].red_ws, arr[i].M, arr[i].H, arr[i].NL, arr[i].out_w, arr[i].n_din = _ptr(ws), M, H, NL, out_w, n_din
+        for l in range(NL):
+            arr[i].db[l] = _ptr(db[l])
+        arr[i].dscale = _ptr(dscale)
+    with torch.cuda.device(dev):
+        rc = _capi.lib().mgn_colred_batch(len(deferred), arr, _stream(dev))
+    _capi.check(rc, "mgn_colred_batch")
+    deferred.clear()
 
 
 def wgrad(jobs, dev, precision: int = 0):
@@ -623,6 +642,8 @@ class ProcessorFunction(torch.autograd.Function):
         fuse = x6 and _os.environ.get("MGN_FRONT") is not None
         dZn_sets = [dZn, [torch.empty(N, H, **f) for _ in range(4)] if fuse and L > 1 else dZn]
         node_done = False
+        # scale-gradient partials of all chain launches, reduced by ONE launch at the end (MGN_NO_DEFER: per launch)
+        deferred = [] if _os.environ.get("MGN_NO_DEFER") is None else None
 
         def units(i):
             return [unit(i, u) for u in range(4)], [unit(i, u) for u in range(4, 8)], [unit(i, u) for u in range(8, 11)]
@@ -651,11 +672,11 @@ class ProcessorFunction(torch.autograd.Function):
             # previous iteration's fused launch except for the last round)
             if not node_done:
                 mlp_bwd(N, H, 4, dx, None, None, H, Un, Rn, sn, Hn, WTn, dZn, [(WT0n_agg, None, dAgg)],
-                        [None] * 4, g[17], wpk=kn, Ms=Mn, precision=prec)
+                        [None] * 4, g[17], wpk=kn, Ms=Mn, precision=prec, defer=deferred)
             # edge MLP chain: dM = dE' + dAgg[dst] -> dZe[3..0], dE = dE' + W0e[:, :H]^T dZe0
             de_new = de_buf[0] if de.data_ptr() != de_buf[0].data_ptr() else de_buf[1]
             mlp_bwd(E, H, 4, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
-                    [None] * 4, g[8], wpk=ke, Ms=Me, precision=prec)
+                    [None] * 4, g[8], wpk=ke, Ms=Me, precision=prec, defer=deferred)
             # scatter of the first-layer pre-activations' grads onto dst / src nodes
             if H == 128:
                 segsum2(dZe[0], topo.rowptr_dst, None, Sd, topo.rowptr_src, topo.perm_src, Ss)
@@ -683,12 +704,13 @@ class ProcessorFunction(torch.autograd.Function):
                 kn_p, _, _ = units(i - 1)
                 mlp_bwd(N, H, 4, dx, None, None, H, Un_p, Rn_p, qp[17], Hn_p, WTn, dZn_sets[(i - 1) & 1],
                         [(WT0n_agg, None, dAgg)], [None] * 4, gs[i - 1][17], wpk=kx + kn_p, Ms=Mn_p, precision=prec,
-                        front=([dZn[0], Sd, Ss], dx, dx_new))
+                        front=([dZn[0], Sd, Ss], dx, dx_new), defer=deferred)
                 node_done = True
             else:
                 mlp_fwd(N, H, [(dZn[0], None, H), (Sd, None, H), (Ss, None, H)], [Wcat], [None], None, H, dx, dx_new, wpk=kx, precision=prec)
                 node_done = False
             grads[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)] = g
             dx, de = dx_new, de_new
+        colred_batch(deferred, dev)
         ctx.saved_acts = None
         return (dx, de, None, None, *grads)

@@ -192,9 +192,23 @@ typedef struct {
   const float* front_src[MGN_MAX_PHASES];
   const float* front_resid;
   float* front_out;
+  /* != 0: leave the column sums (db[], dscale) as per-workgroup partials in red_ws -- which must
+   * then stay alive -- and finish many launches at once with mgn_colred_batch. */
+  int defer_reduce;
 } mgn_mlp_bwd_args;
 size_t mgn_mlp_bwd_workspace_bytes(int64_t M, int H, int NL);
 int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream);
+
+/* Deferred column reductions of mgn_mlp_bwd launches (defer_reduce != 0), all in one launch.
+ * M, H, NL, out_w, n_din as in the launch that filled red_ws (they fix its partial count). */
+typedef struct {
+  const void* red_ws;
+  int64_t M;
+  int H, NL, out_w, n_din;
+  float* db[MGN_MAX_LAYERS];
+  float* dscale;
+} mgn_colred_job;
+int mgn_colred_batch(int n, const mgn_colred_job* jobs, void* stream);
 
 /* ------------------------------------------------------------------ weight grads
  * For each job: dW[j, k] = sum_m A[m, j] * B[m, k],  j < 16*nja, k < 16*nkb
