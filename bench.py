@@ -131,7 +131,7 @@ def kernel_rooflines(gp, ops, eng, batch, dev, steps=3):
                ms["edge_fwd"], b_fwd, "edge_fwd_bytes", mfma(ms["edge_fwd"], nterm if x6 else 1))
     roof["launches_per_step"] = n["edge_fwd"]
     others = [
-        hbm(f"k_mlp_bwd_{t} + k_colred (edge backward chain: RMSNorm bwd, 3 masked dgrad GEMMs, input grad)", ms["edge_bwd"], b_bwd,
+        hbm(f"k_mlp_bwd_{t} (edge backward chain: RMSNorm bwd, 3 masked dgrad GEMMs, input grad)", ms["edge_bwd"], b_bwd,
             "edge_bwd_bytes", dict(mfma(ms["edge_bwd"], nterm if x6 else 1), launches_per_step=n["edge_bwd"])),
         hbm(f"k_wgrad_{'x6' if x6 else 'lds'} + k_wgrad_red (weight gradients of one round: 4 edge + 6..7 node jobs)", ms["wgrad"], b_wg,
             "wgrad_bytes", {"launches_per_step": n["wgrad"]}),
