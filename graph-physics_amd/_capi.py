@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _REPO = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_CSRC, "libmgn_hip.so")
+LIB_PATH = os.environ.get("MGN_LIB") or os.path.join(_CSRC, "libmgn_hip.so")
 SOURCES = [os.path.join(_CSRC, "mgn_kernels.hip"), os.path.join(_CSRC, "mgn_prep.hip")]
 DEPS = [os.path.join(_CSRC, "mgn_x6.inc")]  # included by the source
 HEADER = os.path.join(_REPO, "include", "mgn_hip.h")
@@ -119,6 +119,9 @@ class SimDesc(C.Structure):
         ("accumulate", C.c_int * 3),
         ("std_eps", C.c_float),
         ("node_out", _f32p), ("target_out", _f32p), ("edge_out", _f32p),
+        ("norm_w", C.c_int * 3),
+        ("max_accumulations", C.c_float),
+        ("type_err", C.c_void_p),
     ]
 
 
@@ -168,6 +171,12 @@ SYMBOLS = {
 _lib = None
 _lock = threading.Lock()
 
+#: ABI version this binding was written against (mgn_version() of the library must match: the
+#: ctypes structs above mirror exactly that header)
+EXPECTED_VERSION = 120
+HASH_PATH = os.path.join(_CSRC, "libmgn_hip.srchash")
+LOCK_PATH = os.path.join(_CSRC, ".build.lock")
+
 
 def hipcc_path():
     for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
@@ -178,33 +187,68 @@ def hipcc_path():
     return which("hipcc")
 
 
+def source_hash() -> str:
+    """sha256 over the HIP sources, their includes and the header (file contents, not mtimes: a
+    snapshot copy of the tree -- the GPU box -- must not look stale)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in SOURCES + DEPS + [HEADER]:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read() + b"\0")
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
+    if os.environ.get("MGN_LIB"):  # A/B experiments: an explicitly named build is taken as is
+        return False
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(s) > t for s in SOURCES + DEPS + [HEADER])
+    try:
+        with open(HASH_PATH) as fh:
+            return fh.read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into csrc/libmgn_hip.so (in-tree)."""
+    """Compile the HIP sources for gfx950 into csrc/libmgn_hip.so (in-tree).  Safe under
+    ``torch.distributed.run``: the build is serialised by an flock, every process compiles into
+    its own temporary file, and a process that waited for the lock re-checks before compiling."""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build csrc/libmgn_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", os.path.join(_REPO, "include"), "-o", LIB_PATH + ".tmp"] + SOURCES
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    import fcntl
+
+    with open(LOCK_PATH, "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # another rank built it while we waited
+                return LIB_PATH
+            tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                   "-I", os.path.join(_REPO, "include"), "-o", tmp] + SOURCES
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+            os.replace(tmp, LIB_PATH)
+            with open(f"{HASH_PATH}.{os.getpid()}.tmp", "w") as fh:
+                fh.write(source_hash() + "\n")
+            os.replace(f"{HASH_PATH}.{os.getpid()}.tmp", HASH_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     if verbose:
         print("built", LIB_PATH)
     return LIB_PATH
 
 
 def lib():
-    """The loaded C-ABI library.  Raises RuntimeError if it is missing and cannot be built."""
+    """The loaded C-ABI library.  Raises RuntimeError if it is missing / stale and cannot be
+    rebuilt, or if its ABI version is not the one this binding mirrors."""
     global _lib
     if _lib is not None:
         return _lib
@@ -214,10 +258,9 @@ def lib():
                 try:
                     build()
                 except Exception as e:  # noqa: BLE001
-                    if not os.path.exists(LIB_PATH):
-                        raise RuntimeError(
-                            f"MI355X engine library {LIB_PATH} is missing and could not be built ({e}); "
-                            "run `python -c 'import __graft_entry__ as g; g.build()'`") from e
+                    raise RuntimeError(
+                        f"MI355X engine library {LIB_PATH} is missing or older than its sources and could not be "
+                        f"rebuilt ({e}); run `python -c 'import __graft_entry__ as g; g.build()'`") from e
             try:
                 L = C.CDLL(LIB_PATH)
             except OSError as e:
@@ -226,6 +269,10 @@ def lib():
                 fn = getattr(L, name)
                 fn.restype = res
                 fn.argtypes = args
+            v = L.mgn_version()
+            if v != EXPECTED_VERSION:
+                raise RuntimeError(f"{LIB_PATH} has ABI version {v}, this binding needs {EXPECTED_VERSION}: rebuild it "
+                                   "(`python -c 'import __graft_entry__ as g; g.build()'`)")
             _lib = L
     return _lib
 

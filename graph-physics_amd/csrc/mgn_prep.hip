@@ -305,7 +305,9 @@ __device__ __forceinline__ float sim_value(const mgn_sim_desc& d, int stream, lo
     const int nf = d.feat_end - d.feat_start;
     if (col < nf) return d.x[row * d.x_w + d.feat_start + col];
     const float t = d.x[row * d.x_w + d.type_idx];
-    return ((int)(long)t == col - nf) ? 1.f : 0.f;  // one_hot(node_type.long(), 9)
+    const int ti = (int)(long)t;
+    if (col == nf && d.type_err != nullptr && (ti < 0 || ti >= MGN_NODE_TYPES)) *d.type_err = 1;  // F.one_hot raises
+    return (ti == col - nf) ? 1.f : 0.f;  // one_hot(node_type.long(), 9)
   }
   if (stream == 1) return d.y[row * d.y_w + col] - d.x[row * d.x_w + d.out_start + col];
   return d.edge_attr[row * d.edge_w + col];
@@ -318,7 +320,7 @@ __device__ __forceinline__ long sim_rows(const mgn_sim_desc& d, int stream) { re
 // grid (SIM_PART, 3): workgroup b of stream s sums rows b, b+SIM_PART*R, ... ; thread = (row lane, column)
 __global__ void __launch_bounds__(256) k_stats_partial(const mgn_sim_desc d, float* __restrict__ part) {
   const int stream = blockIdx.y;
-  if (!d.accumulate[stream]) return;
+  if (!d.accumulate[stream] || !(*d.num_acc[stream] < d.max_accumulations)) return;
   const int W = sim_width(d, stream);
   const long M = sim_rows(d, stream);
   __shared__ float s1[256], s2[256];
@@ -346,7 +348,8 @@ __global__ void __launch_bounds__(256) k_stats_partial(const mgn_sim_desc d, flo
 
 __global__ void __launch_bounds__(64) k_stats_final(const mgn_sim_desc d, const float* __restrict__ part) {
   const int stream = blockIdx.x;
-  if (!d.accumulate[stream]) return;
+  // one wave: every lane reads the counter before lane 0 bumps it at the end
+  if (!d.accumulate[stream] || !(*d.num_acc[stream] < d.max_accumulations)) return;
   const int W = sim_width(d, stream);
   const int col = threadIdx.x % SIM_MAXW, which = threadIdx.x / SIM_MAXW;  // 0: sum, 1: sum of squares
   if (col < W) {
@@ -388,6 +391,13 @@ extern "C" int mgn_sim_pre(const mgn_sim_desc* desc, void* ws, size_t ws_bytes, 
   if (d.feat_end < d.feat_start || Wn > SIM_MAXW || d.out_w < 1 || d.out_w > SIM_MAXW || d.edge_w > SIM_MAXW)
     return pfail(1, "mgn_sim_pre: feature widths out of range (<= 32 columns per stream)");
   if (d.N < 0 || d.E < 0 || d.x == nullptr) return pfail(1, "mgn_sim_pre: bad arguments");
+  if (d.feat_start < 0 || d.feat_end > d.x_w || d.type_idx < 0 || d.type_idx >= d.x_w)
+    return pfail(1, "mgn_sim_pre: feature / node-type columns outside x");
+  if (d.y != nullptr && (d.out_start < 0 || d.out_start + d.out_w > d.x_w || d.out_w > d.y_w))
+    return pfail(1, "mgn_sim_pre: output columns outside x / y");
+  if (Wn != d.norm_w[0]) return pfail(1, "mgn_sim_pre: node feature width differs from the node normaliser's");
+  if (d.y != nullptr && d.out_w != d.norm_w[1]) return pfail(1, "mgn_sim_pre: output width differs from the output normaliser's");
+  if (d.edge_attr != nullptr && d.edge_w != d.norm_w[2]) return pfail(1, "mgn_sim_pre: edge feature width differs from the edge normaliser's");
   if (d.target_out != nullptr && d.y == nullptr) return pfail(1, "mgn_sim_pre: target requested without y");
   if (d.accumulate[0] || d.accumulate[1] || d.accumulate[2]) {
     if (ws_bytes < mgn_sim_workspace_bytes()) return pfail(1, "mgn_sim_pre: workspace too small");

@@ -408,14 +408,26 @@ class MlpFunction(torch.autograd.Function):
                     saveH[1:] if need else None, U, R, wpk=units)
         else:
             mlp_fwd(M, H, [(x, None, kin)], Wk, bk, scale, out_w, None, y, None, saveH, U, R)
-        ctx.meta = (NL, H, kin, out_w, has_norm)
-        ctx.saved = (x, Wk, scale, saveH, U, R)
+        ctx.meta = (NL, H, kin, out_w, has_norm, kp != kin, op != out_w)
+        # inputs / parameters through save_for_backward (autograd's version counter then catches an
+        # in-place update between forward and backward); padded weight copies and the activations
+        # the kernels wrote are ours and live until the graph is freed
+        ctx.save_for_backward(x, *Ws, *([scale] if has_norm else []))
+        ctx.pads = (W0 if kp != kin else None, Wl if op != out_w else None)
+        ctx.saved_acts = (saveH, U, R)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        NL, H, kin, out_w, has_norm = ctx.meta
-        x, Wk, scale, saveH, U, R = ctx.saved
+        NL, H, kin, out_w, has_norm, pad0, padl = ctx.meta
+        if ctx.saved_acts is None or ctx.saved_acts[0] is None:
+            raise RuntimeError("MlpFunction: no saved activations -- backward ran a second time without retain_graph "
+                               "support, or the forward ran under no_grad")
+        t = ctx.saved_tensors
+        x, Ws = t[0], list(t[1:1 + NL])
+        scale = t[1 + NL] if has_norm else None
+        Wk = [ctx.pads[0] if pad0 else Ws[0]] + Ws[1:-1] + [ctx.pads[1] if padl else Ws[-1]]
+        saveH, U, R = ctx.saved_acts
         dy = _f32c(dy)
         M, dev = x.shape[0], x.device
         kp, op = pad16(kin), pad16(out_w)
@@ -575,12 +587,18 @@ class ProcessorFunction(torch.autograd.Function):
                 saved.append((x, e, agg, He, Ue, Re, Hn, Un, Rn, Me, Mn))
             x, e = x_new, e_new
             Pd, Ps = Pd_n, Ps_n
-        ctx.topo, ctx.L, ctx.P, ctx.saved_acts, ctx.prec = topo, L, P, saved, prec
+        ctx.topo, ctx.L, ctx.saved_acts, ctx.prec = topo, L, (saved if need else None), prec
+        ctx.save_for_backward(*P)  # version-checked by autograd (an optimiser step in between is an error)
         return x, e
 
     @staticmethod
     def backward(ctx, dx, de):
-        topo, L, P, saved, prec = ctx.topo, ctx.L, ctx.P, ctx.saved_acts, ctx.prec
+        topo, L, saved, prec = ctx.topo, ctx.L, ctx.saved_acts, ctx.prec
+        if saved is None:
+            raise RuntimeError("ProcessorFunction: the saved activations were released by an earlier backward pass "
+                               "(retain_graph is not supported: ~2.5 KB per edge and round are freed eagerly), "
+                               "or the forward ran under no_grad")
+        P = list(ctx.saved_tensors)
         dev = P[0].device
         N, E = topo.N, topo.E
         H = P[1].numel()
@@ -634,7 +652,9 @@ class ProcessorFunction(torch.autograd.Function):
                 tb.append((We0 + 4 * H, 3 * H, cat + 4 * H, 3 * H))                          # (W0e[:, H:2H])^T
                 tb.append((We0 + 8 * H, 3 * H, cat + 8 * H, 3 * H))                          # (W0e[:, 2H:])^T
             transpose_blocks(tb, H, dev)
-        gs = [[torch.empty_like(t) for t in P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]] for i in range(L)]
+        # E == 0 / N == 0: some launches return early at M == 0 and would leave their outputs unwritten
+        _alloc = torch.zeros_like if (E == 0 or N == 0) else torch.empty_like
+        gs = [[_alloc(t) for t in P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]] for i in range(L)]
         # packed path: the dX launch of round i and the node chain of round i-1 work on the same
         # rows -> one launch (front stage of mgn_mlp_bwd); dZn double buffered across rounds
         # (measured neutral at N = 30k rows -- 88 us fused vs 57 + 30 us: a launch costs as many tile

@@ -5,22 +5,33 @@ graphphysics/utils/torch_graph.py:108-135, dataset/dataset.py:244-327) is an
 approximation; here the partitioned forward/backward is EXACTLY the single-device
 one: every directed edge lives on the rank that owns its destination, so the
 aggregation is local, edge latents never move, and the only remote data a round
-needs are the latent rows of ghost SOURCE nodes (one neighbour exchange per round).
+needs are the (projected) latent rows of ghost SOURCE nodes -- one neighbour
+exchange per round.
 
-No METIS library exists in this image (the reference gets it through PyG
-``ClusterData``); the partitioner is recursive coordinate bisection, which for
-quasi-uniform meshes is within a small factor of METIS' edge cut and perfectly
-balanced.
+Partitioner.  The reference reaches METIS through PyG ``ClusterData``
+(torch_graph.py:127-135); no METIS library exists in this image, so the same
+scheme is written here (vectorised numpy, host side, one-time prep):
+
+  * ``multilevel_partition``  METIS' multilevel k-way: coarsen by heavy-edge matching
+    (handshake rounds), partition the coarsest graph by recursive graph-growing bisection,
+    project back level by level with a balance-constrained greedy boundary refinement
+    (Fiduccia-Mattheyses-style gains).  Needs only the graph -- works for the aneurysm /
+    plate geometries where coordinates are a poor guide.
+  * ``rcb_partition``         recursive coordinate bisection, perfectly balanced, O(n log n);
+    with ``refine_partition`` on top it is the fast path for quasi-uniform meshes with
+    coordinates (the 1M-node Delaunay of BASELINE configs[3]: 0.6 s + refinement).
+  * ``partition_nodes``       picks between them.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import List
+from dataclasses import dataclass, field
+from typing import List, Optional
 
 import numpy as np
 import torch
 
 
+# ----------------------------------------------------------------------------- geometric
 def rcb_partition(pos: np.ndarray, k: int) -> np.ndarray:
     """Recursive coordinate bisection: part id in [0,k) per node, sizes within 1."""
     pos = np.asarray(pos, dtype=np.float64)
@@ -42,18 +53,258 @@ def rcb_partition(pos: np.ndarray, k: int) -> np.ndarray:
     return part
 
 
+# --------------------------------------------------------------------------- refinement
+def _as_np_edges(edge_index):
+    ei = edge_index.cpu().numpy() if torch.is_tensor(edge_index) else np.asarray(edge_index)
+    return ei[0].astype(np.int64), ei[1].astype(np.int64)
+
+
+def refine_partition(edge_index, part: np.ndarray, k: int, passes: int = 8, imbalance: float = 0.01,
+                     node_w: Optional[np.ndarray] = None, edge_w: Optional[np.ndarray] = None) -> np.ndarray:
+    """Greedy k-way boundary refinement (the uncoarsening step of multilevel k-way partitioning).
+
+    Per pass every boundary node computes, for each adjacent part, gain = (edge weight into that
+    part) - (edge weight into its own part); nodes with a positive best gain move, subject to
+      * direction: in even passes only towards higher part ids, in odd passes towards lower ones,
+        so two neighbours never swap sides in the same pass (the edge cut never increases);
+      * balance: a part never grows beyond (1+imbalance) x average weight nor shrinks below
+        (1-imbalance) x average; the best gains go first.
+    ``edge_index`` is taken as directed pairs; for the symmetric meshes of this repo every
+    undirected edge appears in both directions and counts once from either end."""
+    src, dst = _as_np_edges(edge_index)
+    part = np.asarray(part, dtype=np.int64).copy()
+    n = part.shape[0]
+    nw = np.ones(n, dtype=np.float64) if node_w is None else np.asarray(node_w, dtype=np.float64)
+    ew = np.ones(src.shape[0], dtype=np.float64) if edge_w is None else np.asarray(edge_w, dtype=np.float64)
+    loops = src == dst
+    if loops.any():
+        src, dst, ew = src[~loops], dst[~loops], ew[~loops]
+    avg = nw.sum() / k
+    hi, lo = avg * (1.0 + imbalance) + nw.max(), avg * (1.0 - imbalance) - nw.max()
+    for it in range(passes):
+        ps, pd = part[src], part[dst]
+        cut = ps != pd
+        if not cut.any():
+            break
+        internal = np.bincount(src[~cut], weights=ew[~cut], minlength=n)
+        key = src[cut] * k + pd[cut]
+        uk, inv = np.unique(key, return_inverse=True)
+        ext = np.bincount(inv, weights=ew[cut], minlength=uk.shape[0])
+        node, tgt = uk // k, uk % k
+        gain = ext - internal[node]
+        order = np.lexsort((-gain, node))
+        ns = node[order]
+        first = np.ones(ns.shape[0], dtype=bool)
+        first[1:] = ns[1:] != ns[:-1]
+        cn, ct, cg = ns[first], tgt[order][first], gain[order][first]
+        frm = part[cn]
+        sel = (cg > 0) & ((frm < ct) if (it % 2 == 0) else (frm > ct))
+        if not sel.any():
+            if it % 2 == 1:
+                # both directions exhausted
+                sel_other = (cg > 0)
+                if not sel_other.any():
+                    break
+            continue
+        cn, ct, cg, frm = cn[sel], ct[sel], cg[sel], frm[sel]
+        sizes = np.bincount(part, weights=nw, minlength=k)
+        order = np.argsort(-cg, kind="stable")
+        cn, ct, cg, frm = cn[order], ct[order], cg[order], frm[order]
+        w = nw[cn]
+        # balance caps, best gains first: cumulative weight entering each target / leaving each source
+        accept = np.ones(cn.shape[0], dtype=bool)
+        for b in range(k):
+            into = np.nonzero(ct == b)[0]
+            if into.size:
+                room = hi - sizes[b]
+                accept[into[np.cumsum(w[into]) > room]] = False
+        for a in range(k):
+            out = np.nonzero((frm == a) & accept)[0]
+            if out.size:
+                room = sizes[a] - lo
+                accept[out[np.cumsum(w[out]) > room]] = False
+        if not accept.any():
+            continue
+        part[cn[accept]] = ct[accept]
+    return part
+
+
+# --------------------------------------------------------------------------- multilevel
+def _coarsen(src, dst, ew, nw, rng):
+    """one level of heavy-edge matching (handshake rounds) + contraction"""
+    n = nw.shape[0]
+    match = np.full(n, -1, dtype=np.int64)
+    for _ in range(4):
+        free = match < 0
+        valid = free[src] & free[dst] & (src != dst)
+        if not valid.any():
+            break
+        s, d = src[valid], dst[valid]
+        w = ew[valid] * (1.0 + 1e-3 * rng.random(s.shape[0]))  # random tie-break between equal weights
+        order = np.lexsort((-w, s))
+        so = s[order]
+        first = np.ones(so.shape[0], dtype=bool)
+        first[1:] = so[1:] != so[:-1]
+        pick = np.full(n, -1, dtype=np.int64)
+        pick[so[first]] = d[order][first]
+        u = np.nonzero(pick >= 0)[0]
+        u = u[pick[pick[u]] == u]          # mutual choice
+        u = u[u < pick[u]]
+        match[u] = pick[u]
+        match[pick[u]] = u
+    rep = np.where((match >= 0) & (match < np.arange(n)), match, np.arange(n))  # representative = smaller id
+    uniq, cid = np.unique(rep, return_inverse=True)
+    nc = uniq.shape[0]
+    cs, cd = cid[src], cid[dst]
+    keep = cs != cd
+    key = cs[keep] * nc + cd[keep]
+    uk, inv = np.unique(key, return_inverse=True)
+    cw = np.bincount(inv, weights=ew[keep], minlength=uk.shape[0])
+    cnw = np.bincount(cid, weights=nw, minlength=nc)
+    return cid, uk // nc, uk % nc, cw, cnw
+
+
+def _grow_bisect(src, dst, nw, ids_mask, frac, rng):
+    """graph-growing bisection of the sub-graph ``ids_mask``: BFS from a pseudo-peripheral node until
+    ``frac`` of the weight is collected.  Returns a boolean 'left' mask over all nodes."""
+    n = nw.shape[0]
+    ids = np.nonzero(ids_mask)[0]
+    total = nw[ids].sum()
+    e_in = ids_mask[src] & ids_mask[dst]
+    s, d = src[e_in], dst[e_in]
+    order = np.argsort(s, kind="stable")
+    s, d = s[order], d[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(s, minlength=n), out=rowptr[1:])
+
+    def bfs(start):
+        seen = np.zeros(n, dtype=bool)
+        seen[start] = True
+        frontier = np.array([start], dtype=np.int64)
+        seq = [frontier]
+        while frontier.size:
+            cnt = rowptr[frontier + 1] - rowptr[frontier]
+            tot = int(cnt.sum())
+            if tot == 0:
+                break
+            base = np.repeat(rowptr[frontier], cnt)
+            off = np.arange(tot) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            nb = d[base + off]
+            nb = np.unique(nb[~seen[nb]])
+            if nb.size == 0:
+                break
+            seen[nb] = True
+            frontier = nb
+            seq.append(nb)
+        return np.concatenate(seq)
+
+    start = ids[rng.integers(ids.size)]
+    far = bfs(start)[-1]                       # pseudo-peripheral: the last node of a BFS
+    seq = bfs(far)
+    if seq.size < ids.size:                    # disconnected remainder: append in id order
+        seen = np.zeros(n, dtype=bool)
+        seen[seq] = True
+        seq = np.concatenate([seq, ids[~seen[ids]]])
+    take = np.searchsorted(np.cumsum(nw[seq]), frac * total, side="left") + 1
+    left = np.zeros(n, dtype=bool)
+    left[seq[:take]] = True
+    return left
+
+
+def _initial_partition(src, dst, ew, nw, k, rng):
+    n = nw.shape[0]
+    part = np.zeros(n, dtype=np.int64)
+
+    def rec(mask, first, parts):
+        if parts == 1 or mask.sum() <= 1:
+            part[mask] = first
+            return
+        lp = parts // 2
+        left = _grow_bisect(src, dst, nw, mask, lp / parts, rng)
+        rec(left, first, lp)
+        rec(mask & ~left, first + lp, parts - lp)
+
+    rec(np.ones(n, dtype=bool), 0, k)
+    return part
+
+
+def multilevel_partition(edge_index, num_nodes: int, k: int, seed: int = 0, imbalance: float = 0.02,
+                         coarse_target: Optional[int] = None) -> np.ndarray:
+    """METIS-style multilevel k-way partition from the graph alone (no coordinates)."""
+    if k <= 1:
+        return np.zeros(num_nodes, dtype=np.int64)
+    rng = np.random.default_rng(seed)
+    src, dst = _as_np_edges(edge_index)
+    keep = src != dst
+    key = np.unique(src[keep] * num_nodes + dst[keep])       # coalesce: parallel edges count once
+    src, dst = key // num_nodes, key % num_nodes
+    ew, nw = np.ones(src.shape[0]), np.ones(num_nodes)
+    levels = []
+    target = coarse_target if coarse_target is not None else max(64 * k, 2000)
+    while nw.shape[0] > target:
+        cid, cs, cd, cw, cnw = _coarsen(src, dst, ew, nw, rng)
+        if cnw.shape[0] > 0.95 * nw.shape[0]:               # matching stalled (e.g. star graphs)
+            break
+        levels.append((cid, src, dst, ew, nw))
+        src, dst, ew, nw = cs, cd, cw, cnw
+    best, best_cut = None, None
+    for _ in range(8):  # the coarsest graph is tiny: several graph-growing trials, keep the smallest cut
+        cand = _initial_partition(src, dst, ew, nw, k, rng)
+        cand = refine_partition(np.stack([src, dst]), cand, k, passes=10, imbalance=imbalance, node_w=nw, edge_w=ew)
+        c = float(ew[cand[src] != cand[dst]].sum())
+        if best_cut is None or c < best_cut:
+            best, best_cut = cand, c
+    part = best
+    for cid, fs, fd, few, fnw in reversed(levels):
+        part = part[cid]
+        part = refine_partition(np.stack([fs, fd]), part, k, passes=6, imbalance=imbalance, node_w=fnw, edge_w=few)
+    return part
+
+
+def partition_nodes(pos: Optional[np.ndarray], edge_index, k: int, method: str = "auto", seed: int = 0) -> np.ndarray:
+    """k-way node partition for the large-mesh path.  ``method``: "rcb" (coordinates only), "rcb+refine"
+    (default when ``pos`` is given: bisection, then boundary refinement on the graph), "multilevel"
+    (default without coordinates)."""
+    n = int(pos.shape[0]) if pos is not None else int(_as_np_edges(edge_index)[0].max()) + 1
+    if k <= 1:
+        return np.zeros(n, dtype=np.int64)
+    if method == "auto":
+        method = "rcb+refine" if pos is not None else "multilevel"
+    if method == "rcb":
+        return rcb_partition(pos, k)
+    if method == "rcb+refine":
+        return refine_partition(edge_index, rcb_partition(pos, k), k)
+    if method == "multilevel":
+        return multilevel_partition(edge_index, n, k, seed=seed)
+    raise ValueError(f"unknown partition method '{method}'")
+
+
+# ------------------------------------------------------------------------------ halo plan
 @dataclass
 class RankPlan:
-    """Everything rank ``rank`` needs; all index tensors are int64 on the host."""
+    """Everything rank ``rank`` needs; all index tensors are int64 on the host.
+
+    Local numbering: owned nodes 0..n_own-1 -- first the ``n_interior`` INTERIOR nodes (every
+    in-edge has an owned source), then the boundary nodes (at least one ghost source); ghosts
+    after, grouped by owner rank.  With the local edges sorted by destination (the engine's CSR
+    order) the first ``n_interior_edges`` rows therefore need no remote data: they are computed
+    while the halo exchange of the round is in flight."""
     rank: int
     world: int
-    owned: torch.Tensor          # [n_own] global node ids (ascending)
+    owned: torch.Tensor          # [n_own] global node ids: interior (ascending), then boundary (ascending)
     ghost: torch.Tensor          # [n_ghost] global ids, grouped by owner rank, ascending inside
-    edge_ids: torch.Tensor       # [E_loc] global edge ids of the local edges (dst owned here)
-    edge_index: torch.Tensor     # [2,E_loc] LOCAL numbering: owned = 0..n_own-1, ghosts after
+    edge_ids: torch.Tensor       # [E_loc] global edge ids of the local edges (dst owned here), ascending
+    edge_index: torch.Tensor     # [2,E_loc] LOCAL numbering
     send_idx: torch.Tensor       # local owned indices to send, concatenated by peer rank
     send_counts: List[int]       # rows sent to each peer
     recv_counts: List[int]       # ghost rows received from each peer (== layout of ``ghost``)
+    n_interior: int = 0          # owned nodes without a ghost in-neighbour
+    n_interior_edges: int = 0    # local edges whose destination is an interior node
+    # the send list grouped by node, for the atomics-free backward (ghost gradients summed into owners
+    # in a fixed order): node send_nodes[j] receives rows send_perm[send_rowptr[j]:send_rowptr[j+1]]
+    send_nodes: torch.Tensor = field(default_factory=lambda: torch.zeros(0, dtype=torch.int64))
+    send_rowptr: torch.Tensor = field(default_factory=lambda: torch.zeros(1, dtype=torch.int64))
+    send_perm: torch.Tensor = field(default_factory=lambda: torch.zeros(0, dtype=torch.int64))
 
     @property
     def n_own(self) -> int:
@@ -67,35 +318,52 @@ class RankPlan:
 def build_rank_plan(edge_index: torch.Tensor, part: np.ndarray, rank: int, world: int) -> RankPlan:
     ei = edge_index.cpu().numpy()
     part = np.asarray(part)
+    n = part.shape[0]
     src, dst = ei[0], ei[1]
-    owned = np.nonzero(part == rank)[0]
-    mine = np.nonzero(part[dst] == rank)[0]  # edges whose destination is owned here
-    gsrc = src[mine]
-    ghost_all = np.unique(gsrc[part[gsrc] != rank])
+    owned_mask = part == rank
+    mine = np.nonzero(owned_mask[dst])[0]    # edges whose destination is owned here
+    gsrc, gdst = src[mine], dst[mine]
+    remote = ~owned_mask[gsrc]
+    ghost_all = np.unique(gsrc[remote])
     order = np.lexsort((ghost_all, part[ghost_all]))  # by owner rank, then id
     ghost = ghost_all[order]
-    recv_counts = [int(np.sum(part[ghost] == q)) for q in range(world)]
-    # local numbering
-    loc = np.full(part.shape[0], -1, dtype=np.int64)
+    recv_counts = np.bincount(part[ghost], minlength=world).astype(int).tolist() if ghost.size else [0] * world
+    # owned nodes: interior first (no in-edge from a ghost), then boundary
+    is_bnd = np.zeros(n, dtype=bool)
+    is_bnd[gdst[remote]] = True
+    owned_all = np.nonzero(owned_mask)[0]
+    interior, boundary = owned_all[~is_bnd[owned_all]], owned_all[is_bnd[owned_all]]
+    owned = np.concatenate([interior, boundary])
+    loc = np.full(n, -1, dtype=np.int64)
     loc[owned] = np.arange(owned.size)
     loc[ghost] = owned.size + np.arange(ghost.size)
-    le = np.stack([loc[src[mine]], loc[dst[mine]]], axis=0)
-    # what the peers need from me: the ghosts of rank q that I own, in q's ghost order
-    send_idx, send_counts = [], []
-    for q in range(world):
-        if q == rank:
-            send_counts.append(0)
-            continue
-        qe = np.nonzero(part[dst] == q)[0]
-        qs = src[qe]
-        need = np.unique(qs[part[qs] == rank])  # ascending id == q's order inside my group
-        send_idx.append(loc[need])
-        send_counts.append(int(need.size))
-    send_idx = np.concatenate(send_idx) if send_idx else np.zeros(0, dtype=np.int64)
+    le = np.stack([loc[gsrc], loc[gdst]], axis=0)
+    n_int_edges = int(np.count_nonzero(~is_bnd[gdst]))
+    # what the peers need from me: the ghosts of rank q that I own, in q's ghost order (ascending id)
+    cut = owned_mask[src] & ~owned_mask[dst]  # my nodes feeding edges that live elsewhere
+    cs, cq = src[cut], part[dst[cut]]
+    key = np.unique(cq.astype(np.int64) * n + cs)
+    sq, sn = key // n, key % n
+    send_idx = loc[sn]
+    send_counts = np.bincount(sq, minlength=world).astype(int).tolist() if key.size else [0] * world
+    # send list grouped by node (stable: ascending position inside a node's group)
+    perm = np.argsort(send_idx, kind="stable")
+    sorted_nodes = send_idx[perm]
+    uniq, counts = np.unique(sorted_nodes, return_counts=True)
+    rowptr = np.zeros(uniq.size + 1, dtype=np.int64)
+    np.cumsum(counts, out=rowptr[1:])
     return RankPlan(rank, world, torch.from_numpy(owned), torch.from_numpy(ghost), torch.from_numpy(mine),
-                    torch.from_numpy(le), torch.from_numpy(send_idx.astype(np.int64)), send_counts, recv_counts)
+                    torch.from_numpy(le), torch.from_numpy(send_idx.astype(np.int64)), send_counts, recv_counts,
+                    n_interior=int(interior.size), n_interior_edges=n_int_edges,
+                    send_nodes=torch.from_numpy(uniq.astype(np.int64)), send_rowptr=torch.from_numpy(rowptr),
+                    send_perm=torch.from_numpy(perm.astype(np.int64)))
 
 
 def edge_cut(edge_index: torch.Tensor, part: np.ndarray) -> float:
-    ei = edge_index.cpu().numpy()
+    ei = edge_index.cpu().numpy() if torch.is_tensor(edge_index) else np.asarray(edge_index)
     return float(np.mean(part[ei[0]] != part[ei[1]]))
+
+
+def imbalance_of(part: np.ndarray, k: int) -> float:
+    sizes = np.bincount(part, minlength=k)
+    return float(sizes.max() / (part.shape[0] / k) - 1.0)

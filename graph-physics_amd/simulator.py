@@ -41,6 +41,8 @@ class Simulator(nn.Module):
         self.device = device
         self.fused = True  # engine kernels for the pre / post processing of CUDA tensors
         self._ws = None
+        self._type_err = None      # device flag: node type outside [0, 9) seen by the fused kernels
+        self._types_checked = False
 
     # ------------------------------------------------------------------ fused path (N1)
     def _can_fuse(self, inputs) -> bool:
@@ -51,12 +53,37 @@ class Simulator(nn.Module):
                 and (inputs.edge_attr is None or inputs.edge_attr.dtype == torch.float32)
                 and (getattr(inputs, "y", None) is None or inputs.y.dtype == torch.float32))
 
+    def _check_widths(self, x, y, ea):
+        """The shape errors the reference raises from its slicing / ``cat`` / broadcasting
+        (simulator.py:86-143, layers.py:331-349), raised here before the fused kernels index with
+        these widths."""
+        nf = self.feature_index_end - self.feature_index_start
+        if nf < 0 or self.feature_index_start < 0 or self.feature_index_end > x.shape[1]:
+            raise ValueError(f"feature columns [{self.feature_index_start}, {self.feature_index_end}) are outside x (width {x.shape[1]})")
+        if not (0 <= self.node_type_index < x.shape[1]):
+            raise ValueError(f"node_type_index {self.node_type_index} is outside x (width {x.shape[1]})")
+        if nf + NodeType.SIZE != self.node_input_size:
+            raise ValueError(f"node features have {nf} + {NodeType.SIZE} columns but node_input_size is {self.node_input_size} "
+                             "(the node normaliser's width)")
+        if self.output_index_end - self.output_index_start != self.output_size:
+            raise ValueError("output_index_end - output_index_start differs from output_size")
+        if y is not None:
+            if self.output_index_start < 0 or self.output_index_start + self.output_size > x.shape[1]:
+                raise ValueError(f"output columns [{self.output_index_start}, {self.output_index_start + self.output_size}) are outside x")
+            if y.shape[1] < self.output_size:
+                raise ValueError(f"y has {y.shape[1]} columns, output_size is {self.output_size}")
+            if y.shape[0] != x.shape[0]:
+                raise ValueError("x and y have different row counts")
+        if ea is not None and ea.shape[1] != self.edge_input_size:
+            raise ValueError(f"edge_attr has {ea.shape[1]} columns, edge_input_size is {self.edge_input_size}")
+
     def _desc(self, inputs, is_training: bool):
         d = _capi.SimDesc()
         x = inputs.x.contiguous()
         y = getattr(inputs, "y", None)
         y = y.contiguous() if y is not None else None
         ea = inputs.edge_attr.contiguous() if (self._edge_normalizer is not None and inputs.edge_attr is not None) else None
+        self._check_widths(x, y, ea)
         keep = [x, y, ea]
         d.N, d.E = x.shape[0], (ea.shape[0] if ea is not None else 0)
         d.x, d.x_w = x.data_ptr(), x.shape[1]
@@ -71,16 +98,26 @@ class Simulator(nn.Module):
                 nz = self._node_normalizer  # never dereferenced: edge_w == 0
             d.acc_sum[s], d.acc_sumsq[s] = nz._acc_sum.data_ptr(), nz._acc_sum_squared.data_ptr()
             d.acc_count[s], d.num_acc[s] = nz._acc_count.data_ptr(), nz._num_accumulations.data_ptr()
-            acc = False
-            if is_training and here and norms[s] is not None:
-                if nz._host_num_acc is None:
-                    nz._host_num_acc = int(nz._num_accumulations.item())
-                if nz._host_num_acc < nz._max_accumulations:  # Normalizer.forward, layers.py:345-349
-                    acc = True
-                    nz._host_num_acc += 1
+            d.norm_w[s] = nz._acc_sum.shape[1]
+            # Normalizer.forward (layers.py:345-349) accumulates in train() while the DEVICE counter is
+            # below max_accumulations: the kernels read it themselves (no host sync, and a captured
+            # hipGraph stops accumulating at the same step the reference does)
+            acc = bool(is_training and here and norms[s] is not None)
+            if acc:
+                nz._host_num_acc = None  # the torch path's host mirror is stale from here on
             d.accumulate[s] = int(acc)
+        d.max_accumulations = float(self._output_normalizer._max_accumulations)
         d.std_eps = float(self._output_normalizer._std_epsilon_value)
+        if self._type_err is None or self._type_err.device != x.device:
+            self._type_err = torch.zeros(1, dtype=torch.int32, device=x.device)
+        d.type_err = self._type_err.data_ptr()
         return d, keep, (x, y, ea)
+
+    def check_node_types(self) -> None:
+        """Raise if a fused call met a node-type code outside [0, NodeType.SIZE) (``F.one_hot``
+        raises there).  Synchronises; the first fused call of a Simulator checks itself."""
+        if self._type_err is not None and int(self._type_err.item()) != 0:
+            raise RuntimeError(f"node type codes must lie in [0, {NodeType.SIZE}) (class values must be smaller than num_classes)")
 
     def _build_input_graph_fused(self, inputs, is_training: bool):
         dev = inputs.x.device
@@ -98,6 +135,9 @@ class Simulator(nn.Module):
         with torch.cuda.device(dev):
             rc = L.mgn_sim_pre(C.byref(d), self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
         _capi.check(rc, "mgn_sim_pre", prep=True)
+        if not self._types_checked and not torch.cuda.is_current_stream_capturing():
+            self._types_checked = True  # one sync, on the first step only
+            self.check_node_types()
         graph = Graph(x=xn, pos=inputs.pos, edge_attr=en, edge_index=inputs.edge_index)
         topo = getattr(inputs, "mgn_topology", None)
         if topo is not None:

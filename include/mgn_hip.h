@@ -291,9 +291,11 @@ int mgn_edge_features(const float* pos, int D, const int64_t* src, const int64_t
  *   0 node features  cat[x[:, feat_start:feat_end], one_hot(x[:, type_idx], 9)]
  *   1 target delta   y[:, 0:out_w] - x[:, out_start:out_start+out_w]
  *   2 edge features  edge_attr
- * accumulate[s] != 0: first add this batch's column sums / sums of squares / row count to the
- * running buffers (two-stage, atomics-free), then normalise with the updated statistics --
- * Normalizer.forward's order.  out pointers may be NULL (stream skipped). */
+ * accumulate[s] != 0 (and *num_acc[s] < max_accumulations): first add this batch's column sums /
+ * sums of squares / row count to the running buffers (two-stage, atomics-free), then normalise
+ * with the updated statistics -- Normalizer.forward's order.  out pointers may be NULL (stream
+ * skipped).  Returns 1 when a width is inconsistent: feat_end / out_start+out_w / type_idx beyond
+ * x_w, out_w beyond y_w, or a stream width different from norm_w[s]. */
 #define MGN_NODE_TYPES 9     /* NodeType.SIZE (graphphysics/utils/nodetype.py) */
 #define MGN_NODE_NORMAL 0
 #define MGN_NODE_OUTFLOW 5
@@ -307,6 +309,16 @@ typedef struct {
   int accumulate[3];
   float std_eps;
   float* node_out; float* target_out; float* edge_out;
+  /* widths of the three normalisers' acc_sum / acc_sumsq buffers; mgn_sim_pre rejects (code 1)
+   * a stream whose width differs -- the reference raises a shape error there. */
+  int norm_w[3];
+  /* Normalizer._max_accumulations (layers.py:311,345-349): accumulate[s] asks for accumulation,
+   * the kernels decide from the DEVICE counter *num_acc[s] < max_accumulations -- a hipGraph
+   * replay of a captured training step therefore stops accumulating like the reference does. */
+  float max_accumulations;
+  /* optional device int: set to 1 when a node-type code is outside [0, MGN_NODE_TYPES) (F.one_hot
+   * raises there); never cleared by the engine. */
+  int* type_err;
 } mgn_sim_desc;
 size_t mgn_sim_workspace_bytes(void);
 int mgn_sim_pre(const mgn_sim_desc* desc, void* ws, size_t ws_bytes, void* stream);

@@ -47,8 +47,34 @@ def rms_norm(x: torch.Tensor, scale: torch.Tensor, eps: float = 1e-8) -> torch.T
 
 
 # --------------------------------------------------------------------------- R2
-def mlp(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str, act: str = "relu") -> torch.Tensor:
+#: bf16-mixed evaluation (set by :func:`bf16_mixed`).  The reference trains with Lightning
+#: ``precision="bf16-mixed"`` when ``training.enable_vram_optimizations`` is set (train.py:74-78,
+#: 268-293) -- on its target (a GPU) that is ``torch.autocast("cuda", torch.bfloat16)``, whose op
+#: lists (torch.amp docs, "CUDA Ops that can autocast to float16 / float32") cast ``linear`` inputs,
+#: weight and bias to bf16 (bf16 result, fp32 accumulation inside the GEMM) and run ``norm`` in
+#: fp32; everything else follows type promotion.  CPU autocast has different lists (``norm`` stays
+#: bf16 there), so the oracle states the CUDA semantic explicitly instead of relying on
+#: ``torch.autocast("cpu")``: Linear in bf16, activation in bf16, RMSNorm on the bf16 result in
+#: fp32, residual stream / aggregation / loss in fp32.
+_BF16_MIXED = False
+
+
+class bf16_mixed:
+    """context manager: evaluate ``mlp`` (and everything built on it) with the bf16-mixed semantic"""
+
+    def __enter__(self):
+        global _BF16_MIXED
+        self._old, _BF16_MIXED = _BF16_MIXED, True
+
+    def __exit__(self, *a):
+        global _BF16_MIXED
+        _BF16_MIXED = self._old
+
+
+def mlp(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str, act: str = "relu",
+        pre_out: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
     """build_mlp(nb_of_layers=4) forward, graphphysics/models/layers.py:163-210.
+    ``pre_out`` (tests): receives the pre-activations of the three hidden layers.
 
     Sequential entries 0,2,4,6 are nn.Linear (y = x W^T + b, W[out,in]); 1,3,5
     are the activation (ReLU unless the global SiLU flag is set,
@@ -58,9 +84,17 @@ def mlp(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str, act: str = "re
     f = torch.relu if act == "relu" else torch.nn.functional.silu
     h = x
     for i in (0, 2, 4, 6):
-        h = torch.nn.functional.linear(h, p[f"{prefix}{i}.weight"], p[f"{prefix}{i}.bias"])
+        W, b = p[f"{prefix}{i}.weight"], p[f"{prefix}{i}.bias"]
+        if _BF16_MIXED:
+            h = torch.nn.functional.linear(h.to(torch.bfloat16), W.to(torch.bfloat16), b.to(torch.bfloat16))
+        else:
+            h = torch.nn.functional.linear(h, W, b)
         if i != 6:
+            if pre_out is not None:
+                pre_out.append(h.detach())
             h = f(h)
+    if _BF16_MIXED:
+        h = h.float()  # norm runs in fp32 under CUDA autocast; bf16 / fp32 promotes to fp32 (exact widening)
     key = f"{prefix}7.scale"
     if key in p:
         h = rms_norm(h, p[key])
@@ -90,13 +124,15 @@ def graph_net_block(
     row, col = edge_index[0], edge_index[1]
     x_i = x[col]
     x_j = x[row]
-    m = mlp(torch.cat([e, x_i, x_j], dim=-1), p, prefix + "edge_block.", act)
+    pre_e: Optional[List[torch.Tensor]] = [] if return_intermediates else None
+    pre_n: Optional[List[torch.Tensor]] = [] if return_intermediates else None
+    m = mlp(torch.cat([e, x_i, x_j], dim=-1), p, prefix + "edge_block.", act, pre_e)
     agg = torch.zeros(x.shape[0], m.shape[1], dtype=m.dtype).index_add_(0, col, m)
-    upd = mlp(torch.cat([x, agg], dim=-1), p, prefix + "node_block.", act)
+    upd = mlp(torch.cat([x, agg], dim=-1), p, prefix + "node_block.", act, pre_n)
     e_new = e + m
     x_new = x + upd
     if return_intermediates:
-        return x_new, e_new, {"m": m, "agg": agg, "upd": upd}
+        return x_new, e_new, {"m": m, "agg": agg, "upd": upd, "edge_pre": pre_e, "node_pre": pre_n}
     return x_new, e_new
 
 
@@ -110,6 +146,7 @@ def epd_forward(
     only_processor: bool = False,
     act: str = "relu",
     per_round: Optional[List[torch.Tensor]] = None,
+    intermediates: Optional[List[dict]] = None,
 ) -> torch.Tensor:
     """EncodeProcessDecode.forward, graphphysics/models/processors.py:162-215
     (rope / gate / temporal block off -- the defaults of every shipped JSON)."""
@@ -119,7 +156,11 @@ def epd_forward(
         x = mlp(x_in, p, "nodes_encoder.", act)  # processors.py:179
         e = mlp(edge_attr_in, p, "edges_encoder.", act)  # processors.py:180
     for i in range(message_passing_num):  # processors.py:193-202
-        x, e = graph_net_block(x, e, edge_index, p, f"processor_list.{i}.", act)
+        if intermediates is not None:
+            x, e, inter = graph_net_block(x, e, edge_index, p, f"processor_list.{i}.", act, return_intermediates=True)
+            intermediates.append(inter)
+        else:
+            x, e = graph_net_block(x, e, edge_index, p, f"processor_list.{i}.", act)
         if per_round is not None:
             per_round.append(x)
     if only_processor:
@@ -223,13 +264,17 @@ def train_steps(
     lr: float,
     warmup: int,
     num_steps: int,
+    mixed: bool = False,
+    grads_out: Optional[List[Dict[str, torch.Tensor]]] = None,
 ):
     """Reference training semantics: LightningModule.training_step
     (training/lightning_module.py:270-320) + configure_optimizers (:494-511) +
     Trainer(gradient_clip_val=1.0) (train.py:288).
 
     ``params`` are leaf tensors (requires_grad) updated in place.  Returns the
-    list of (loss, grad_norm_before_clip) per step.
+    list of (loss, grad_norm_before_clip) per step.  ``mixed``: the bf16-mixed semantic
+    (``training.enable_vram_optimizations``); parameters, optimiser state and the
+    normalisers stay fp32 as under Lightning's mixed precision.
     """
     names = list(params.keys())
     leaves = [params[k] for k in names]
@@ -239,10 +284,16 @@ def train_steps(
         for g in opt.param_groups:  # LR for THIS step = base_lr * factor(last_epoch=step)
             g["lr"] = lr * lr_factor(step, warmup, num_steps)
         xn, en, target = sim.build_input(x, y, edge_attr, training=True)
-        out = epd_forward(xn, en, edge_index, params, message_passing_num)
+        if mixed:  # Lightning bf16-mixed: forward + loss inside autocast (train.py:74-78,268-293)
+            with bf16_mixed():
+                out = epd_forward(xn, en, edge_index, params, message_passing_num)
+        else:
+            out = epd_forward(xn, en, edge_index, params, message_passing_num)
         loss = l2_loss(out, target, x[:, sim.ix["node_type_index"]])
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if grads_out is not None:  # un-clipped gradients of this step (tests)
+            grads_out.append({k: params[k].grad.detach().clone() for k in names})
         gn = torch.nn.utils.clip_grad_norm_(leaves, 1.0)
         opt.step()
         log.append((float(loss.detach()), float(gn)))
