@@ -53,6 +53,8 @@ class MlpFwdArgs(C.Structure):
         ("precision", C.c_int),
         ("out_relu", C.c_int),
         ("seg_key", C.c_void_p), ("seg_rowptr", C.c_void_p), ("seg_out", _f32p), ("seg_part", _f32p),
+        ("act", C.c_int),
+        ("saveZ", _f32p * MAX_LAYERS),
     ]
 
 
@@ -83,6 +85,8 @@ class MlpBwdArgs(C.Structure):
         ("front_resid", _f32p),
         ("front_out", _f32p),
         ("defer_reduce", C.c_int),
+        ("act", C.c_int),
+        ("Zs", _f32p * MAX_LAYERS),
     ]
 
 
@@ -165,6 +169,14 @@ SYMBOLS = {
     "mgn_clip_adamw_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(OptTensor)]),
     "mgn_clip_adamw": (C.c_int, [C.c_int, C.POINTER(OptTensor), C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "mgn_halo_unpack_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "mgn_gate_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgn_gate_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgn_rope_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_int, C.c_void_p, C.c_void_p]),
+    "mgn_rope_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgn_prep_last_error": (C.c_char_p, []),
 }
 

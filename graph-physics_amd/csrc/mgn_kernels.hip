@@ -235,6 +235,14 @@ __device__ __forceinline__ float colsum16(float v) {
   return v;
 }
 
+// SiLU (layers.py:132-160, nn.SiLU): z * sigmoid(z); its derivative sigma * (1 + z * (1 - sigma)).
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + expf(-z)); }
+__device__ __forceinline__ float dsilu_f(float z) {
+  const float sg = 1.0f / (1.0f + expf(-z));
+  return sg * (1.0f + z * (1.0f - sg));
+}
+__device__ __forceinline__ float act_f(float z, int act) { return act == MGN_ACT_SILU ? silu_f(z) : fmaxf(z, 0.f); }
+
 // ========================================================================= forward
 template <int HB, int MT, bool RAGGED>
 __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_mlp_fwd_args a) {
@@ -294,12 +302,13 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_ml
         for (int t = 0; t < MT; ++t) nx[t] = sp + (ip ? (long)ip[mm[t]] : mm[t]) * H + 4 * g;
       }
     } else {  // layer l >= 1: the accumulator IS the next B operand
+      if (a.act == MGN_ACT_SILU && a.saveZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.saveZ[l - 1], acc, H, mm, valid, g);
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int ib = 0; ib < HB; ++ib)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) in[t][ib][r] = fmaxf(acc[t][ib][r], 0.f);
+          for (int r = 0; r < 4; ++r) in[t][ib][r] = act_f(acc[t][ib][r], a.act);
       if (a.saveH[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.saveH[l - 1], in, H, mm, valid, g);
       const int nib = (l == a.NL - 1) ? nib_last : HB;
       init_bias<HB, MT>(acc, a.b[l], nib, g);
@@ -358,7 +367,18 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_ml
 #pragma unroll
       for (int ib = 0; ib < HB; ++ib)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][ib][r] = fmaxf(acc[t][ib][r], 0.f);
+        for (int r = 0; r < 4; ++r) acc[t][ib][r] = act_f(acc[t][ib][r], a.act);
+    if (a.saveM[0] != nullptr) {  // ReLU mask bits in the packed kernels' layout (saveM of mgn_hip.h)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bits |= (acc[t][ib][r] > 0.f) ? (1u << (4 * ib + r)) : 0u;
+        if (valid[t]) a.saveM[0][mm[t] * 4 + g] = bits;
+      }
+    }
   }
   store_tl<HB, MT, RAGGED>(a.out, acc, a.out_w, mm, valid, g);
 }
@@ -469,13 +489,15 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
 #pragma unroll
         for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
       gemm_tl<HB, MT>(acc, dz, a.WT[l], 16 * nkb_last, HB, nkb_last, c, g);
-      load_tl<HB, MT, RAGGED>(dz, a.Hs[l - 1], nullptr, H, mm, g, nkb);
+      load_tl<HB, MT, RAGGED>(dz, (a.act == MGN_ACT_SILU) ? a.Zs[l - 1] : a.Hs[l - 1], nullptr, H, mm, g, nkb);
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int ib = 0; ib < HB; ++ib)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dz[t][ib][r] = (valid[t] && dz[t][ib][r] > 0.f) ? acc[t][ib][r] : 0.f;
+          for (int r = 0; r < 4; ++r)
+            dz[t][ib][r] = !valid[t] ? 0.f : (a.act == MGN_ACT_SILU) ? acc[t][ib][r] * dsilu_f(dz[t][ib][r])
+                                                                       : (dz[t][ib][r] > 0.f ? acc[t][ib][r] : 0.f);
       if (a.dZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.dZ[l - 1], dz, H, mm, valid, g);
       if (a.db[l - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
       --l;
@@ -493,8 +515,9 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
 #pragma unroll
           for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
         Wp = a.WT[l];
+        const float* hz = (a.act == MGN_ACT_SILU) ? a.Zs[l - 1] : a.Hs[l - 1];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) nx[t] = a.Hs[l - 1] + mm[t] * H + 4 * g;  // dz <- h_l on the way out
+        for (int t = 0; t < MT; ++t) nx[t] = hz + mm[t] * H + 4 * g;  // dz <- h_l (ReLU) / z_l (SiLU) on the way out
       } else {
         if (a.din_resid[q] != nullptr) {
           load_tl<HB, MT, RAGGED>(acc, a.din_resid[q], nullptr, H, mm, g, nkb);
@@ -523,7 +546,9 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
 #pragma unroll
           for (int ib = 0; ib < HB; ++ib)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dz[t][ib][r] = (valid[t] && dz[t][ib][r] > 0.f) ? acc[t][ib][r] : 0.f;
+            for (int r = 0; r < 4; ++r)
+              dz[t][ib][r] = !valid[t] ? 0.f : (a.act == MGN_ACT_SILU) ? acc[t][ib][r] * dsilu_f(dz[t][ib][r])
+                                                                         : (dz[t][ib][r] > 0.f ? acc[t][ib][r] : 0.f);
         if (a.dZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.dZ[l - 1], dz, H, mm, valid, g);
         if (a.db[l - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
         --l;
@@ -1826,6 +1851,10 @@ static bool fwd_x6(const mgn_mlp_fwd_args& a) {
     if (a.wpk[u] == nullptr) return false;
   return true;
 }
+template <int TERMS, int NW, int ACT>
+static int set_fwd_x6_attr() {
+  return hipFuncSetAttribute((const void*)k_mlp_fwd_x6<TERMS, NW, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(NW)) != hipSuccess;
+}
 
 template <int HB>
 static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
@@ -1836,12 +1865,13 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
     int nw = (a.M >= 128 * 256) ? X6_FWD_NW_LARGE : 4;
     if (const char* e = getenv("MGN_NW")) nw = (atoi(e) == 8) ? 8 : 4;
     if (a.seg_out != nullptr) nw = 4;  // the partials are indexed by 4-wave tiles
+    const bool silu = (a.act == MGN_ACT_SILU);
+    if (silu) nw = 4;  // the SiLU variant is built for 4-wave workgroups only
     static thread_local bool attr_done = false;
     if (!attr_done) {
-      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<6, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(4)) != hipSuccess) return 1;
-      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(4)) != hipSuccess) return 1;
-      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(8)) != hipSuccess) return 1;
-      if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(8)) != hipSuccess) return 1;
+      if (set_fwd_x6_attr<6, 4, 0>() || set_fwd_x6_attr<1, 4, 0>() || set_fwd_x6_attr<6, 8, 0>() || set_fwd_x6_attr<1, 8, 0>() ||
+          set_fwd_x6_attr<6, 4, 1>() || set_fwd_x6_attr<1, 4, 1>())
+        return 1;
       attr_done = true;
     }
     const int rows = 16 * nw;
@@ -1851,16 +1881,21 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
     if (const char* e = getenv("MGN_GRID")) {  // occupancy experiments: fewer persistent workgroups
       if (atoi(e) > 0 && (unsigned)atoi(e) < grid) grid = (unsigned)atoi(e);
     }
-    if (nw == 8) {
+    if (silu) {
       if (a.precision == 1)
-        hipLaunchKernelGGL((k_mlp_fwd_x6<1, 8>), dim3(grid), dim3(512), X6_FWD_LDS_BYTES(8), s, a);
+        hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 1>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
       else
-        hipLaunchKernelGGL((k_mlp_fwd_x6<6, 8>), dim3(grid), dim3(512), X6_FWD_LDS_BYTES(8), s, a);
+        hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 1>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+    } else if (nw == 8) {
+      if (a.precision == 1)
+        hipLaunchKernelGGL((k_mlp_fwd_x6<1, 8, 0>), dim3(grid), dim3(512), X6_FWD_LDS_BYTES(8), s, a);
+      else
+        hipLaunchKernelGGL((k_mlp_fwd_x6<6, 8, 0>), dim3(grid), dim3(512), X6_FWD_LDS_BYTES(8), s, a);
     } else {
       if (a.precision == 1)
-        hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+        hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 0>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
       else
-        hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+        hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
     }
     return 0;
   }
@@ -1895,6 +1930,12 @@ static bool bwd_x6(const mgn_mlp_bwd_args& a) {
   if (a.n_front > 0 && a.dOut2 != nullptr) return false;
   for (int u = 0; u < G; ++u)
     if (a.wpk[u] == nullptr) return false;
+  if (a.act == MGN_ACT_SILU) {
+    if (a.n_front > 0 || (a.n_din == 0 && a.dOut2 != nullptr)) return false;  // see k_mlp_bwd_x6: pd2 carries the z rows
+    for (int l = 1; l < a.NL; ++l)
+      if (a.Zs[l - 1] == nullptr) return false;
+    return true;
+  }
   for (int l = 1; l < a.NL; ++l)
     if (a.Ms[l - 1] == nullptr) return false;  // the split-bf16 chain reads ReLU masks as bits
   return true;
@@ -1907,25 +1948,32 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
     static thread_local bool attr_done = false;
     if (!attr_done) {
       const int lds = X6_BWD_LDS_BYTES(LDS_MAX_NL);
-      if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return 1;
       attr_done = true;
     }
     const size_t lds = X6_BWD_LDS_BYTES(a.NL);
     const bool front = a.n_front > 0;
-    if (a.precision == 1) {
-      if (front)
-        hipLaunchKernelGGL((k_mlp_bwd_x6<1, true>), dim3(p.grid), dim3(256), lds, s, a);
+    if (a.act == MGN_ACT_SILU) {
+      if (a.precision == 1)
+        hipLaunchKernelGGL((k_mlp_bwd_x6<1, false, 1>), dim3(p.grid), dim3(256), lds, s, a);
       else
-        hipLaunchKernelGGL((k_mlp_bwd_x6<1, false>), dim3(p.grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((k_mlp_bwd_x6<6, false, 1>), dim3(p.grid), dim3(256), lds, s, a);
+    } else if (a.precision == 1) {
+      if (front)
+        hipLaunchKernelGGL((k_mlp_bwd_x6<1, true, 0>), dim3(p.grid), dim3(256), lds, s, a);
+      else
+        hipLaunchKernelGGL((k_mlp_bwd_x6<1, false, 0>), dim3(p.grid), dim3(256), lds, s, a);
     } else {
       if (front)
-        hipLaunchKernelGGL((k_mlp_bwd_x6<6, true>), dim3(p.grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((k_mlp_bwd_x6<6, true, 0>), dim3(p.grid), dim3(256), lds, s, a);
       else
-        hipLaunchKernelGGL((k_mlp_bwd_x6<6, false>), dim3(p.grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((k_mlp_bwd_x6<6, false, 0>), dim3(p.grid), dim3(256), lds, s, a);
     }
     return 0;
   }
@@ -2038,9 +2086,12 @@ int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream) {
   if (a.precision != 0 && a.precision != 1) return fail(1, "mgn_mlp_fwd: precision must be 0 (fp32-grade) or 1 (bf16)");
   if (a.seg_out != nullptr && !(plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && fwd_x6(a)))
     return fail(1, "mgn_mlp_fwd: the fused segment sum needs the packed split-bf16 path (and seg_key / seg_rowptr / seg_part, no post-products)");
-  if (a.out_relu && (a.scale != nullptr || a.resid != nullptr || a.y_out != nullptr || a.wpk[0] != nullptr ||
+  if (a.out_relu && (a.scale != nullptr || a.resid != nullptr || a.wpk[0] != nullptr ||
                      plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds))
     return fail(1, "mgn_mlp_fwd: out_relu is for a plain ragged-input launch (no norm / residual / packed path)");
+  if (a.act != MGN_ACT_RELU && a.act != MGN_ACT_SILU) return fail(1, "mgn_mlp_fwd: act must be MGN_ACT_RELU or MGN_ACT_SILU");
+  if (a.act == MGN_ACT_SILU && plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && !fwd_x6(a) && a.NL > 1)
+    return fail(1, "mgn_mlp_fwd: SiLU is not available on the exact-fp32 LDS generation (pass packed weights)");
   if (a.precision == 1 && !(plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && fwd_x6(a)))
     return fail(1, "mgn_mlp_fwd: bf16 matrix mode needs the packed split-bf16 path (H = 128, full widths, wpk)");
   if (a.nphase < 1 || a.nphase > MGN_MAX_PHASES) return fail(1, "mgn_mlp_fwd: nphase out of range");
@@ -2076,6 +2127,13 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   if (a.n_din < 0 || a.n_din > MGN_MAX_PHASES) return fail(1, "mgn_mlp_bwd: n_din out of range");
   if (a.n_din > 1 && a.dZ[0] == nullptr) return fail(1, "mgn_mlp_bwd: n_din > 1 needs dZ[0]");
   if (a.precision != 0 && a.precision != 1) return fail(1, "mgn_mlp_bwd: precision must be 0 (fp32-grade) or 1 (bf16)");
+  if (a.act != MGN_ACT_RELU && a.act != MGN_ACT_SILU) return fail(1, "mgn_mlp_bwd: act must be MGN_ACT_RELU or MGN_ACT_SILU");
+  if (a.act == MGN_ACT_SILU) {
+    for (int l = 1; l < a.NL; ++l)
+      if (a.Zs[l - 1] == nullptr) return fail(1, "mgn_mlp_bwd: SiLU needs the saved pre-activations Zs[]");
+    if (plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && !bwd_x6(a))
+      return fail(1, "mgn_mlp_bwd: SiLU is not available on the exact-fp32 LDS generation (pass packed weights)");
+  }
   if (a.n_front != 0 && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
     return fail(1, "mgn_mlp_bwd: the front stage needs the packed split-bf16 path (H = 128, full widths, wpk, Ms, no dOut2)");
   if (a.precision == 1 && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))

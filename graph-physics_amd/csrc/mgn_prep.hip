@@ -580,3 +580,193 @@ extern "C" int mgn_clip_adamw(int n, const mgn_opt_tensor* t, float max_norm, co
   }
   return pcheck("mgn_clip_adamw");
 }
+
+// ============================================================== halo exchange (8e)
+// The partitioned large-mesh path exchanges one [rows, H] block per round and neighbour: the send
+// rows are packed straight from the node kernel's output (mgn_gather_rows) and, in the backward
+// pass, the ghost-row gradients that come back are summed into their owners in a fixed order
+// (mgn_halo_unpack_add: the send list grouped by node, no atomics => bit-deterministic gradients).
+// Both are HBM-bound row copies: 16-byte lanes, H/4 lanes per row.
+__global__ void __launch_bounds__(256) k_gather_rows(const float* __restrict__ src, const int32_t* __restrict__ idx, long n, int H,
+                                                    float* __restrict__ out) {
+  const int lpr = H / 4;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long r = t / lpr;
+  const int l = (int)(t % lpr);
+  if (r >= n) return;
+  const float4 v = *(const float4*)(src + (size_t)idx[r] * H + 4 * l);
+  *(float4*)(out + (size_t)r * H + 4 * l) = v;
+}
+
+extern "C" int mgn_gather_rows(const float* src, const int32_t* idx, int64_t n, int H, float* out, void* stream) {
+  if (n < 0 || H < 4 || (H & 3)) return pfail(1, "mgn_gather_rows: bad arguments");
+  if (n == 0) return 0;
+  const long lanes = (long)n * (H / 4);
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, idx, (long)n, H, out);
+  return pcheck("mgn_gather_rows");
+}
+
+// dst[nodes[j], :] += sum_{k = rowptr[j]}^{rowptr[j+1]-1} rows[perm[k], :]     (k ascending: fixed order)
+__global__ void __launch_bounds__(256) k_halo_unpack_add(const float* __restrict__ rows, const int32_t* __restrict__ nodes,
+                                                        const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm, long n_nodes,
+                                                        int H, float* __restrict__ dst) {
+  const int lpr = H / 4;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long j = t / lpr;
+  const int l = (int)(t % lpr);
+  if (j >= n_nodes) return;
+  float* d = dst + (size_t)nodes[j] * H + 4 * l;
+  float4 s = *(float4*)d;
+  for (int k = rowptr[j]; k < rowptr[j + 1]; ++k) {
+    const float4 v = *(const float4*)(rows + (size_t)perm[k] * H + 4 * l);
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
+  *(float4*)d = s;
+}
+
+extern "C" int mgn_halo_unpack_add(const float* rows, const int32_t* nodes, const int32_t* rowptr, const int32_t* perm, int64_t n_nodes,
+                                   int H, float* dst, void* stream) {
+  if (n_nodes < 0 || H < 4 || (H & 3)) return pfail(1, "mgn_halo_unpack_add: bad arguments");
+  if (n_nodes == 0) return 0;
+  const long lanes = (long)n_nodes * (H / 4);
+  hipLaunchKernelGGL(k_halo_unpack_add, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, nodes, rowptr, perm,
+                     (long)n_nodes, H, dst);
+  return pcheck("mgn_halo_unpack_add");
+}
+
+// ====================================================== GraphNetBlock variants (N3)
+// Elementwise / gather stages of the reference's optional block features; the GEMMs around them
+// run on the MLP kernels.  HBM-bound: one 16-byte lane per 4 features, rows of H floats.
+
+// ---- sigmoid gate on the aggregate (layers.py:1091-1098):
+//   gate = sigmoid(G + phi[n] * gate_pos[j]),  G = gate_proj(x);   agg_out = agg * gate
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__global__ void __launch_bounds__(256) k_gate_fwd(const float* __restrict__ G, const float* __restrict__ phi, const float* __restrict__ gate_pos,
+                                                 const float* __restrict__ agg, long n, int H, float* __restrict__ gate_out,
+                                                 float* __restrict__ agg_out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * H) return;
+  float logit = G[i];
+  if (phi != nullptr && gate_pos != nullptr) logit += phi[i / H] * gate_pos[i % H];
+  const float gt = sigmoid_f(logit);
+  if (gate_out != nullptr) gate_out[i] = gt;
+  agg_out[i] = agg[i] * gt;
+}
+
+// dAgg = dAggG * gate;  dG = dAggG * agg * gate * (1 - gate)      (dAgg may alias dAggG)
+__global__ void __launch_bounds__(256) k_gate_bwd(const float* dAggG, const float* __restrict__ agg, const float* __restrict__ gate, long n, int H,
+                                                 float* dAgg, float* __restrict__ dG) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * H) return;
+  const float d = dAggG[i], gt = gate[i];
+  dG[i] = d * agg[i] * gt * (1.0f - gt);
+  dAgg[i] = d * gt;
+}
+
+extern "C" int mgn_gate_fwd(const float* G, const float* phi, const float* gate_pos, const float* agg, int64_t N, int H, float* gate_out,
+                            float* agg_out, void* stream) {
+  if (N < 0 || H < 1 || G == nullptr || agg == nullptr || agg_out == nullptr) return pfail(1, "mgn_gate_fwd: bad arguments");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_gate_fwd, dim3((unsigned)((N * H + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, phi, gate_pos, agg, (long)N, H,
+                     gate_out, agg_out);
+  return pcheck("mgn_gate_fwd");
+}
+
+extern "C" int mgn_gate_bwd(const float* dAggG, const float* agg, const float* gate, int64_t N, int H, float* dAgg, float* dG, void* stream) {
+  if (N < 0 || H < 1 || dAggG == nullptr || agg == nullptr || gate == nullptr || dAgg == nullptr || dG == nullptr)
+    return pfail(1, "mgn_gate_bwd: bad arguments");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_gate_bwd, dim3((unsigned)((N * H + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dAggG, agg, gate, (long)N, H, dAgg, dG);
+  return pcheck("mgn_gate_bwd");
+}
+
+// ---- relative RoPE on the source features (layers.py:1020-1026,1104-1149).  The first
+// rope_dim = 2 * pair_count * axes channels are rotated pairwise: pair i of axis a (channels
+// 2*(a*pair_count + i), +1) by theta = (pos[src] - pos[dst])[a] * inv_freq[i]:
+//   even' = even cos - odd sin,  odd' = even sin + odd cos ;   the remaining channels pass through.
+// One thread per (edge, channel pair).  SIGN = +1 forward, -1 the transpose (rotation by -theta).
+__device__ __forceinline__ void rope_angle(const float* __restrict__ pos, int pos_w, const float* __restrict__ inv_freq, int pair_count, int axes,
+                                           int s, int d, int pair, float& cs, float& sn, bool& rot) {
+  rot = pair < pair_count * axes;
+  cs = 1.f, sn = 0.f;
+  if (rot) {
+    const int axis = pair / pair_count, i = pair % pair_count;
+    const float delta = pos[(size_t)s * pos_w + axis] - pos[(size_t)d * pos_w + axis];
+    const float theta = delta * inv_freq[i];
+    cs = cosf(theta);
+    sn = sinf(theta);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_rope_gather(const float* __restrict__ x, const float* __restrict__ pos, int pos_w,
+                                                    const float* __restrict__ inv_freq, int pair_count, int axes, const int32_t* __restrict__ src,
+                                                    const int32_t* __restrict__ dst, long E, int H, float* __restrict__ out) {
+  const int hp = H / 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long k = t / hp;
+  const int pair = (int)(t % hp);
+  if (k >= E) return;
+  const int s = src[k], d = dst[k];
+  float cs, sn;
+  bool rot;
+  rope_angle(pos, pos_w, inv_freq, pair_count, axes, s, d, pair, cs, sn, rot);
+  const float2 v = *(const float2*)(x + (size_t)s * H + 2 * pair);
+  float2 o = v;
+  if (rot) {
+    o.x = v.x * cs - v.y * sn;
+    o.y = v.x * sn + v.y * cs;
+  }
+  *(float2*)(out + (size_t)k * H + 2 * pair) = o;
+}
+
+// out[j] = resid[j] + sum over the edges k whose source is j (src-grouped CSR: rowptr_src / perm_src
+// index the dst-sorted edge rows) of R_k^T T[k], summed in CSR order: deterministic, atomics-free.
+__global__ void __launch_bounds__(256) k_rope_scatter(const float* __restrict__ T, const float* __restrict__ pos, int pos_w,
+                                                     const float* __restrict__ inv_freq, int pair_count, int axes,
+                                                     const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                     const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ perm_src, long N, int H,
+                                                     const float* __restrict__ resid, float* __restrict__ out) {
+  const int hp = H / 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long j = t / hp;
+  const int pair = (int)(t % hp);
+  if (j >= N) return;
+  float2 acc = (resid != nullptr) ? *(const float2*)(resid + (size_t)j * H + 2 * pair) : make_float2(0.f, 0.f);
+  for (int q = rowptr_src[j]; q < rowptr_src[j + 1]; ++q) {
+    const int k = perm_src[q];
+    float cs, sn;
+    bool rot;
+    rope_angle(pos, pos_w, inv_freq, pair_count, axes, src[k], dst[k], pair, cs, sn, rot);
+    const float2 v = *(const float2*)(T + (size_t)k * H + 2 * pair);
+    if (rot) {  // transpose of the rotation
+      acc.x += v.x * cs + v.y * sn;
+      acc.y += -v.x * sn + v.y * cs;
+    } else {
+      acc.x += v.x;
+      acc.y += v.y;
+    }
+  }
+  *(float2*)(out + (size_t)j * H + 2 * pair) = acc;
+}
+
+extern "C" int mgn_rope_gather(const float* x, const float* pos, int pos_w, const float* inv_freq, int pair_count, int axes,
+                               const int32_t* src, const int32_t* dst, int64_t E, int H, float* out, void* stream) {
+  if (E < 0 || H < 2 || (H & 1) || pair_count < 0 || axes < 1 || axes > 3 || pos_w < axes || 2 * pair_count * axes > H)
+    return pfail(1, "mgn_rope_gather: bad arguments");
+  if (E == 0) return 0;
+  hipLaunchKernelGGL(k_rope_gather, dim3((unsigned)((E * (H / 2) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, pos, pos_w, inv_freq,
+                     pair_count, axes, src, dst, (long)E, H, out);
+  return pcheck("mgn_rope_gather");
+}
+
+extern "C" int mgn_rope_scatter(const float* T, const float* pos, int pos_w, const float* inv_freq, int pair_count, int axes,
+                                const int32_t* src, const int32_t* dst, const int32_t* rowptr_src, const int32_t* perm_src, int64_t N, int H,
+                                const float* resid, float* out, void* stream) {
+  if (N < 0 || H < 2 || (H & 1) || pair_count < 0 || axes < 1 || axes > 3 || pos_w < axes || 2 * pair_count * axes > H)
+    return pfail(1, "mgn_rope_scatter: bad arguments");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_rope_scatter, dim3((unsigned)((N * (H / 2) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, T, pos, pos_w, inv_freq,
+                     pair_count, axes, src, dst, rowptr_src, perm_src, (long)N, H, resid, out);
+  return pcheck("mgn_rope_scatter");
+}

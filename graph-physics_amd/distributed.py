@@ -70,16 +70,88 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
 # ----------------------------------------------------------------------------------
 # Partitioned large-mesh path: one-hop halo exchange of ghost-node latents per round.
 # ----------------------------------------------------------------------------------
+class HaloState:
+    """Device side of a :class:`partition.RankPlan` for the HIP engine (ops.ProcessorFunction drives it).
+
+    Forward, once per round: the rows of ``Ps`` (next round's source projection x W_s^T -- the only
+    remote data an edge row needs) that peers use as ghost sources are packed by ``mgn_gather_rows``
+    and travel by ONE ``all_to_all_single`` straight into the ghost rows of the same ``[n_own +
+    n_ghost, H]`` buffer the edge kernel gathers from (no concatenation); the collective is started
+    right after the node kernel and completed only before the BOUNDARY edge rows -- the interior rows
+    (destinations without a ghost in-neighbour) run in between.  Backward: the ghost rows of the
+    source-side scatter ``Ss`` go back the same way (contiguous: no packing) while the E-row weight
+    gradients run, and ``mgn_halo_unpack_add`` sums them into their owners in a fixed order -- no
+    atomics anywhere, so partitioned gradients are bit-reproducible.
+
+    Over RCCL (backend "nccl") ``async_op=True`` puts the collective on RCCL's own stream: it waits for
+    the packed rows, the compute stream waits for it only at ``finish_*``.  The exchange is a
+    neighbour all-to-all of 0.4-0.7 MB per rank and round on the 1M-node mesh: latency-bound over
+    point-to-point xGMI, hence one collective per round rather than a ring."""
+
+    def __init__(self, plan, device, group=None):
+        self.plan, self.group, self.device = plan, group, device
+        self.n_own, self.n_ghost = plan.n_own, plan.n_ghost
+        self.n_interior, self.n_interior_edges = plan.n_interior, plan.n_interior_edges
+        i32 = dict(dtype=torch.int32, device=device)
+        self.send_idx = plan.send_idx.to(**i32)
+        self.send_nodes = plan.send_nodes.to(**i32)
+        self.send_rowptr = plan.send_rowptr.to(**i32)
+        self.send_perm = plan.send_perm.to(**i32)
+        self.send_counts, self.recv_counts = list(plan.send_counts), list(plan.recv_counts)
+        self.active = plan.world > 1 and dist.is_initialized() and dist.get_world_size(group) > 1
+        self._rowptr_bnd = None
+
+    def rowptr_bnd(self, topo):
+        """rowptr_dst shifted to the first boundary edge row: the boundary launch numbers its rows from 0"""
+        if self._rowptr_bnd is None:
+            self._rowptr_bnd = (topo.rowptr_dst - self.n_interior_edges).contiguous()
+        return self._rowptr_bnd
+
+    # ---- forward: owners' rows -> ghost rows of the same buffer
+    def start_forward(self, buf: torch.Tensor):
+        from . import ops
+        if self.n_ghost == 0 and self.send_idx.numel() == 0:
+            return None
+        if not self.active:  # a single process holding a multi-rank plan (timing rehearsal): ghosts read as zeros
+            buf[self.n_own:].zero_()
+            return None
+        send = ops.gather_rows(buf, self.send_idx)
+        work = dist.all_to_all_single(buf[self.n_own:], send, output_split_sizes=self.recv_counts,
+                                      input_split_sizes=self.send_counts, group=self.group, async_op=True)
+        return (work, send)  # `send` stays referenced until the collective has consumed it
+
+    def finish_forward(self, pending):
+        if pending is not None:
+            pending[0].wait()
+
+    # ---- backward: ghost-row gradients -> summed into their owners
+    def start_backward(self, Ss: torch.Tensor):
+        if not self.active or (self.n_ghost == 0 and self.send_idx.numel() == 0):
+            return None
+        back = torch.empty(self.send_idx.numel(), Ss.shape[1], dtype=Ss.dtype, device=Ss.device)
+        work = dist.all_to_all_single(back, Ss[self.n_own:], output_split_sizes=self.send_counts,
+                                      input_split_sizes=self.recv_counts, group=self.group, async_op=True)
+        return (work, back)
+
+    def finish_backward(self, pending, Ss: torch.Tensor):
+        from . import ops
+        if pending is None:
+            return
+        pending[0].wait()
+        ops.halo_unpack_add(pending[1], self.send_nodes, self.send_rowptr, self.send_perm, Ss)
+
+
 class HaloExchange(torch.autograd.Function):
-    """ghost rows <- owners' rows (forward); ghost-row gradients summed back into the
-    owners' rows (backward).  One ``all_to_all_single`` each way -- a neighbour exchange
-    of ~O(sqrt(N/P)) rows per peer, latency-bound over xGMI."""
+    """Generic (backend-agnostic) exchange of latent rows: ghost rows <- owners' rows (forward);
+    ghost-row gradients summed back into the owners' rows (backward, in the fixed order of the plan's
+    send list grouped by node).  Used by compute backends that need the ghost LATENTS themselves (the
+    CPU oracle backend of the tests, widths the packed kernels do not take); the HIP engine exchanges
+    projected rows inside ``ops.ProcessorFunction`` instead (:class:`HaloState`)."""
 
     @staticmethod
     def forward(ctx, x_own, plan, group):
         ctx.plan, ctx.group, ctx.n_own = plan, group, x_own.shape[0]
         idx = plan.send_idx.to(x_own.device)
-        ctx.idx = idx
         ctx.local = plan.world == 1 or not dist.is_initialized()
         send = x_own.detach().index_select(0, idx).contiguous()
         recv = torch.empty(plan.n_ghost, x_own.shape[1], dtype=x_own.dtype, device=x_own.device)
@@ -92,17 +164,29 @@ class HaloExchange(torch.autograd.Function):
     def backward(ctx, d_ghost):
         plan = ctx.plan
         d_ghost = d_ghost.contiguous()
-        back = torch.empty(ctx.idx.numel(), d_ghost.shape[1], dtype=d_ghost.dtype, device=d_ghost.device)
-        if ctx.local:
-            return torch.zeros(ctx.n_own, d_ghost.shape[1], dtype=d_ghost.dtype, device=d_ghost.device), None, None
-        dist.all_to_all_single(back, d_ghost, output_split_sizes=plan.send_counts, input_split_sizes=plan.recv_counts, group=ctx.group)
         d_own = torch.zeros(ctx.n_own, d_ghost.shape[1], dtype=d_ghost.dtype, device=d_ghost.device)
-        d_own.index_add_(0, ctx.idx, back)
+        if ctx.local:
+            return d_own, None, None
+        back = torch.empty(plan.send_idx.numel(), d_ghost.shape[1], dtype=d_ghost.dtype, device=d_ghost.device)
+        dist.all_to_all_single(back, d_ghost, output_split_sizes=plan.send_counts, input_split_sizes=plan.recv_counts, group=ctx.group)
+        # fixed order (no index_add_ atomics): rows grouped by node, ascending position inside a group
+        dev = d_ghost.device
+        grouped = back.index_select(0, plan.send_perm.to(dev))
+        rp = plan.send_rowptr
+        nodes = plan.send_nodes.to(dev)
+        maxc = int((rp[1:] - rp[:-1]).max()) if nodes.numel() else 0
+        start = rp[:-1].to(dev)
+        cnt = (rp[1:] - rp[:-1]).to(dev)
+        for k in range(maxc):  # k-th contribution of every node that has one: a plain indexed add per k
+            sel = cnt > k
+            d_own[nodes[sel]] += grouped[start[sel] + k]
         return d_own, None, None
 
 
 class HipBackend:
     """Compute backend of the partitioned model: the HIP engine (default, GPU only)."""
+
+    fused = True  # all rounds + the halo exchange inside ONE autograd node (ops.ProcessorFunction)
 
     def prepare(self, edge_index, n_local):
         from . import ops
@@ -117,7 +201,7 @@ class HipBackend:
     def block(self, block, x, e, ctx):
         from . import ops
         from .layers import _block_params
-        return ops.processor_apply(x, e, ctx, 1, *_block_params(block))
+        return ops.processor_apply(x, e, ctx, 1, *_block_params(block), spec=block.spec)
 
 
 class PartitionedEPD(torch.nn.Module):
@@ -133,6 +217,7 @@ class PartitionedEPD(torch.nn.Module):
         self.model, self.plan, self.group = model, plan, group
         self.backend = backend if backend is not None else HipBackend()
         self._ctx = None
+        self._halo = None
 
     def forward(self, x_in_own: torch.Tensor, edge_attr_loc: torch.Tensor) -> torch.Tensor:
         plan, be, m = self.plan, self.backend, self.model
@@ -141,11 +226,24 @@ class PartitionedEPD(torch.nn.Module):
             self._ctx = be.prepare(plan.edge_index.to(dev), plan.n_own + plan.n_ghost)
         x_own = be.mlp(m.nodes_encoder, x_in_own)
         e = be.mlp(m.edges_encoder, be.order_edges(edge_attr_loc, self._ctx))
-        for blk in m.processor_list:
-            x_gh = HaloExchange.apply(x_own, plan, self.group)
-            x_full = torch.cat([x_own, x_gh], dim=0)
-            x_full, e = be.block(blk, x_full, e, self._ctx)
-            x_own = x_full[: plan.n_own]
+        blocks = list(m.processor_list)
+        fused = getattr(be, "fused", False) and blocks and m.hidden_size == 128 and not m.use_rope and not m.use_gated_mlp
+        if fused:
+            from . import ops
+            from .layers import _block_params
+            if self._halo is None:
+                self._halo = HaloState(plan, dev, self.group)
+            params = []
+            for blk in blocks:
+                params += _block_params(blk)
+            x_own, _ = ops.processor_apply(x_own, e, self._ctx, len(blocks), *params, spec=blocks[0].spec, halo=self._halo,
+                                           phi=None)
+        else:
+            for blk in blocks:
+                x_gh = HaloExchange.apply(x_own, plan, self.group)
+                x_full = torch.cat([x_own, x_gh], dim=0)
+                x_full, e = be.block(blk, x_full, e, self._ctx)
+                x_own = x_full[: plan.n_own]
         return be.mlp(m.decode_module, x_own)
 
 

@@ -26,9 +26,10 @@ def use_silu_activation() -> bool:
 
 
 class RMSNorm(nn.Module):
-    """Parameter holder for the trailing normalisation of ``build_mlp``
-    (layers.py:73-129: y = scale * x / (||x||/sqrt(d) + eps), eps OUTSIDE the
-    root).  The arithmetic is fused into the MLP kernel's epilogue."""
+    """Trailing normalisation of ``build_mlp`` (layers.py:73-129: y = scale * x / (||x||/sqrt(d) + eps),
+    eps OUTSIDE the root).  Inside an MLP the arithmetic is fused into the kernel's epilogue and this
+    module only holds ``scale``; called on its own (``net.nodes_encoder[7](x)``, the leading norm of a
+    gated MLP) it evaluates the same formula with elementwise device ops."""
 
     def __init__(self, d: int, p: float = -1.0, eps: float = 1e-8, bias: bool = False):
         super().__init__()
@@ -39,21 +40,38 @@ class RMSNorm(nn.Module):
         self.d, self.p, self.eps, self.bias = d, p, eps, bias
         self.scale = nn.Parameter(torch.ones(d))
 
-    def forward(self, x):  # never used stand-alone on the path
-        raise RuntimeError("RMSNorm runs fused inside the MLP kernel; call the enclosing MLP")
+    def forward(self, x):
+        ops._require_device(x)
+        rms = x.norm(2, dim=-1, keepdim=True) / (self.d ** 0.5)
+        return self.scale * (x / (rms + self.eps))
 
 
 class ReLU(nn.Module):
-    """Placeholder so that Sequential indices match the reference (entries 1,3,5)."""
+    """Sequential entries 1,3,5 of ``build_mlp``: fused inside the MLP kernel when the enclosing MLP is
+    called; on its own an elementwise device op (the Sequential stays index-transparent)."""
 
     def forward(self, x):
-        raise RuntimeError("activation runs fused inside the MLP kernel; call the enclosing MLP")
+        ops._require_device(x)
+        return torch.relu(x)
+
+
+class SiLU(ReLU):
+    """nn.SiLU (``use_silu_activation``, layers.py:132-160)."""
+
+    def forward(self, x):
+        ops._require_device(x)
+        return torch.nn.functional.silu(x)
+
+
+_ACT_MODULES = {"relu": ReLU, "silu": SiLU}
 
 
 class MLP(nn.Sequential):
     """``build_mlp`` result: entries 0,2,4,.. nn.Linear, odd entries activation,
     last entry RMSNorm if ``layer_norm`` (layers.py:198-210).  forward() is one
     fused HIP kernel (ops.MlpFunction)."""
+
+    act = "relu"
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lin = [m for m in self if isinstance(m, nn.Linear)]
@@ -63,7 +81,7 @@ class MLP(nn.Sequential):
             params += [m.weight, m.bias]
         if norm is not None:
             params.append(norm.scale)
-        return ops.mlp_apply(x, norm is not None, *params)
+        return ops.mlp_apply(x, norm is not None, *params, act=self.act)
 
 
 def build_mlp(in_size: int, hidden_size: int, out_size: int, nb_of_layers: int = 4,
@@ -73,53 +91,94 @@ def build_mlp(in_size: int, hidden_size: int, out_size: int, nb_of_layers: int =
     key = act if act is not None else ("silu" if _USE_SILU_ACTIVATION else "relu")
     if key not in ("relu", "gelu", "silu"):
         raise NotImplementedError(f"Activation '{key}' not supported. Available: ['relu', 'gelu', 'silu'].")
-    if key != "relu":
-        raise NotImplementedError(f"activation '{key}' is a 'next' row (SURVEY.md N3); the MI355X engine implements ReLU")
-    layers = [nn.Linear(in_size, hidden_size), ReLU()]
+    if key == "gelu":
+        raise NotImplementedError("GELU in build_mlp is reachable only through an explicit act='gelu' argument, which no "
+                                  "caller of the reference passes; the MI355X engine implements ReLU and SiLU")
+    A = _ACT_MODULES[key]
+    layers = [nn.Linear(in_size, hidden_size), A()]
     for _ in range(nb_of_layers - 2):
-        layers.extend([nn.Linear(hidden_size, hidden_size), ReLU()])
+        layers.extend([nn.Linear(hidden_size, hidden_size), A()])
     layers.append(nn.Linear(hidden_size, out_size))
     if layer_norm:
         layers.append(RMSNorm(out_size))
-    return MLP(*layers)
+    mlp = MLP(*layers)
+    mlp.act = key
+    return mlp
+
+
+def _mlp_param_list(mlp: nn.Sequential):
+    out = []
+    for m in mlp:
+        if isinstance(m, nn.Linear):
+            out += [m.weight, m.bias]
+    if isinstance(mlp[len(mlp) - 1], RMSNorm):
+        out.append(mlp[len(mlp) - 1].scale)
+    return out
 
 
 def _block_params(block: "GraphNetBlock"):
-    out = []
-    for mlp in (block.edge_block, block.node_block):
-        for i in (0, 2, 4, 6):
-            out += [mlp[i].weight, mlp[i].bias]
-        out.append(mlp[7].scale)
+    """parameters of one block in the order ops.ProcessorFunction takes them (= state_dict order)"""
+    out = _mlp_param_list(block.edge_block) + _mlp_param_list(block.node_block)
+    if block.use_gate:
+        out += [block.gate_proj.weight, block.gate_proj.bias, block.gate_pos]
     return out
 
 
 class GraphNetBlock(nn.Module):
-    """One MeshGraphNet round (layers.py:890-1042): gather -> edge MLP ->
-    segment-sum -> node MLP -> residuals, on the HIP engine."""
+    """One MeshGraphNet round (layers.py:890-1042): gather -> edge MLP -> segment-sum -> node MLP ->
+    residuals, on the HIP engine; optional relative RoPE on the source features (:1020-1026), sigmoid
+    gate on the aggregate (:1091-1098), SiLU activations (global switch), any ``nb_of_layers >= 2``,
+    ``layer_norm`` on / off, gated-MLP blocks (:213-278)."""
 
     def __init__(self, hidden_size: int, nb_of_layers: int = 4, layer_norm: bool = True,
                  use_rope: bool = False, rope_axes: int = 3, rope_base: float = 10000.0,
                  use_gated_mlp: bool = False, use_gate: bool = False):
         super().__init__()
-        if use_rope and rope_axes not in (2, 3):
-            raise ValueError("rope_axes must be 2 or 3 when use_rope=True.")
-        if use_rope or use_gated_mlp or use_gate:
-            raise NotImplementedError("rope / gate / gated-MLP GraphNetBlock variants are 'next' rows (SURVEY.md N3)")
-        if nb_of_layers != 4 or not layer_norm:
-            raise NotImplementedError("the engine implements the reference default block (4 layers, RMSNorm)")
         self.hidden_size = hidden_size
-        self.use_gated_mlp, self.use_rope, self.use_gate = use_gated_mlp, use_rope, use_gate
-        self.rope_axes, self.rope_base = rope_axes, rope_base
-        self.edge_block = build_mlp(3 * hidden_size, hidden_size, hidden_size, nb_of_layers, layer_norm)
-        self.node_block = build_mlp(2 * hidden_size, hidden_size, hidden_size, nb_of_layers, layer_norm)
-        self.register_buffer("_rope_inv_freq", torch.zeros(0), persistent=False)  # layers.py:977-981
+        self.use_gated_mlp = use_gated_mlp
+        if use_gated_mlp:
+            from .gated import build_gated_mlp
+            self.edge_block = build_gated_mlp(3 * hidden_size, hidden_size, hidden_size)
+            self.node_block = build_gated_mlp(2 * hidden_size, hidden_size, hidden_size)
+        else:
+            self.edge_block = build_mlp(3 * hidden_size, hidden_size, hidden_size, nb_of_layers, layer_norm)
+            self.node_block = build_mlp(2 * hidden_size, hidden_size, hidden_size, nb_of_layers, layer_norm)
+        self.use_rope, self.rope_axes, self.rope_base = use_rope, rope_axes, rope_base
+        if self.use_rope:
+            if rope_axes not in (2, 3):
+                raise ValueError("rope_axes must be 2 or 3 when use_rope=True.")
+            self._pair_count = hidden_size // (2 * rope_axes)
+            self._rope_dim = self._pair_count * 2 * rope_axes
+            if self._pair_count == 0:
+                raise ValueError(f"hidden_size={hidden_size} too small for rope_axes={rope_axes}; "
+                                 "need at least 2 * rope_axes channels.")
+            inv = torch.arange(self._pair_count, dtype=torch.float32)
+            inv = torch.pow(self.rope_base, -inv / max(float(self._pair_count), 1.0))  # layers.py:972-976
+            self.register_buffer("_rope_inv_freq", inv, persistent=False)
+        else:
+            self._pair_count, self._rope_dim = 0, 0
+            self.register_buffer("_rope_inv_freq", torch.zeros(0), persistent=False)  # layers.py:977-981
+        self.use_gate = use_gate
+        if self.use_gate:
+            self.gate_proj = nn.Linear(hidden_size, hidden_size, bias=True)
+            self.gate_pos = nn.Parameter(torch.zeros(hidden_size))
+        self.spec = ops.BlockSpec(nb_layers=nb_of_layers, layer_norm=layer_norm,
+                                  act=("silu" if _USE_SILU_ACTIVATION else "relu"), gate=use_gate, rope=use_rope, rope_axes=rope_axes)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor, size=None,
                 pos: Optional[torch.Tensor] = None, phi: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self.use_rope and pos is None:
+            raise ValueError("Node positions `pos` must be provided when use_rope=True.")
         topo = ops.get_topology(edge_index, x.shape[0])
         e_sorted = edge_attr[topo.perm_dst.long()]
-        x_new, e_new = ops.processor_apply(x, e_sorted, topo, 1, *_block_params(self))
+        if self.use_gated_mlp:
+            from .gated import gated_block_forward
+            x_new, e_new = gated_block_forward(self, x, e_sorted, topo, pos, phi)
+        else:
+            x_new, e_new = ops.processor_apply(x, e_sorted, topo, 1, *_block_params(self), spec=self.spec,
+                                               pos=pos if self.use_rope else None, phi=phi if self.use_gate else None,
+                                               rope_inv_freq=self._rope_inv_freq if self.use_rope else None)
         return x_new, e_new[topo.inv_perm]
 
 

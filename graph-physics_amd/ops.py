@@ -176,7 +176,7 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
             adds: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]] = (),
             posts: Sequence[Tuple[int, torch.Tensor]] = (), post_ldw: int = 0, wpk: Sequence[int] = (),
             saveM: Optional[Sequence[torch.Tensor]] = None, precision: int = 0, out_relu: bool = False,
-            seg=None):
+            seg=None, act: int = 0, saveZ: Optional[Sequence[torch.Tensor]] = None):
     """``seg`` = (key[M] int32 sorted, rowptr[n+1] int32, out[n,H], part[ceil(M/16),2,H]): fused
     segment sum of y (finish with :func:`seg_fix`).
     ``adds``: (rows[*,H], idx or None) gathered into the layer-0 pre-activation;
@@ -209,6 +209,10 @@ def mlp_fwd(M: int, H: int, phases: Sequence[Tuple[torch.Tensor, Optional[torch.
     a.out_relu = int(out_relu)
     if seg is not None:
         a.seg_key, a.seg_rowptr, a.seg_out, a.seg_part = (_ptr(t) for t in seg)
+    a.act = act
+    if saveZ is not None:
+        for l, t in enumerate(saveZ):
+            a.saveZ[l] = _ptr(t)
     dev = out.device
     with torch.cuda.device(dev):
         rc = _capi.lib().mgn_mlp_fwd(C.byref(a), _stream(dev))
@@ -219,7 +223,8 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
             Hs: Sequence[torch.Tensor], WT: Sequence[Optional[torch.Tensor]], dZ: Sequence[Optional[torch.Tensor]],
             din: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]],
             db: Sequence[Optional[torch.Tensor]], dscale: Optional[torch.Tensor], wpk: Sequence[int] = (),
-            Ms: Optional[Sequence[torch.Tensor]] = None, precision: int = 0, front=None, defer: Optional[list] = None):
+            Ms: Optional[Sequence[torch.Tensor]] = None, precision: int = 0, front=None, defer: Optional[list] = None,
+            act: int = 0, Zs: Optional[Sequence[torch.Tensor]] = None):
     """``front`` = (rows[<=3] each [M,H], resid[M,H] or None, out[M,H] or None): the fused front
     stage of the packed kernel, dY = resid + sum_p wpk[p] . rows[p] (then ``dOut`` is ignored)."""
     L = _capi.lib()
@@ -227,7 +232,7 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
     a.M, a.H, a.NL = M, H, NL
     a.dOut, a.dOut2, a.idx2, a.out_w = _ptr(dOut), _ptr(dOut2), _ptr(idx2), out_w
     a.U, a.R, a.scale, a.eps = _ptr(U), _ptr(R), _ptr(scale), EPS
-    for l, h in enumerate(Hs):
+    for l, h in enumerate(Hs or ()):
         a.Hs[l] = _ptr(h)
     for l in range(NL):
         a.WT[l] = _ptr(WT[l])
@@ -243,6 +248,10 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
         for l, t in enumerate(Ms):
             a.Ms[l] = _ptr(t)
     a.precision = precision
+    a.act = act
+    if Zs is not None:
+        for l, t in enumerate(Zs):
+            a.Zs[l] = _ptr(t)
     if front is not None:
         rows, fres, fout = front
         a.n_front = len(rows)
@@ -324,12 +333,66 @@ def transpose_blocks(blocks: Sequence[Tuple[int, int, int, int]], H: int, dev):
     _capi.check(rc, "mgn_transpose_blocks")
 
 
+# ------------------------------------------------------------ small row kernels
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i,:] = src[idx[i],:] (idx int32): packs the rows a halo peer needs."""
+    n, H = int(idx.numel()), int(src.shape[1])
+    if out is None:
+        out = torch.empty(n, H, dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        rc = _capi.lib().mgn_gather_rows(_ptr(src), _ptr(idx), n, H, _ptr(out), _stream(src.device))
+    _capi.check(rc, "mgn_gather_rows", prep=True)
+    return out
+
+
+def halo_unpack_add(rows: torch.Tensor, nodes: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor, dst: torch.Tensor):
+    """dst[nodes[j]] += sum of rows[perm[rowptr[j]:rowptr[j+1]]] in ascending order (atomics-free)."""
+    with torch.cuda.device(dst.device):
+        rc = _capi.lib().mgn_halo_unpack_add(_ptr(rows), _ptr(nodes), _ptr(rowptr), _ptr(perm), int(nodes.numel()), int(dst.shape[1]),
+                                             _ptr(dst), _stream(dst.device))
+    _capi.check(rc, "mgn_halo_unpack_add", prep=True)
+
+
+def gate_fwd(G, phi, gate_pos, agg, gate_out, agg_out):
+    with torch.cuda.device(agg.device):
+        rc = _capi.lib().mgn_gate_fwd(_ptr(G), _ptr(phi), _ptr(gate_pos), _ptr(agg), int(agg.shape[0]), int(agg.shape[1]),
+                                      _ptr(gate_out), _ptr(agg_out), _stream(agg.device))
+    _capi.check(rc, "mgn_gate_fwd", prep=True)
+
+
+def gate_bwd(dAggG, agg, gate, dAgg, dG):
+    with torch.cuda.device(agg.device):
+        rc = _capi.lib().mgn_gate_bwd(_ptr(dAggG), _ptr(agg), _ptr(gate), int(agg.shape[0]), int(agg.shape[1]), _ptr(dAgg), _ptr(dG),
+                                      _stream(agg.device))
+    _capi.check(rc, "mgn_gate_bwd", prep=True)
+
+
+def rope_gather(x, pos, inv_freq, topo: "Topology", axes: int, out):
+    """out[k] = RoPE(x[src[k]], pos[src[k]] - pos[dst[k]]) for the dst-sorted edges (layers.py:1020-1026,1104-1149)."""
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().mgn_rope_gather(_ptr(x), _ptr(pos), int(pos.shape[1]), _ptr(inv_freq), int(inv_freq.numel()), axes,
+                                         _ptr(topo.src_s), _ptr(topo.dst_s), topo.E, int(x.shape[1]), _ptr(out), _stream(x.device))
+    _capi.check(rc, "mgn_rope_gather", prep=True)
+
+
+def rope_scatter(T, pos, inv_freq, topo: "Topology", axes: int, resid, out):
+    """out[j] = resid[j] + sum_{k: src[k]=j} RoPE^T(T[k]) (the gradient of rope_gather wrt x), in the
+    fixed order of the src-grouped CSR."""
+    n = int(out.shape[0])
+    with torch.cuda.device(T.device):
+        rc = _capi.lib().mgn_rope_scatter(_ptr(T), _ptr(pos), int(pos.shape[1]), _ptr(inv_freq), int(inv_freq.numel()), axes,
+                                          _ptr(topo.src_s), _ptr(topo.dst_s), _ptr(topo.rowptr_src), _ptr(topo.perm_src), n,
+                                          int(T.shape[1]), _ptr(resid), _ptr(out), _stream(T.device))
+    _capi.check(rc, "mgn_rope_scatter", prep=True)
+
+
 # ``ctx.needs_input_grad`` mirrors ``tensor.requires_grad`` even under ``torch.no_grad()``, and
 # grad mode is always off INSIDE ``Function.forward`` -- so whether activations must be saved for
 # a backward pass has to be read BEFORE ``apply``.  Without this an inference forward ran the
 # training-mode kernels (4 extra 512-byte stores per row and layer) and kept every round's
 # activations alive (270 GB on the 1M-node mesh).
 import threading as _threading
+from dataclasses import dataclass
 
 _call = _threading.local()
 
@@ -338,20 +401,51 @@ def _saving() -> bool:
     return getattr(_call, "grad", True)
 
 
-def mlp_apply(*args):
+ACT_IDS = {"relu": 0, "silu": 1}
+
+
+def mlp_apply(x, has_norm, *params, act: str = "relu"):
     """MlpFunction.apply with the caller's grad mode recorded."""
     _call.grad = torch.is_grad_enabled()
     try:
-        return MlpFunction.apply(*args)
+        return MlpFunction.apply(x, has_norm, ACT_IDS[act], *params)
     finally:
         _call.grad = True
 
 
-def processor_apply(*args):
+@dataclass(frozen=True)
+class BlockSpec:
+    """Variant of GraphNetBlock the processor runs (layers.py:890-987): Linear layers per MLP, trailing
+    RMSNorm, activation, sigmoid gate on the aggregate, relative RoPE on the source features."""
+    nb_layers: int = 4
+    layer_norm: bool = True
+    act: str = "relu"
+    gate: bool = False
+    rope: bool = False
+    rope_axes: int = 3
+
+    @property
+    def mlp_params(self) -> int:
+        return 2 * self.nb_layers + (1 if self.layer_norm else 0)
+
+    @property
+    def per_block(self) -> int:
+        return 2 * self.mlp_params + (3 if self.gate else 0)
+
+    @property
+    def act_id(self) -> int:
+        return ACT_IDS[self.act]
+
+
+DEFAULT_SPEC = BlockSpec()
+PARAMS_PER_BLOCK = DEFAULT_SPEC.per_block  # 18: edge W0,b0..W3,b3,scale ; node W0,b0..W3,b3,scale
+
+
+def processor_apply(x, e, topo, L, *params, spec: BlockSpec = DEFAULT_SPEC, halo=None, pos=None, phi=None, rope_inv_freq=None):
     """ProcessorFunction.apply with the caller's grad mode recorded."""
     _call.grad = torch.is_grad_enabled()
     try:
-        return ProcessorFunction.apply(*args)
+        return ProcessorFunction.apply(x, e, topo, L, spec, halo, pos, phi, rope_inv_freq, *params)
     finally:
         _call.grad = True
 
@@ -360,13 +454,15 @@ def processor_apply(*args):
 class MlpFunction(torch.autograd.Function):
     """build_mlp forward/backward on the engine (encoders, decoder, stand-alone MLPs).
 
-    apply(x, has_norm, W0, b0, ..., W_{NL-1}, b_{NL-1} [, scale]) -> y[M, out]
+    apply(x, has_norm, act_id, W0, b0, ..., W_{NL-1}, b_{NL-1} [, scale]) -> y[M, out]
     First-layer columns / last-layer rows are zero-padded to multiples of 16 here
-    (plumbing) so that the kernels only see aligned weights.
+    (plumbing) so that the kernels only see aligned weights.  H = 128 with a full-width output runs
+    on the packed split-bf16 kernels in both directions (an encoder's narrow first layer as a
+    stand-alone generic launch); everything else on the generic kernels.
     """
 
     @staticmethod
-    def forward(ctx, x, has_norm, *params):
+    def forward(ctx, x, has_norm, act, *params):
         _require_device(x, *params)
         x = _f32c(x)
         NL = (len(params) - (1 if has_norm else 0)) // 2
@@ -392,34 +488,50 @@ class MlpFunction(torch.autograd.Function):
         Wk = [W0] + Ws[1:-1] + [Wl]
         bk = bs[:-1] + [bl]
         need = any(ctx.needs_input_grad) and _saving()
-        y = torch.empty(M, out_w, dtype=torch.float32, device=dev)
-        saveH = [torch.empty(M, H, dtype=torch.float32, device=dev) for _ in range(NL - 1)] if need else None
-        U = torch.empty(M, H, dtype=torch.float32, device=dev) if (need and has_norm) else None
-        R = torch.empty(M, dtype=torch.float32, device=dev) if (need and has_norm) else None
-        if H == 128 and kin < H and out_w == H and NL >= 3 and NL - 1 <= 4 and X6_ENABLED and M > 0:
-            # encoder: narrow first layer stand-alone (h1 = relu(W0 x + b0), the activation the
-            # backward needs anyway), the full-width layers on the packed split-bf16 path
-            h1 = saveH[0] if need else torch.empty(M, H, dtype=torch.float32, device=dev)
-            mlp_fwd(M, H, [(x, None, kin)], [Wk[0]], [bk[0]], None, H, None, h1, out_relu=True)
+        f = dict(dtype=torch.float32, device=dev)
+        y = torch.empty(M, out_w, **f)
+        x6 = H == 128 and out_w == H and X6_ENABLED and M > 0
+        mode = "generic"
+        if x6 and kin < H and 3 <= NL <= 4:
+            mode = "enc"    # narrow first layer stand-alone, layers 1.. on the packed kernels
+        elif x6 and kin == H and NL <= 4:
+            mode = "full"
+        packed = mode != "generic"
+        saveH = [torch.empty(M, H, **f) for _ in range(NL - 1)] if need else None
+        U = torch.empty(M, H, **f) if (need and has_norm) else None
+        R = torch.empty(M, **f) if (need and has_norm) else None
+        Ms = [torch.empty(M, 4, dtype=torch.int32, device=dev) for _ in range(NL - 1)] if (need and packed and act == 0) else None
+        Zs = [torch.empty(M, H, **f) for _ in range(NL - 1)] if (need and act == 1) else None
+        if mode == "enc":
+            # h1 = act(W0 x + b0): the activation the backward needs anyway
+            h1 = saveH[0] if need else torch.empty(M, H, **f)
+            mlp_fwd(M, H, [(x, None, kin)], [Wk[0]], [bk[0]], None, H, None, h1, Zs[0] if Zs else None, out_relu=True, act=act,
+                    saveM=[Ms[0]] if Ms else None)
             pk = torch.empty((NL - 1) * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
             units = [pk.data_ptr() + u * _capi.WPACK_BYTES for u in range(NL - 1)]
             wpack([(Wk[l + 1].data_ptr(), H, False, units[l]) for l in range(NL - 1)], dev)
             mlp_fwd(M, H, [(h1, None, H)], Wk[1:], bk[1:], scale, out_w, None, y, None,
-                    saveH[1:] if need else None, U, R, wpk=units)
+                    saveH[1:] if need else None, U, R, wpk=units, saveM=Ms[1:] if Ms else None,
+                    saveZ=Zs[1:] if Zs else None, act=act)
+        elif mode == "full":
+            pk = torch.empty(NL * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+            units = [pk.data_ptr() + u * _capi.WPACK_BYTES for u in range(NL)]
+            wpack([(Wk[l].data_ptr(), H, False, units[l]) for l in range(NL)], dev)
+            mlp_fwd(M, H, [(x, None, H)], Wk, bk, scale, out_w, None, y, None, saveH, U, R, wpk=units, saveM=Ms, saveZ=Zs, act=act)
         else:
-            mlp_fwd(M, H, [(x, None, kin)], Wk, bk, scale, out_w, None, y, None, saveH, U, R)
-        ctx.meta = (NL, H, kin, out_w, has_norm, kp != kin, op != out_w)
+            mlp_fwd(M, H, [(x, None, kin)], Wk, bk, scale, out_w, None, y, None, saveH, U, R, act=act, saveZ=Zs)
+        ctx.meta = (NL, H, kin, out_w, has_norm, kp != kin, op != out_w, act, mode)
         # inputs / parameters through save_for_backward (autograd's version counter then catches an
         # in-place update between forward and backward); padded weight copies and the activations
         # the kernels wrote are ours and live until the graph is freed
         ctx.save_for_backward(x, *Ws, *([scale] if has_norm else []))
         ctx.pads = (W0 if kp != kin else None, Wl if op != out_w else None)
-        ctx.saved_acts = (saveH, U, R)
+        ctx.saved_acts = (saveH, U, R, Ms, Zs)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        NL, H, kin, out_w, has_norm, pad0, padl = ctx.meta
+        NL, H, kin, out_w, has_norm, pad0, padl, act, mode = ctx.meta
         if ctx.saved_acts is None or ctx.saved_acts[0] is None:
             raise RuntimeError("MlpFunction: no saved activations -- backward ran a second time without retain_graph "
                                "support, or the forward ran under no_grad")
@@ -427,31 +539,45 @@ class MlpFunction(torch.autograd.Function):
         x, Ws = t[0], list(t[1:1 + NL])
         scale = t[1 + NL] if has_norm else None
         Wk = [ctx.pads[0] if pad0 else Ws[0]] + Ws[1:-1] + [ctx.pads[1] if padl else Ws[-1]]
-        saveH, U, R = ctx.saved_acts
+        saveH, U, R, Ms, Zs = ctx.saved_acts
         dy = _f32c(dy)
         M, dev = x.shape[0], x.device
         kp, op = pad16(kin), pad16(out_w)
+        f = dict(dtype=torch.float32, device=dev)
         widths = [H] * (NL - 1) + [op]
-        dZ = [torch.empty(M, w, dtype=torch.float32, device=dev) for w in widths]
-        db = [torch.empty(w, dtype=torch.float32, device=dev) for w in widths]
-        dscale = torch.empty(H, dtype=torch.float32, device=dev) if has_norm else None
-        WT = [None] + [Wk[l].t().contiguous() for l in range(1, NL)]
-        din = []
+        zero = M == 0  # the launches return early: nothing would be written
+        mk = torch.zeros if zero else torch.empty
+        dZ = [mk(M, w, **f) for w in widths]
+        db = [mk(w, **f) for w in widths]
+        dscale = mk(H, **f) if has_norm else None
         dx = None
-        if ctx.needs_input_grad[0]:
-            if kin != H:
-                raise NotImplementedError("input gradient of a ragged-width MLP input is not needed by the path")
-            dx = torch.empty(M, H, dtype=torch.float32, device=dev)
-            din = [(Wk[0].t().contiguous(), None, dx)]
-        # bias gradients are a by-product of the weight-gradient kernel (it reads dZ anyway)
-        mlp_bwd(M, H, NL, dy, None, None, out_w, U, R, scale, saveH, WT, dZ, din, [None] * NL, dscale)
+        want_dx = ctx.needs_input_grad[0]
+        if want_dx and kin != H:
+            raise NotImplementedError("input gradient of a ragged-width MLP input is not needed by the path")
+        if want_dx:
+            dx = mk(M, H, **f)
+        if mode in ("enc", "full") and M > 0:
+            # packed split-bf16 chain: W^T units of layers NL-1 .. 1 (then layer 0's for the input gradient)
+            tr = [Wk[l] for l in range(NL - 1, 0, -1)] + ([Wk[0]] if want_dx else [])
+            pk = torch.empty(len(tr) * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+            units = [pk.data_ptr() + u * _capi.WPACK_BYTES for u in range(len(tr))]
+            wpack([(w.data_ptr(), H, True, units[u]) for u, w in enumerate(tr)], dev)
+            din = [(None, None, dx)] if want_dx else []
+            mlp_bwd(M, H, NL, dy, None, None, out_w, U, R, scale, saveH, [None] * NL, dZ, din, [None] * NL, dscale,
+                    wpk=units, Ms=Ms, Zs=Zs, act=act)
+        else:
+            WT = [None] + [Wk[l].t().contiguous() for l in range(1, NL)]
+            din = [(Wk[0].t().contiguous(), None, dx)] if want_dx else []
+            # bias gradients are a by-product of the weight-gradient kernel (it reads dZ anyway)
+            mlp_bwd(M, H, NL, dy, None, None, out_w, U, R, scale, saveH, WT, dZ, din, [None] * NL, dscale, act=act, Zs=Zs)
         ins = [x] + list(saveH)
         in_w = [kin] + [H] * (NL - 1)
-        dWs = [torch.empty(widths[l], pad16(in_w[l]), dtype=torch.float32, device=dev) for l in range(NL)]
+        dWs = [mk(widths[l], pad16(in_w[l]), **f) for l in range(NL)]
         jobs = []
         for l in range(NL):
             jobs.append((dZ[l], widths[l], widths[l] // 16, ins[l], in_w[l], pad16(in_w[l]) // 16, in_w[l], dWs[l], 0, pad16(in_w[l]), db[l]))
-        wgrad(jobs, dev)
+        if M > 0:
+            wgrad(jobs, dev)
         grads = []
         for l in range(NL):
             dW, dbl = dWs[l], db[l]
@@ -462,275 +588,442 @@ class MlpFunction(torch.autograd.Function):
             grads += [dW, dbl]
         if has_norm:
             grads.append(dscale)
-        return (dx, None, *grads)
+        ctx.saved_acts = None
+        return (dx, None, None, *grads)
 
 
 # ------------------------------------------------- processor: L GraphNetBlocks (R3-R5)
-PARAMS_PER_BLOCK = 18  # edge W0,b0..W3,b3,scale ; node W0,b0..W3,b3,scale
+def _split_block(q, spec: BlockSpec):
+    """block parameters (state_dict order) -> (We, be, se, Wn, bn, sn, gate params or None)"""
+    NL, k = spec.nb_layers, spec.mlp_params
+    We, be = [q[2 * l] for l in range(NL)], [q[2 * l + 1] for l in range(NL)]
+    se = q[2 * NL] if spec.layer_norm else None
+    Wn, bn = [q[k + 2 * l] for l in range(NL)], [q[k + 2 * l + 1] for l in range(NL)]
+    sn = q[k + 2 * NL] if spec.layer_norm else None
+    gp_ = tuple(q[2 * k: 2 * k + 3]) if spec.gate else None
+    return We, be, se, Wn, bn, sn, gp_
 
 
 class ProcessorFunction(torch.autograd.Function):
     """L rounds of gather -> edge MLP -> segment-sum -> node MLP -> residuals.
 
-    apply(x[N,H], e_sorted[E,H], topo, L, *params) -> (x_out, e_out_sorted)
-    ``e`` is in the topology's dst-sorted order.  params: 18 tensors per block in
-    state_dict order (edge_block.{0,2,4,6}.{weight,bias}, edge_block.7.scale,
-    node_block...).
+    apply(x[Nn,H], e_sorted[E,H], topo, L, spec, halo, pos, phi, rope_inv_freq, *params) -> (x_out, e_out_sorted)
+    ``e`` is in the topology's dst-sorted order.  params: ``spec.per_block`` tensors per block in
+    state_dict order (edge_block.{0,2,..}.{weight,bias}[, .scale], node_block..., [gate_proj.weight,
+    gate_proj.bias, gate_pos]).  ``halo`` (distributed.HaloState): the node-partitioned mesh -- ``x`` holds
+    the OWNED rows, the topology counts owned + ghost nodes, and once per round the projected latents of
+    the ghost sources are exchanged (overlapped with the edge rows that need no remote data).
     """
 
     @staticmethod
-    def forward(ctx, x, e, topo: Topology, L: int, *params):
+    def forward(ctx, x, e, topo: Topology, L: int, spec: BlockSpec, halo, pos, phi, rope_inv_freq, *params):
         _require_device(x, e, *params)
         x, e = _f32c(x), _f32c(e)
-        N, H = x.shape
+        Nn, H = x.shape            # node rows computed here (all of them, or the owned ones)
+        N = topo.N                 # node index space of the topology (owned + ghosts under a halo)
         E = e.shape[0]
+        NL, act, PB = spec.nb_layers, spec.act_id, spec.per_block
         if H not in SUPPORTED_H:
             raise NotImplementedError(f"hidden_size={H} not supported by the MI355X engine (16/32/64/128)")
-        if N != topo.N or E != topo.E:
+        if E != topo.E or (halo is None and Nn != N) or (halo is not None and (Nn != halo.n_own or N != halo.n_own + halo.n_ghost)):
             raise ValueError("x / edge_attr do not match the topology")
+        if len(params) != L * PB:
+            raise ValueError(f"expected {L} x {PB} block parameters, got {len(params)}")
+        if NL < 2 or NL > _capi.MAX_LAYERS:
+            raise AssertionError("The MLP must have at least 2 layers (input and output)." if NL < 2 else f"at most {_capi.MAX_LAYERS} layers per MLP")
         dev = x.device
         P = [_f32c(p) for p in params]
         need = any(ctx.needs_input_grad) and _saving()
         f = dict(dtype=torch.float32, device=dev)
-        saved = []
-        fuse_agg = (H == 128) and X6_ENABLED and E > 0 and _os.environ.get("MGN_NO_FUSED_AGG") is None
-        m = None if fuse_agg else torch.empty(E, H, **f)
-        part = torch.empty((E + 15) // 16, 2, H, **f) if fuse_agg else None
-        # H = 128: algebraic split of the first edge layer (W0 = [W_e | W_d | W_s]):
+        if spec.rope:
+            if pos is None:
+                raise ValueError("Node positions `pos` must be provided when use_rope=True.")
+            pos = _f32c(pos)
+            if pos.shape[1] < spec.rope_axes:
+                raise ValueError("pos has fewer columns than rope_axes")
+        if phi is not None:
+            phi = _f32c(phi).reshape(-1)
+        # packed split-bf16 kernels: H = 128, at most 4 layers per MLP
+        x6 = (H == 128) and X6_ENABLED and NL <= 4 and L > 0 and E > 0
+        # algebraic split of the first edge layer (W0 = [W_e | W_d | W_s]):
         #   W0.[e, x_dst, x_src] = W_e.e + (x W_d^T)[dst] + (x W_s^T)[src]
-        # the two node-level projections of round i+1 are post-products of round i's node
-        # kernel (x' still in registers); round 0's come from two small launches.
-        split = (H == 128)
-        Pd = Ps = None
-        # split-bf16 matrix path: all GEMM units of all rounds packed by one launch; per round
-        # [We0|e, We1, We2, We3, Wn0|x, Wn0|agg, Wn1, Wn2, Wn3, We0|x_dst, We0|x_src]
-        x6 = split and L > 0 and E > 0 and X6_ENABLED
+        # the two node-level projections of round i+1 are post-products of round i's node kernel (x'
+        # still in registers); round 0's come from two small launches.  RoPE rotates x_src per edge,
+        # so there the three slabs stay three gathered phases.
+        split = (H == 128) and NL <= 4 and not spec.rope and (x6 or act == 0) and L > 0 and E > 0
         prec = 1 if _matrix_precision == "bf16" else 0
         if prec and not x6 and L > 0 and E > 0:
             raise NotImplementedError("bf16 matrix mode needs hidden_size=128 (the packed split-bf16 kernels)")
         prec = prec if x6 else 0
-        NU = 11
+        if halo is not None and not (x6 and split):
+            raise NotImplementedError("the partitioned path runs on the packed H = 128 kernels (no RoPE)")
+        fuse_agg = x6 and _os.environ.get("MGN_NO_FUSED_AGG") is None
+        relu_bits = x6 and act == 0
+        # ---- packed units of all rounds, one launch.  Per round:
+        #   edge  [We0|e (, We0|x_dst, We0|x_src with RoPE), We1 .. We_{NL-1}]
+        #   node  [Wn0|x, Wn0|agg, Wn1 .. Wn_{NL-1}, NEXT round's We0|x_dst, We0|x_src (split)]
+        #   gate  [W_gate]
+        ne = NL + (2 if spec.rope else 0)
+        un0, up0 = ne, ne + NL + 1
+        ug = up0 + 2
+        NU = ug + (1 if spec.gate else 0)
         if x6:
-            # per round [We0|e, We1, We2, We3 | Wn0|x, Wn0|agg, Wn1, Wn2, Wn3, NEXT round's We0|x_dst, We0|x_src]:
-            # the units of every launch lie back to back (edge 0..3, node 4..8 + its two post-products 9..10);
-            # round 0's own projections sit in two extra slots at the end
             pk = torch.empty((L * NU + 2) * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
             pk0 = pk.data_ptr()
-            blocks = []
-            for i in range(L):
-                q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
-                We0, Wn0 = q[0].data_ptr(), q[9].data_ptr()
-                srcs = [(We0, 3 * H), (q[2].data_ptr(), H), (q[4].data_ptr(), H), (q[6].data_ptr(), H),
-                        (Wn0, 2 * H), (Wn0 + 4 * H, 2 * H), (q[11].data_ptr(), H), (q[13].data_ptr(), H), (q[15].data_ptr(), H)]
-                if i + 1 < L:
-                    Wnx = P[PARAMS_PER_BLOCK * (i + 1)].data_ptr()
-                    srcs += [(Wnx + 4 * H, 3 * H), (Wnx + 8 * H, 3 * H)]
-                for u, (sa, ld) in enumerate(srcs):
-                    blocks.append((sa, ld, False, pk0 + (i * NU + u) * _capi.WPACK_BYTES))
-            W00 = P[0].data_ptr()
-            blocks.append((W00 + 4 * H, 3 * H, False, pk0 + (L * NU) * _capi.WPACK_BYTES))
-            blocks.append((W00 + 8 * H, 3 * H, False, pk0 + (L * NU + 1) * _capi.WPACK_BYTES))
-            wpack(blocks, dev)
 
             def unit(i, u):
                 return pk0 + (i * NU + u) * _capi.WPACK_BYTES
-        if split and L > 0 and E > 0:
+
+            blocks = []
+            for i in range(L):
+                We, _, _, Wn, _, _, gpar = _split_block(P[PB * i: PB * (i + 1)], spec)
+                We0, Wn0 = We[0].data_ptr(), Wn[0].data_ptr()
+                srcs = [(We0, 3 * H)] + ([(We0 + 4 * H, 3 * H), (We0 + 8 * H, 3 * H)] if spec.rope else [])
+                srcs += [(We[l].data_ptr(), H) for l in range(1, NL)]
+                srcs += [(Wn0, 2 * H), (Wn0 + 4 * H, 2 * H)] + [(Wn[l].data_ptr(), H) for l in range(1, NL)]
+                for u, (sa, ld) in enumerate(srcs):
+                    blocks.append((sa, ld, False, unit(i, u)))
+                if split and i + 1 < L:
+                    Wnx = P[PB * (i + 1)].data_ptr()
+                    blocks += [(Wnx + 4 * H, 3 * H, False, unit(i, up0)), (Wnx + 8 * H, 3 * H, False, unit(i, up0 + 1))]
+                if spec.gate:
+                    blocks.append((gpar[0].data_ptr(), H, False, unit(i, ug)))
+            if split:
+                W00 = P[0].data_ptr()
+                blocks += [(W00 + 4 * H, 3 * H, False, unit(L, 0)), (W00 + 8 * H, 3 * H, False, unit(L, 1))]
+            wpack(blocks, dev)
+        Pd = Ps = None
+        pending = None  # halo exchange in flight
+        if split:
             W0 = P[0]
-            Pd, Ps = torch.empty(N, H, **f), torch.empty(N, H, **f)
+            Pd, Ps = torch.empty(Nn, H, **f), torch.empty(N, H, **f)
             for slab, dst_t in ((1, Pd), (2, Ps)):
-                mlp_fwd(N, H, [(x, None, H)], [W0[:, slab * H:(slab + 1) * H].contiguous()], [None], None, H, None, dst_t,
+                mlp_fwd(Nn, H, [(x, None, H)], [W0[:, slab * H:(slab + 1) * H].contiguous()], [None], None, H, None, dst_t,
                         wpk=[unit(L, slab - 1)] if x6 else (), precision=prec)
+            if halo is not None:
+                pending = halo.start_forward(Ps)
+        saved = []
         for i in range(L):
-            q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
-            We, be, se = [q[0], q[2], q[4], q[6]], [q[1], q[3], q[5], q[7]], q[8]
-            Wn, bn, sn = [q[9], q[11], q[13], q[15]], [q[10], q[12], q[14], q[16]], q[17]
+            We, be, se, Wn, bn, sn, gpar = _split_block(P[PB * i: PB * (i + 1)], spec)
             e_new = torch.empty(E, H, **f)
-            x_new = torch.empty(N, H, **f)
-            agg = torch.empty(N, H, **f)
+            x_new = torch.empty(Nn, H, **f)
+            agg = torch.empty(Nn, H, **f)
+            m = None if fuse_agg else torch.empty(E, H, **f)
+            He = Hn = Me = Mn = Ze = Zn = None
+            Ue = Re = Un = Rn = None
             if need:
-                He = [torch.empty(E, H, **f) for _ in range(3)]
-                Ue, Re = torch.empty(E, H, **f), torch.empty(E, **f)
-                Hn = [torch.empty(N, H, **f) for _ in range(3)]
-                Un, Rn = torch.empty(N, H, **f), torch.empty(N, **f)
-                # ReLU masks as bits (16 B per row and layer): what the backward chain reads
-                Me = [torch.empty(E, 4, dtype=torch.int32, device=dev) for _ in range(3)] if x6 else None
-                Mn = [torch.empty(N, 4, dtype=torch.int32, device=dev) for _ in range(3)] if x6 else None
-            else:
-                He = Hn = None
-                Ue = Re = Un = Rn = None
-                Me = Mn = None
+                He = [torch.empty(E, H, **f) for _ in range(NL - 1)]
+                Hn = [torch.empty(Nn, H, **f) for _ in range(NL - 1)]
+                if spec.layer_norm:
+                    Ue, Re = torch.empty(E, H, **f), torch.empty(E, **f)
+                    Un, Rn = torch.empty(Nn, H, **f), torch.empty(Nn, **f)
+                if relu_bits:  # ReLU masks as bits (16 B per row and layer): what the packed backward chain reads
+                    Me = [torch.empty(E, 4, dtype=torch.int32, device=dev) for _ in range(NL - 1)]
+                    Mn = [torch.empty(Nn, 4, dtype=torch.int32, device=dev) for _ in range(NL - 1)]
+                if act == 1:   # SiLU: the pre-activations
+                    Ze = [torch.empty(E, H, **f) for _ in range(NL - 1)]
+                    Zn = [torch.empty(Nn, H, **f) for _ in range(NL - 1)]
+            xj = None
+            if spec.rope:
+                xj = torch.empty(E, H, **f)
+                rope_gather(x, pos, rope_inv_freq, topo, spec.rope_axes, xj)
+
             # R3: m = edge_block(cat[e, x[dst], x[src]]);  e' = e + m     (layers.py:1017-1028,1039)
-            if split and E > 0:
-                mlp_fwd(E, H, [(e, None, H)], We, be, se, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
-                        adds=[(Pd, topo.dst_s), (Ps, topo.src_s)],
-                        wpk=[unit(i, u) for u in range(4)] if x6 else (), saveM=Me, precision=prec,
-                        seg=(topo.dst_s, topo.rowptr_dst, agg, part) if (fuse_agg and x6) else None)
-            else:
-                mlp_fwd(E, H, [(e, None, H), (x, topo.dst_s, H), (x, topo.src_s, H)], We, be, se, H, e, e_new, m, He, Ue, Re)
+            def edge_rows(r0, r1, rowptr, part_rows):
+                """rows [r0, r1) of the dst-sorted edge arrays (one launch); with the aggregation fused"""
+                sl = slice(r0, r1)
+                M = r1 - r0
+                sv = lambda ts: [t[sl] for t in ts] if ts is not None else None  # noqa: E731
+                seg = None
+                if fuse_agg:
+                    part = torch.empty((M + 15) // 16, 2, H, **f)
+                    seg = (topo.dst_s[sl], rowptr, agg, part)
+                y = m[sl] if m is not None else None
+                common = dict(saveM=sv(Me), saveZ=sv(Ze), act=act, precision=prec, seg=seg)
+                if spec.rope:
+                    mlp_fwd(M, H, [(e[sl], None, H), (x, topo.dst_s[sl], H), (xj[sl], None, H)], We, be, se, H, e[sl], e_new[sl], y,
+                            sv(He), Ue[sl] if Ue is not None else None, Re[sl] if Re is not None else None,
+                            wpk=[unit(i, u) for u in range(ne)] if x6 else (), **common)
+                elif split:
+                    mlp_fwd(M, H, [(e[sl], None, H)], We, be, se, H, e[sl], e_new[sl], y, sv(He),
+                            Ue[sl] if Ue is not None else None, Re[sl] if Re is not None else None, ldw0=3 * H,
+                            adds=[(Pd, topo.dst_s[sl]), (Ps, topo.src_s[sl])],
+                            wpk=[unit(i, u) for u in range(ne)] if x6 else (), **common)
+                else:
+                    mlp_fwd(M, H, [(e[sl], None, H), (x, topo.dst_s[sl], H), (x, topo.src_s[sl], H)], We, be, se, H, e[sl], e_new[sl], y,
+                            sv(He), Ue[sl] if Ue is not None else None, Re[sl] if Re is not None else None, act=act, saveZ=sv(Ze))
+                if fuse_agg:
+                    n0, n1 = part_rows
+                    seg_fix(rowptr[n0:n1 + 1], seg[3], agg[n0:n1])   # the kernel summed inside its wave tiles
+
+            if E > 0:
+                if halo is None:
+                    edge_rows(0, E, topo.rowptr_dst, (0, Nn))
+                else:
+                    # rows whose destination is an interior node need no remote data: they run while the
+                    # exchange of this round's ghost projections is in flight
+                    Ei, ni = halo.n_interior_edges, halo.n_interior
+                    if Ei > 0:
+                        edge_rows(0, Ei, topo.rowptr_dst, (0, ni))
+                    halo.finish_forward(pending)
+                    pending = None
+                    if E > Ei:
+                        edge_rows(Ei, E, halo.rowptr_bnd(topo), (ni, Nn))
+                    elif fuse_agg and Nn > ni:
+                        agg[ni:].zero_()
             # R4: agg = segment-sum of m over dst                          (layers.py:1031-1037)
-            if fuse_agg and x6 and split:
-                seg_fix(topo.rowptr_dst, part, agg)   # the edge kernel summed inside its wave tiles
-            else:
-                segsum(m, topo.rowptr_dst, None, agg)
+            if not fuse_agg:
+                segsum(m, topo.rowptr_dst[:Nn + 1], None, agg)
+            # gate on the aggregate (layers.py:1091-1098): agg * sigmoid(gate_proj(x) + phi * gate_pos)
+            agg_in, gate_t = agg, None
+            if spec.gate:
+                Wg, bg, gpos = gpar
+                G = torch.empty(Nn, H, **f)
+                mlp_fwd(Nn, H, [(x, None, H)], [Wg], [bg], None, H, None, G, wpk=[unit(i, ug)] if x6 else (), precision=prec)
+                agg_in = torch.empty(Nn, H, **f)
+                gate_t = torch.empty(Nn, H, **f) if need else None
+                gate_fwd(G, phi, gpos if phi is not None else None, agg, gate_t, agg_in)
             # R5: x' = x + node_block(cat[x, agg])                         (layers.py:1100-1101,1040)
             posts, Pd_n, Ps_n = (), None, None
-            if split and E > 0 and i + 1 < L:
-                W0n = P[PARAMS_PER_BLOCK * (i + 1)]
-                Pd_n, Ps_n = torch.empty(N, H, **f), torch.empty(N, H, **f)
+            if split and i + 1 < L:
+                W0n = P[PB * (i + 1)]
+                Pd_n, Ps_n = torch.empty(Nn, H, **f), torch.empty(N, H, **f)
                 posts = [(W0n.data_ptr() + 4 * H, Pd_n), (W0n.data_ptr() + 8 * H, Ps_n)]
             wn = ()
             if x6:
-                wn = [unit(i, u) for u in range(4, 9)] + ([unit(i, 9), unit(i, 10)] if posts else [])
-            mlp_fwd(N, H, [(x, None, H), (agg, None, H)], Wn, bn, sn, H, x, x_new, None, Hn, Un, Rn,
-                    posts=posts, post_ldw=3 * H, wpk=wn, saveM=Mn, precision=prec)
+                wn = [unit(i, un0 + u) for u in range(NL + 1)] + ([unit(i, up0), unit(i, up0 + 1)] if posts else [])
+            if Nn > 0:
+                mlp_fwd(Nn, H, [(x, None, H), (agg_in, None, H)], Wn, bn, sn, H, x, x_new, None, Hn, Un, Rn,
+                        posts=posts, post_ldw=3 * H, wpk=wn, saveM=Mn, saveZ=Zn, act=act, precision=prec)
+            if halo is not None and Ps_n is not None:
+                pending = halo.start_forward(Ps_n)
             if need:
-                saved.append((x, e, agg, He, Ue, Re, Hn, Un, Rn, Me, Mn))
+                saved.append(dict(x=x, e=e, agg=agg, agg_in=agg_in, gate=gate_t, xj=xj, He=He, Ue=Ue, Re=Re, Hn=Hn, Un=Un, Rn=Rn,
+                                  Me=Me, Mn=Mn, Ze=Ze, Zn=Zn))
             x, e = x_new, e_new
             Pd, Ps = Pd_n, Ps_n
-        ctx.topo, ctx.L, ctx.saved_acts, ctx.prec = topo, L, (saved if need else None), prec
+        ctx.topo, ctx.L, ctx.saved_acts, ctx.prec, ctx.spec, ctx.halo = topo, L, (saved if need else None), prec, spec, halo
+        ctx.aux = (pos, phi, rope_inv_freq, x6, split)
         ctx.save_for_backward(*P)  # version-checked by autograd (an optimiser step in between is an error)
         return x, e
 
     @staticmethod
     def backward(ctx, dx, de):
-        topo, L, saved, prec = ctx.topo, ctx.L, ctx.saved_acts, ctx.prec
+        topo, L, saved, prec, spec, halo = ctx.topo, ctx.L, ctx.saved_acts, ctx.prec, ctx.spec, ctx.halo
+        pos, phi, rope_inv_freq, x6, split = ctx.aux
         if saved is None:
             raise RuntimeError("ProcessorFunction: the saved activations were released by an earlier backward pass "
                                "(retain_graph is not supported: ~2.5 KB per edge and round are freed eagerly), "
                                "or the forward ran under no_grad")
         P = list(ctx.saved_tensors)
-        dev = P[0].device
+        NL, act, PB = spec.nb_layers, spec.act_id, spec.per_block
         N, E = topo.N, topo.E
+        if L == 0:
+            return (dx, de, None, None, None, None, None, None, None)
+        dev = P[0].device
         H = P[1].numel()
+        Nn = saved[0]["x"].shape[0]
         f = dict(dtype=torch.float32, device=dev)
-        dx = _f32c(dx) if dx is not None else torch.zeros(N, H, **f)
+        dx = _f32c(dx) if dx is not None else torch.zeros(Nn, H, **f)
         de = _f32c(de) if de is not None else torch.zeros(E, H, **f)
-        dZn = [torch.empty(N, H, **f) for _ in range(4)]
-        dZe = [torch.empty(E, H, **f) for _ in range(4)]
-        dAgg, Sd, Ss = torch.empty(N, H, **f), torch.empty(N, H, **f), torch.empty(N, H, **f)
-        dx_buf, de_buf = [torch.empty(N, H, **f), torch.empty(N, H, **f)], [torch.empty(E, H, **f), torch.empty(E, H, **f)]
-        grads: List[Optional[torch.Tensor]] = [None] * (PARAMS_PER_BLOCK * L)
+        empty = (E == 0 or Nn == 0)  # some launches return early at M == 0 and would leave their outputs unwritten
+        mk = torch.zeros if empty else torch.empty
+        dZn = [mk(Nn, H, **f) for _ in range(NL)]
+        dZe = [mk(E, H, **f) for _ in range(NL)]
+        dAgg, Sd, Ss = mk(Nn, H, **f), mk(N, H, **f), mk(N, H, **f)
+        dx_buf, de_buf = [mk(Nn, H, **f), mk(Nn, H, **f)], [mk(E, H, **f), mk(E, H, **f)]
+        grads: List[Optional[torch.Tensor]] = [None] * (PB * L)
         nb = H // 16
         HH = H * H
-        x6 = (H == 128) and X6_ENABLED and L > 0 and saved[0][9] is not None
-        NU = 11
+        k_ = spec.mlp_params
+        # ---- transposed weights of every round.  Packed: per round
+        #   [Wn_{NL-1}^T .. Wn_1^T, Wn0|agg^T] [We_{NL-1}^T .. We_1^T, We0|e^T] [Wn0|x^T, We0|x_dst^T, We0|x_src^T] [W_gate^T]
+        NU = 2 * NL + 3 + (1 if spec.gate else 0)
+        ukn, uke, ukx, ukg = 0, NL, 2 * NL, 2 * NL + 3
         if x6:
-            # split-bf16 path: the transposed GEMM units of every round packed by one launch; per
-            # round [Wn3^T, Wn2^T, Wn1^T, Wn0|agg^T, We3^T, We2^T, We1^T, We0|e^T, Wn0|x^T, We0|x_dst^T, We0|x_src^T]
             pk = torch.empty(L * NU * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
             pk0 = pk.data_ptr()
-            blocks = []
-            for i in range(L):
-                q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
-                We0, Wn0 = q[0].data_ptr(), q[9].data_ptr()
-                srcs = [(q[15].data_ptr(), H), (q[13].data_ptr(), H), (q[11].data_ptr(), H), (Wn0 + 4 * H, 2 * H),
-                        (q[6].data_ptr(), H), (q[4].data_ptr(), H), (q[2].data_ptr(), H), (We0, 3 * H),
-                        (Wn0, 2 * H), (We0 + 4 * H, 3 * H), (We0 + 8 * H, 3 * H)]
-                for u, (sa, ld) in enumerate(srcs):
-                    blocks.append((sa, ld, True, pk0 + (i * NU + u) * _capi.WPACK_BYTES))
-            wpack(blocks, dev)
 
             def unit(i, u):
                 return pk0 + (i * NU + u) * _capi.WPACK_BYTES
+
+            blocks = []
+            for i in range(L):
+                We, _, _, Wn, _, _, gpar = _split_block(P[PB * i: PB * (i + 1)], spec)
+                We0, Wn0 = We[0].data_ptr(), Wn[0].data_ptr()
+                srcs = [(Wn[l].data_ptr(), H) for l in range(NL - 1, 0, -1)] + [(Wn0 + 4 * H, 2 * H)]
+                srcs += [(We[l].data_ptr(), H) for l in range(NL - 1, 0, -1)] + [(We0, 3 * H)]
+                srcs += [(Wn0, 2 * H), (We0 + 4 * H, 3 * H), (We0 + 8 * H, 3 * H)]
+                if spec.gate:
+                    srcs.append((gpar[0].data_ptr(), H))
+                for u, (sa, ld) in enumerate(srcs):
+                    blocks.append((sa, ld, True, unit(i, u)))
+            wpack(blocks, dev)
             wt = None
         else:
-            # W^T operands of every round in one buffer, filled by one batched transpose launch:
-            # per round 11 H x H blocks  [WTn1..3 | WTe1..3 | WT0n_agg | WT0e_e | Wcat (H x 3H)]
-            wt = torch.empty(L, 11, H, H, **f)
+            # W^T operands of every round in one buffer, filled by one batched transpose launch: per round
+            #   [WTn_1..NL-1 | WTe_1..NL-1 | WT0n_agg | WT0e_e | Wcat (H x 3H) | WgT]
+            nblk = 2 * (NL - 1) + 2 + 3 + (1 if spec.gate else 0)
+            wt = torch.empty(L, nblk, H, H, **f)
             tb = []
             for i in range(L):
-                q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
-                base = wt.data_ptr() + 4 * (i * 11 * HH)
-                We0, Wn0 = q[0].data_ptr(), q[9].data_ptr()
-                for k, l in enumerate((1, 2, 3)):
-                    tb.append((q[9 + 2 * l].data_ptr(), H, base + 4 * (k * HH), H))          # WTn[l]
-                    tb.append((q[2 * l].data_ptr(), H, base + 4 * ((3 + k) * HH), H))        # WTe[l]
-                tb.append((Wn0 + 4 * H, 2 * H, base + 4 * (6 * HH), H))                      # (W0n[:, H:])^T
-                tb.append((We0, 3 * H, base + 4 * (7 * HH), H))                              # (W0e[:, :H])^T
-                cat = base + 4 * (8 * HH)                                                    # Wcat [H, 3H]
-                tb.append((Wn0, 2 * H, cat, 3 * H))                                          # (W0n[:, :H])^T
-                tb.append((We0 + 4 * H, 3 * H, cat + 4 * H, 3 * H))                          # (W0e[:, H:2H])^T
-                tb.append((We0 + 8 * H, 3 * H, cat + 8 * H, 3 * H))                          # (W0e[:, 2H:])^T
+                We, _, _, Wn, _, _, gpar = _split_block(P[PB * i: PB * (i + 1)], spec)
+                base = wt.data_ptr() + 4 * (i * nblk * HH)
+                We0, Wn0 = We[0].data_ptr(), Wn[0].data_ptr()
+                for k, l in enumerate(range(1, NL)):
+                    tb.append((Wn[l].data_ptr(), H, base + 4 * (k * HH), H))                    # WTn[l]
+                    tb.append((We[l].data_ptr(), H, base + 4 * ((NL - 1 + k) * HH), H))         # WTe[l]
+                o = 2 * (NL - 1)
+                tb.append((Wn0 + 4 * H, 2 * H, base + 4 * (o * HH), H))                         # (W0n[:, H:])^T
+                tb.append((We0, 3 * H, base + 4 * ((o + 1) * HH), H))                           # (W0e[:, :H])^T
+                cat = base + 4 * ((o + 2) * HH)                                                 # Wcat [H, 3H]
+                tb.append((Wn0, 2 * H, cat, 3 * H))                                             # (W0n[:, :H])^T
+                tb.append((We0 + 4 * H, 3 * H, cat + 4 * H, 3 * H))                             # (W0e[:, H:2H])^T
+                tb.append((We0 + 8 * H, 3 * H, cat + 8 * H, 3 * H))                             # (W0e[:, 2H:])^T
+                if spec.gate:
+                    tb.append((gpar[0].data_ptr(), H, base + 4 * ((o + 5) * HH), H))
             transpose_blocks(tb, H, dev)
-        # E == 0 / N == 0: some launches return early at M == 0 and would leave their outputs unwritten
-        _alloc = torch.zeros_like if (E == 0 or N == 0) else torch.empty_like
-        gs = [[_alloc(t) for t in P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]] for i in range(L)]
+        gs = [[(torch.zeros_like if empty else torch.empty_like)(t) for t in P[PB * i: PB * (i + 1)]] for i in range(L)]
         # packed path: the dX launch of round i and the node chain of round i-1 work on the same
         # rows -> one launch (front stage of mgn_mlp_bwd); dZn double buffered across rounds
         # (measured neutral at N = 30k rows -- 88 us fused vs 57 + 30 us: a launch costs as many tile
         # times as it has GEMM units -- so it is opt-in: MGN_FRONT=1; tests/test_hip_parity.py covers it)
-        fuse = x6 and _os.environ.get("MGN_FRONT") is not None
-        dZn_sets = [dZn, [torch.empty(N, H, **f) for _ in range(4)] if fuse and L > 1 else dZn]
+        fuse = (x6 and _os.environ.get("MGN_FRONT") is not None and spec == DEFAULT_SPEC and halo is None)
+        dZn_sets = [dZn, [torch.empty(Nn, H, **f) for _ in range(NL)] if fuse and L > 1 else dZn]
         node_done = False
         # scale-gradient partials of all chain launches, reduced by ONE launch at the end (MGN_NO_DEFER: per launch)
         deferred = [] if _os.environ.get("MGN_NO_DEFER") is None else None
 
-        def units(i):
-            return [unit(i, u) for u in range(4)], [unit(i, u) for u in range(4, 8)], [unit(i, u) for u in range(8, 11)]
-
         for i in reversed(range(L)):
-            q = P[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)]
-            We, se = [q[0], q[2], q[4], q[6]], q[8]
-            Wn, sn = [q[9], q[11], q[13], q[15]], q[17]
-            x, e, agg, He, Ue, Re, Hn, Un, Rn, Me, Mn = saved[i]
+            q = P[PB * i: PB * (i + 1)]
+            We, be, se, Wn, bn, sn, gpar = _split_block(q, spec)
+            S = saved[i]
+            x, e, agg, agg_in = S["x"], S["e"], S["agg"], S["agg_in"]
+            He, Ue, Re, Hn, Un, Rn = S["He"], S["Ue"], S["Re"], S["Hn"], S["Un"], S["Rn"]
             g = gs[i]
+            gWe = [g[2 * l] for l in range(NL)]
+            gbe = [g[2 * l + 1] for l in range(NL)]
+            gWn = [g[k_ + 2 * l] for l in range(NL)]
+            gbn = [g[k_ + 2 * l + 1] for l in range(NL)]
+            gse = g[2 * NL] if spec.layer_norm else None
+            gsn = g[k_ + 2 * NL] if spec.layer_norm else None
             dZn = dZn_sets[i & 1]
             if x6:
-                # never dereferenced on the packed path: any valid [H,H] / [H,3H] tensors do
-                WTn = WTe = [None, q[2], q[2], q[2]]
-                WT0n_agg = WT0e_e = q[2]
-                Wcat = q[0]
-                kn, ke, kx = units(i)
+                # never dereferenced on the packed path
+                WTn = WTe = [None] * NL
+                WT0n_agg = WT0e_e = Wcat = WgT = None
+                kn = [unit(i, ukn + u) for u in range(NL)]
+                ke = [unit(i, uke + u) for u in range(NL)]
+                kx = [unit(i, ukx + u) for u in range(3)]
+                kg = [unit(i, ukg)] if spec.gate else []
             else:
                 w = wt[i]
-                WTn = [None, w[0], w[1], w[2]]
-                WTe = [None, w[3], w[4], w[5]]
-                WT0n_agg, WT0e_e = w[6], w[7]
-                Wcat = w[8:11].reshape(H, 3 * H)
-                kn = ke = kx = ()
-            # node MLP chain: dX' -> dZn[3..0], dAgg = W0n[:,H:]^T dZn0  (already done by the
+                o = 2 * (NL - 1)
+                WTn = [None] + [w[k] for k in range(NL - 1)]
+                WTe = [None] + [w[NL - 1 + k] for k in range(NL - 1)]
+                WT0n_agg, WT0e_e = w[o], w[o + 1]
+                Wcat = w[o + 2:o + 5].reshape(H, 3 * H)
+                WgT = w[o + 5] if spec.gate else None
+                kn = ke = kx = kg = ()
+            # node MLP chain: dX' -> dZn[NL-1..0], dAgg = W0n[:,H:]^T dZn0  (already done by the
             # previous iteration's fused launch except for the last round)
-            if not node_done:
-                mlp_bwd(N, H, 4, dx, None, None, H, Un, Rn, sn, Hn, WTn, dZn, [(WT0n_agg, None, dAgg)],
-                        [None] * 4, g[17], wpk=kn, Ms=Mn, precision=prec, defer=deferred)
-            # edge MLP chain: dM = dE' + dAgg[dst] -> dZe[3..0], dE = dE' + W0e[:, :H]^T dZe0
+            if not node_done and Nn > 0:
+                mlp_bwd(Nn, H, NL, dx, None, None, H, Un, Rn, sn, Hn, WTn, dZn, [(WT0n_agg, None, dAgg)],
+                        [None] * NL, gsn, wpk=kn, Ms=S["Mn"], Zs=S["Zn"], act=act, precision=prec, defer=deferred)
+            dG = None
+            if spec.gate:  # d(agg * gate): dAgg <- dAggG * gate, dG = dAggG * agg * gate (1 - gate)
+                dG = torch.empty(Nn, H, **f)
+                gate_bwd(dAgg, agg, S["gate"], dAgg, dG)
+            # edge MLP chain: dM = dE' + dAgg[dst] -> dZe[NL-1..0], dE = dE' + W0e[:, :H]^T dZe0
             de_new = de_buf[0] if de.data_ptr() != de_buf[0].data_ptr() else de_buf[1]
-            mlp_bwd(E, H, 4, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
-                    [None] * 4, g[8], wpk=ke, Ms=Me, precision=prec, defer=deferred)
+            if E > 0:
+                mlp_bwd(E, H, NL, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
+                        [None] * NL, gse, wpk=ke, Ms=S["Me"], Zs=S["Ze"], act=act, precision=prec, defer=deferred)
+            else:
+                de_new = de
             # scatter of the first-layer pre-activations' grads onto dst / src nodes
-            if H == 128:
+            dx_res = dx
+            if spec.rope:
+                # the source slab saw ROTATED rows: T = W_s^T dz0 per edge, rotated back and summed over
+                # the edges of each source node, straight into the residual of the dX launch
+                segsum(dZe[0], topo.rowptr_dst, None, Sd)
+                T = torch.empty(E, H, **f)
+                WsT = None if x6 else Wcat[:, 2 * H:].contiguous()
+                mlp_fwd(E, H, [(dZe[0], None, H)], [WsT], [None], None, H, None, T, wpk=[kx[2]] if x6 else (), precision=prec)
+                dx_res = torch.empty(Nn, H, **f)
+                rope_scatter(T, pos, rope_inv_freq, topo, spec.rope_axes, dx, dx_res)
+            elif H == 128:
                 segsum2(dZe[0], topo.rowptr_dst, None, Sd, topo.rowptr_src, topo.perm_src, Ss)
             else:
                 segsum(dZe[0], topo.rowptr_dst, None, Sd)
                 segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)
+            back = None
+            if halo is not None:  # ghost rows of Ss go back to their owners while the E-row weight gradients run
+                back = halo.start_backward(Ss)
             # weight gradients: dW = dZ^T X
             # (A = dZ, B = layer input, dW slab[, db = bias gradient as a by-product])
-            jobs = [
-                (dZn[0], H, nb, x, H, nb, H, g[9], 0, 2 * H, g[10]),
-                (dZn[0], H, nb, agg, H, nb, H, g[9], H, 2 * H),
-                (dZe[0], H, nb, e, H, nb, H, g[0], 0, 3 * H, g[1]),
-                (Sd, H, nb, x, H, nb, H, g[0], H, 3 * H),
-                (Ss, H, nb, x, H, nb, H, g[0], 2 * H, 3 * H),
+            ejobs = [(dZe[0], H, nb, e, H, nb, H, gWe[0], 0, 3 * H, gbe[0])]
+            if spec.rope:
+                ejobs.append((dZe[0], H, nb, S["xj"], H, nb, H, gWe[0], 2 * H, 3 * H))
+            njobs = [
+                (dZn[0], H, nb, x, H, nb, H, gWn[0], 0, 2 * H, gbn[0]),
+                (dZn[0], H, nb, agg_in, H, nb, H, gWn[0], H, 2 * H),
+                (Sd[:Nn], H, nb, x, H, nb, H, gWe[0], H, 3 * H),
             ]
-            for l in (1, 2, 3):
-                jobs.append((dZn[l], H, nb, Hn[l - 1], H, nb, H, g[9 + 2 * l], 0, H, g[10 + 2 * l]))
-                jobs.append((dZe[l], H, nb, He[l - 1], H, nb, H, g[2 * l], 0, H, g[1 + 2 * l]))
-            wgrad(jobs, dev, prec)
-            # dX = dX' + W0n[:, :H]^T dZn0 + W0e[:, H:2H]^T Sd + W0e[:, 2H:]^T Ss
+            if not spec.rope:
+                njobs.append((Ss[:Nn], H, nb, x, H, nb, H, gWe[0], 2 * H, 3 * H))
+            for l in range(1, NL):
+                njobs.append((dZn[l], H, nb, Hn[l - 1], H, nb, H, gWn[l], 0, H, gbn[l]))
+                ejobs.append((dZe[l], H, nb, He[l - 1], H, nb, H, gWe[l], 0, H, gbe[l]))
+            if spec.gate:
+                gWg, gbg, gpos = g[2 * k_], g[2 * k_ + 1], g[2 * k_ + 2]
+                njobs.append((dG, H, nb, x, H, nb, H, gWg, 0, H, gbg))
+            if halo is not None:
+                if E > 0:
+                    wgrad(ejobs, dev, prec)
+                halo.finish_backward(back, Ss)
+                if Nn > 0:
+                    wgrad(njobs, dev, prec)
+            elif E > 0 and Nn > 0:
+                # one launch for the whole round: node first-layer jobs, edge first-layer jobs, the two
+                # scattered slabs, then the deeper layers alternating node / edge (same plan as round 1)
+                n_sc = 1 if spec.rope else 2
+                deep = [j for pair in zip(njobs[2 + n_sc:2 + n_sc + NL - 1], ejobs[len(ejobs) - (NL - 1):]) for j in pair]
+                wgrad(njobs[:2] + ejobs[:len(ejobs) - (NL - 1)] + njobs[2:2 + n_sc] + deep + (njobs[-1:] if spec.gate else []), dev, prec)
+            if spec.gate:
+                if phi is not None:  # d gate_pos = sum_n phi[n] * dG[n, :]  (a [H, 1] weight-gradient job)
+                    tmp = torch.empty(H, 16, **f)
+                    wgrad([(dG, H, nb, phi.reshape(-1, 1), 1, 1, 1, tmp, 0, 16)], dev)
+                    gpos.copy_(tmp[:, 0])
+                else:
+                    gpos.zero_()
+            # dX = dX' + W0n[:, :H]^T dZn0 + W0e[:, H:2H]^T Sd + W0e[:, 2H:]^T Ss  (+ W_gate^T dG)
             dx_new = dx_buf[0] if dx.data_ptr() != dx_buf[0].data_ptr() else dx_buf[1]
             if fuse and i > 0:  # ... fused with the node chain of round i-1 (same rows)
-                qp = P[PARAMS_PER_BLOCK * (i - 1): PARAMS_PER_BLOCK * i]
-                _, _, _, _, _, _, Hn_p, Un_p, Rn_p, _, Mn_p = saved[i - 1]
-                kn_p, _, _ = units(i - 1)
-                mlp_bwd(N, H, 4, dx, None, None, H, Un_p, Rn_p, qp[17], Hn_p, WTn, dZn_sets[(i - 1) & 1],
-                        [(WT0n_agg, None, dAgg)], [None] * 4, gs[i - 1][17], wpk=kx + kn_p, Ms=Mn_p, precision=prec,
+                Sp = saved[i - 1]
+                _, _, _, _, _, snp, _ = _split_block(P[PB * (i - 1): PB * i], spec)
+                kn_p = [unit(i - 1, ukn + u) for u in range(NL)]
+                mlp_bwd(Nn, H, NL, dx, None, None, H, Sp["Un"], Sp["Rn"], snp, Sp["Hn"], WTn, dZn_sets[(i - 1) & 1],
+                        [(WT0n_agg, None, dAgg)], [None] * NL, gs[i - 1][k_ + 2 * NL], wpk=kx + kn_p, Ms=Sp["Mn"], precision=prec,
                         front=([dZn[0], Sd, Ss], dx, dx_new), defer=deferred)
                 node_done = True
-            else:
-                mlp_fwd(N, H, [(dZn[0], None, H), (Sd, None, H), (Ss, None, H)], [Wcat], [None], None, H, dx, dx_new, wpk=kx, precision=prec)
+            elif Nn > 0:
+                if spec.rope:
+                    Wc2 = None if x6 else Wcat[:, :2 * H].contiguous()
+                    mlp_fwd(Nn, H, [(dZn[0], None, H), (Sd[:Nn], None, H)], [Wc2], [None], None, H, dx_res, dx_new,
+                            wpk=kx[:2] if x6 else (), precision=prec)
+                else:
+                    mlp_fwd(Nn, H, [(dZn[0], None, H), (Sd[:Nn], None, H), (Ss[:Nn], None, H)], [Wcat], [None], None, H, dx, dx_new,
+                            wpk=kx, precision=prec)
+                if spec.gate:
+                    dx_g = torch.empty(Nn, H, **f)
+                    mlp_fwd(Nn, H, [(dG, None, H)], [WgT], [None], None, H, dx_new, dx_g, wpk=kg, precision=prec)
+                    dx_new = dx_g
                 node_done = False
-            grads[PARAMS_PER_BLOCK * i: PARAMS_PER_BLOCK * (i + 1)] = g
+            else:
+                dx_new = dx
+            grads[PB * i: PB * (i + 1)] = g
             dx, de = dx_new, de_new
         colred_batch(deferred, dev)
         ctx.saved_acts = None
-        return (dx, de, None, None, *grads)
+        return (dx, de, None, None, None, None, None, None, None, *grads)

@@ -30,7 +30,8 @@ class EncodeProcessDecode(nn.Module):
         if self.use_rope and self.rope_axes not in (2, 3):
             raise ValueError("rope_pos_dimension must be 2 or 3 when use_rope_embeddings=True.")
         if use_temporal_block:
-            raise NotImplementedError("TemporalAttention tail is a 'next' row (SURVEY.md N3)")
+            raise NotImplementedError("TemporalAttention tail (training.use_temporal_block) is not built yet (SURVEY.md N3/N4: "
+                                      "it runs on the sparse-attention kernels of the Transformer processor)")
         self.temporal_block = None
         if not self.only_processor:
             self.nodes_encoder = build_mlp(node_input_size, hidden_size, hidden_size)
@@ -56,10 +57,20 @@ class EncodeProcessDecode(nn.Module):
             x = self.nodes_encoder(graph.x)
             # encode edges directly in the engine's dst-sorted order (F_e floats per edge to permute)
             e = self.edges_encoder(graph.edge_attr[perm])
-        params = []
-        for block in self.processor_list:
-            params += _block_params(block)
-        x, _ = ops.processor_apply(x, e, topo, len(self.processor_list), *params)
+        blocks = list(self.processor_list)
+        pos = getattr(graph, "pos", None) if self.use_rope else None
+        phi = getattr(graph, "phi", None) if self.use_gate else None
+        if self.use_gated_mlp:
+            from .gated import gated_block_forward
+            for block in blocks:
+                x, e = gated_block_forward(block, x, e, topo, pos, phi)
+        elif blocks:
+            params = []
+            for block in blocks:
+                params += _block_params(block)
+            b0 = blocks[0]
+            x, _ = ops.processor_apply(x, e, topo, len(blocks), *params, spec=b0.spec, pos=pos, phi=phi,
+                                       rope_inv_freq=b0._rope_inv_freq if self.use_rope else None)
         if self.only_processor:
             return x
         return self.decode_module(x)

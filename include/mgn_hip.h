@@ -73,7 +73,7 @@ int mgn_segsum2(const float* src, const int32_t* rowptr0, const int32_t* perm0, 
 /* ------------------------------------------------------------ fused MLP forward
  * For each row m in [0,M):
  *   in  = cat_p src[p][ idx[p] ? idx[p][m] : m , 0:kw[p] ]      (p < nphase)
- *   z   = W[NL-1] act(... act(W[0] in + b[0]) ...) + b[NL-1]     (act = ReLU)
+ *   z   = W[NL-1] act(... act(W[0] in + b[0]) ...) + b[NL-1]     (act = ReLU, or SiLU: field `act`)
  *   y   = scale ? scale * z / (||z||_2/sqrt(H) + eps) : z        (RMSNorm, layers.py:104-129)
  *   out = (resid ? resid[m] : 0) + y ;   y_out = y (optional)
  * W[0] is [Hout, ktot] with ktot = sum_p pad16(kw[p]) and phase p occupying columns
@@ -129,8 +129,9 @@ typedef struct {
    * and every stored tensor stay fp32) -- the semantic of the reference under bf16-mixed
    * autocast (train.py:74-78,268-293), BASELINE configs[2]. */
   int precision;
-  /* out = relu(z) instead of z (generic ragged-input kernel only; no norm / residual): lets an
-   * encoder run its narrow first layer stand-alone and the three full layers on the packed path. */
+  /* out = act(z) instead of z (generic ragged-input kernel only; no norm / residual): lets an
+   * encoder run its narrow first layer stand-alone and the three full layers on the packed path
+   * (y_out, if given, still receives z: the pre-activation a SiLU backward needs). */
   int out_relu;
   /* Fused segment sum (split-bf16 kernel, no post-products): rows are sorted by seg_key[m] (the
    * CSR order), seg_rowptr[k] .. seg_rowptr[k+1] is the row range of key k.  The kernel adds up
@@ -143,7 +144,16 @@ typedef struct {
   const int32_t* seg_rowptr;
   float* seg_out;
   float* seg_part;
+  /* Activation between the layers: MGN_ACT_RELU (0) or MGN_ACT_SILU (1) -- the reference's
+   * process-global switch (layers.py:132-160, JSON model.use_silu_activation).  SiLU is not
+   * invertible, so its backward needs the PRE-activations: saveZ[l] ([M,H], optional) receives
+   * the input of the activation that follows layer l (saveM is ReLU-only).  Supported by the
+   * generic and the split-bf16 kernels (not by the exact-fp32 LDS generation). */
+  int act;
+  float* saveZ[MGN_MAX_LAYERS];
 } mgn_mlp_fwd_args;
+#define MGN_ACT_RELU 0
+#define MGN_ACT_SILU 1
 int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream);
 
 /* ----------------------------------------------------- fused MLP backward chain
@@ -195,6 +205,10 @@ typedef struct {
   /* != 0: leave the column sums (db[], dscale) as per-workgroup partials in red_ws -- which must
    * then stay alive -- and finish many launches at once with mgn_colred_batch. */
   int defer_reduce;
+  /* activation as in mgn_mlp_fwd_args; for MGN_ACT_SILU Zs[l-1] = saveZ[l-1] of the forward launch
+   * (pre-activations) replaces Hs / Ms:  dZ[l-1] = (WT[l] dZ[l]) * silu'(Zs[l-1]). */
+  int act;
+  const float* Zs[MGN_MAX_LAYERS];
 } mgn_mlp_bwd_args;
 size_t mgn_mlp_bwd_workspace_bytes(int64_t M, int H, int NL);
 int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream);
@@ -344,6 +358,39 @@ size_t mgn_clip_adamw_workspace_bytes(int n, const mgn_opt_tensor* tensors);
 int mgn_clip_adamw(int n, const mgn_opt_tensor* tensors, float max_norm, const float* lr, float* step,
                    float beta1, float beta2, float eps, float weight_decay, float* grad_norm_out,
                    void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------- halo exchange
+ * One-hop halo of the node-partitioned large mesh (no reference counterpart: the reference's
+ * Cluster-GCN sub-meshing, graphphysics/utils/torch_graph.py:108-135, drops the cut edges).
+ * mgn_gather_rows: out[i,:] = src[idx[i],:], i < n -- packs the rows a peer needs.
+ * mgn_halo_unpack_add: dst[nodes[j],:] += sum_{k in [rowptr[j], rowptr[j+1])} rows[perm[k],:], k
+ * ascending -- the backward of the exchange: ghost-row gradients summed into their owners in a
+ * fixed order (the send list grouped by node; atomics-free => bit-deterministic).  H % 4 == 0. */
+int mgn_gather_rows(const float* src, const int32_t* idx, int64_t n, int H, float* out, void* stream);
+int mgn_halo_unpack_add(const float* rows, const int32_t* nodes, const int32_t* rowptr, const int32_t* perm,
+                        int64_t n_nodes, int H, float* dst, void* stream);
+
+/* ------------------------------------------------- GraphNetBlock variants
+ * Sigmoid gate on the aggregated messages (graphphysics/models/layers.py:1091-1098,
+ * JSON model.use_gated_attention):  gate = sigmoid(G + phi[n] * gate_pos[j]) with G = gate_proj(x)
+ * (an mgn_mlp_fwd launch), agg_out = agg * gate.  phi / gate_pos may be NULL (no positional term),
+ * gate_out may be NULL (inference).  Backward: dAgg = dAggG * gate (may alias dAggG),
+ * dG = dAggG * agg * gate * (1 - gate). */
+int mgn_gate_fwd(const float* G, const float* phi, const float* gate_pos, const float* agg, int64_t N, int H,
+                 float* gate_out, float* agg_out, void* stream);
+int mgn_gate_bwd(const float* dAggG, const float* agg, const float* gate, int64_t N, int H, float* dAgg, float* dG,
+                 void* stream);
+/* Relative RoPE on the source-node features (layers.py:1020-1026,1104-1149, JSON
+ * model.use_rope_embeddings): out[k,:] = RoPE(x[src[k],:], pos[src[k]] - pos[dst[k]]); the first
+ * 2*pair_count*axes channels are rotated pairwise, pair i of axis a by (delta pos)[a] * inv_freq[i]
+ * (inv_freq: the block's _rope_inv_freq buffer, layers.py:972-976), the rest pass through.
+ * mgn_rope_scatter is its transpose summed over the edges of each source node (src-grouped CSR over
+ * the same edge rows): out[j,:] = resid[j,:] + sum_{k: src[k] = j} RoPE^T(T[k,:]), fixed order. */
+int mgn_rope_gather(const float* x, const float* pos, int pos_w, const float* inv_freq, int pair_count, int axes,
+                    const int32_t* src, const int32_t* dst, int64_t E, int H, float* out, void* stream);
+int mgn_rope_scatter(const float* T, const float* pos, int pos_w, const float* inv_freq, int pair_count, int axes,
+                     const int32_t* src, const int32_t* dst, const int32_t* rowptr_src, const int32_t* perm_src,
+                     int64_t N, int H, const float* resid, float* out, void* stream);
 
 /* text of the last error of the entry points in this section */
 const char* mgn_prep_last_error(void);

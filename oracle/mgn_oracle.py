@@ -83,22 +83,62 @@ def mlp(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str, act: str = "re
     """
     f = torch.relu if act == "relu" else torch.nn.functional.silu
     h = x
-    for i in (0, 2, 4, 6):
+    idx = []  # Linear entries 0, 2, 4, ... (nb_of_layers of them; 4 unless the block was built otherwise)
+    while f"{prefix}{2 * len(idx)}.weight" in p:
+        idx.append(2 * len(idx))
+    for i in idx:
         W, b = p[f"{prefix}{i}.weight"], p[f"{prefix}{i}.bias"]
         if _BF16_MIXED:
             h = torch.nn.functional.linear(h.to(torch.bfloat16), W.to(torch.bfloat16), b.to(torch.bfloat16))
         else:
             h = torch.nn.functional.linear(h, W, b)
-        if i != 6:
+        if i != idx[-1]:
             if pre_out is not None:
                 pre_out.append(h.detach())
             h = f(h)
     if _BF16_MIXED:
         h = h.float()  # norm runs in fp32 under CUDA autocast; bf16 / fp32 promotes to fp32 (exact widening)
-    key = f"{prefix}7.scale"
+    key = f"{prefix}{idx[-1] + 1}.scale"
     if key in p:
         h = rms_norm(h, p[key])
     return h
+
+
+def gated_mlp(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str, act: str = "relu") -> torch.Tensor:
+    """build_gated_mlp, graphphysics/models/layers.py:256-278: Sequential(RMSNorm(in) [entry 0],
+    GatedMLP [entry 1: act(linear1 x) * linear2 x, layers.py:249-253; activation SiLU when the global
+    switch is set, else GELU, :235-236], Linear [entry 2])."""
+    h = rms_norm(x, p[prefix + "0.scale"])
+    a = torch.nn.functional.silu if act == "silu" else torch.nn.functional.gelu
+    left = a(torch.nn.functional.linear(h, p[prefix + "1.linear1.weight"], p[prefix + "1.linear1.bias"]))
+    right = torch.nn.functional.linear(h, p[prefix + "1.linear2.weight"], p[prefix + "1.linear2.bias"])
+    return torch.nn.functional.linear(left * right, p[prefix + "2.weight"], p[prefix + "2.bias"])
+
+
+def rope_inv_freq(hidden_size: int, rope_axes: int, rope_base: float) -> torch.Tensor:
+    """GraphNetBlock.__init__, layers.py:965-976"""
+    pair_count = hidden_size // (2 * rope_axes)
+    inv = torch.arange(pair_count, dtype=torch.float32)
+    return torch.pow(rope_base, -inv / max(float(pair_count), 1.0))
+
+
+def apply_rope_rel(x_src: torch.Tensor, delta_pos: torch.Tensor, inv_freq: torch.Tensor, rope_axes: int) -> torch.Tensor:
+    """GraphNetBlock._apply_rope_rel, layers.py:1104-1149: per axis, pairs (even, odd) of the next
+    2*pair_count channels rotate by theta = delta[axis] * inv_freq[pair]."""
+    pair_count = inv_freq.numel()
+    if pair_count == 0:
+        return x_src
+    E = x_src.shape[0]
+    rope_dim = pair_count * 2 * rope_axes
+    parts, start = [], 0
+    for axis in range(rope_axes):
+        seg = x_src[:, start:start + 2 * pair_count].reshape(E, pair_count, 2)
+        theta = delta_pos[:, axis].unsqueeze(1) * inv_freq.unsqueeze(0)
+        c, s_ = torch.cos(theta), torch.sin(theta)
+        even, odd = seg[..., 0], seg[..., 1]
+        parts.append(torch.stack([even * c - odd * s_, even * s_ + odd * c], dim=-1).reshape(E, 2 * pair_count))
+        start += 2 * pair_count
+    return torch.cat(parts + [x_src[:, rope_dim:]], dim=-1)
 
 
 # ------------------------------------------------------------------- R3, R4, R5
@@ -110,6 +150,9 @@ def graph_net_block(
     prefix: str,
     act: str = "relu",
     return_intermediates: bool = False,
+    variant: Optional[dict] = None,
+    pos: Optional[torch.Tensor] = None,
+    phi: Optional[torch.Tensor] = None,
 ):
     """GraphNetBlock.forward, graphphysics/models/layers.py:989-1042.
 
@@ -121,14 +164,31 @@ def graph_net_block(
     node_block(cat[x, agg]) (layers.py:1100-1101); residuals layers.py:1039-1040
     -- note the aggregated message is the PRE-residual MLP output.
     """
+    v = variant or {}
     row, col = edge_index[0], edge_index[1]
     x_i = x[col]
     x_j = x[row]
+    if v.get("use_rope"):  # layers.py:1020-1026: relative RoPE on the SOURCE features
+        axes = v.get("rope_axes", 3)
+        delta_pos = pos[row, :axes] - pos[col, :axes]
+        x_j = apply_rope_rel(x_j, delta_pos, rope_inv_freq(x.shape[1], axes, v.get("rope_base", 10000.0)), axes)
     pre_e: Optional[List[torch.Tensor]] = [] if return_intermediates else None
     pre_n: Optional[List[torch.Tensor]] = [] if return_intermediates else None
-    m = mlp(torch.cat([e, x_i, x_j], dim=-1), p, prefix + "edge_block.", act, pre_e)
+    gated = v.get("use_gated_mlp", False)
+    if gated:  # layers.py:932-942
+        m = gated_mlp(torch.cat([e, x_i, x_j], dim=-1), p, prefix + "edge_block.", act)
+    else:
+        m = mlp(torch.cat([e, x_i, x_j], dim=-1), p, prefix + "edge_block.", act, pre_e)
     agg = torch.zeros(x.shape[0], m.shape[1], dtype=m.dtype).index_add_(0, col, m)
-    upd = mlp(torch.cat([x, agg], dim=-1), p, prefix + "node_block.", act, pre_n)
+    if v.get("use_gate"):  # update(), layers.py:1091-1098
+        logits = torch.nn.functional.linear(x, p[prefix + "gate_proj.weight"], p[prefix + "gate_proj.bias"])
+        if phi is not None:
+            logits = logits + phi.view(-1, 1) * p[prefix + "gate_pos"].view(1, -1)
+        agg = agg * torch.sigmoid(logits)
+    if gated:
+        upd = gated_mlp(torch.cat([x, agg], dim=-1), p, prefix + "node_block.", act)
+    else:
+        upd = mlp(torch.cat([x, agg], dim=-1), p, prefix + "node_block.", act, pre_n)
     e_new = e + m
     x_new = x + upd
     if return_intermediates:
@@ -147,9 +207,14 @@ def epd_forward(
     act: str = "relu",
     per_round: Optional[List[torch.Tensor]] = None,
     intermediates: Optional[List[dict]] = None,
+    variant: Optional[dict] = None,
+    pos: Optional[torch.Tensor] = None,
+    phi: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
-    """EncodeProcessDecode.forward, graphphysics/models/processors.py:162-215
-    (rope / gate / temporal block off -- the defaults of every shipped JSON)."""
+    """EncodeProcessDecode.forward, graphphysics/models/processors.py:162-215.  ``variant``: the block
+    options the constructor forwards (:129-160: use_rope / rope_axes / rope_base / use_gate /
+    use_gated_mlp); ``act`` = the global SiLU switch; ``pos`` / ``phi`` as read off the graph
+    (:186-192).  The temporal block is not restated."""
     if only_processor:
         x, e = x_in, edge_attr_in  # processors.py:176-177
     else:
@@ -157,10 +222,11 @@ def epd_forward(
         e = mlp(edge_attr_in, p, "edges_encoder.", act)  # processors.py:180
     for i in range(message_passing_num):  # processors.py:193-202
         if intermediates is not None:
-            x, e, inter = graph_net_block(x, e, edge_index, p, f"processor_list.{i}.", act, return_intermediates=True)
+            x, e, inter = graph_net_block(x, e, edge_index, p, f"processor_list.{i}.", act, return_intermediates=True,
+                                          variant=variant, pos=pos, phi=phi)
             intermediates.append(inter)
         else:
-            x, e = graph_net_block(x, e, edge_index, p, f"processor_list.{i}.", act)
+            x, e = graph_net_block(x, e, edge_index, p, f"processor_list.{i}.", act, variant=variant, pos=pos, phi=phi)
         if per_round is not None:
             per_round.append(x)
     if only_processor:

@@ -106,3 +106,60 @@ def trajectory(n: int, steps: int, seed: int):
         xs.append(torch.from_numpy(x))
         ys.append(torch.from_numpy(vel[t + 1]))
     return pos, edge_index, edge_attr[:, :3], xs, ys
+
+
+# ---------------------------------------------------------------- GraphNetBlock variants (N3)
+#: name -> options.  ``variant`` is what the oracle takes, ``act`` the global activation switch,
+#: ``phi``: feed a per-node scalar to the gate.
+VARIANTS = {
+    "silu": dict(seed=1, act="silu", variant={}),
+    "gate": dict(seed=2, act="relu", variant={"use_gate": True}),
+    "gate_phi": dict(seed=3, act="relu", variant={"use_gate": True}, phi=True),
+    "rope3": dict(seed=4, act="relu", variant={"use_rope": True, "rope_axes": 3, "rope_base": 10000.0}),
+    "rope2": dict(seed=5, act="relu", variant={"use_rope": True, "rope_axes": 2, "rope_base": 100.0}),
+    "gated": dict(seed=6, act="relu", variant={"use_gated_mlp": True}),
+    "gated_silu": dict(seed=7, act="silu", variant={"use_gated_mlp": True, "use_gate": True}, phi=True),
+    "l3nonorm": dict(seed=8, act="relu", variant={}, nb_of_layers=3, layer_norm=False),
+    "combo": dict(seed=9, act="silu", variant={"use_gate": True, "use_rope": True, "rope_axes": 3, "rope_base": 10000.0}, phi=True),
+}
+
+
+def block_kwargs(v):
+    """GraphNetBlock(...) keyword arguments of a variant (reference signature, layers.py:896-906)"""
+    vv = v["variant"]
+    kw = dict(use_rope=vv.get("use_rope", False), rope_axes=vv.get("rope_axes", 3), rope_base=vv.get("rope_base", 10000.0),
+              use_gated_mlp=vv.get("use_gated_mlp", False), use_gate=vv.get("use_gate", False))
+    if "nb_of_layers" in v:
+        kw.update(nb_of_layers=v["nb_of_layers"], layer_norm=v["layer_norm"])
+    return kw
+
+
+def epd_kwargs(v):
+    """EncodeProcessDecode(...) keyword arguments (processors.py:67-81; nb_of_layers / layer_norm are not
+    reachable through it, so the l3nonorm variant is block-only there and runs the default EPD)"""
+    vv = v["variant"]
+    return dict(use_rope_embeddings=vv.get("use_rope", False), rope_pos_dimension=vv.get("rope_axes", 3),
+                rope_base=vv.get("rope_base", 10000.0), use_gated_mlp=vv.get("use_gated_mlp", False),
+                use_gated_attention=vv.get("use_gate", False))
+
+
+def variant_params(state_dict, seed: int, key_order=None) -> "OrderedDict[str, torch.Tensor]":
+    """deterministic weights for ANY module layout: shapes are read off ``state_dict`` (key order), values
+    come from the numpy stream -- weights uniform(+-sqrt(6/fan_in)), biases / gate_pos uniform(+-0.1),
+    norm scales 1 + 0.1 N(0,1)"""
+    rng = np.random.default_rng(seed)
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    order = list(key_order) if key_order is not None else list(state_dict.keys())
+    assert set(order) == set(state_dict.keys()), sorted(set(order) ^ set(state_dict.keys()))
+    for k in order:
+        t = state_dict[k]
+        s = tuple(t.shape)
+        if k.endswith("scale"):
+            v = 1.0 + 0.1 * rng.standard_normal(size=s)
+        elif len(s) == 2:
+            a = np.sqrt(6.0 / s[1])
+            v = rng.uniform(-a, a, size=s)
+        else:
+            v = rng.uniform(-0.1, 0.1, size=s)
+        out[k] = torch.from_numpy(v.astype(np.float32))
+    return out

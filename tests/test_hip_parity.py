@@ -239,7 +239,7 @@ def test_epd_per_round_vs_oracle(dev):
         e = net.edges_encoder(R.randn((ea.shape[0], 3), seed + 2).to(dev)[topo.perm_dst.long()])
         from graph_physics_amd.layers import _block_params
         for i, blk in enumerate(net.processor_list):
-            x, e = ops.ProcessorFunction.apply(x, e, topo, 1, *_block_params(blk))
+            x, e = ops.processor_apply(x, e, topo, 1, *_block_params(blk))
             assert rel_err(x, per[i]) < FWD_TOL, f"round {i}"
             assert rel_err(x[0], g["x_round_row0"][i]) < 2e-5, f"round {i}"
 

@@ -42,8 +42,35 @@ def test_error_conventions():
         gp.EncodeProcessDecode(1, 2, 2, 2, use_rope_embeddings=True, rope_pos_dimension=4)  # processors.py:113
     with pytest.raises(ValueError, match="Model type 'foo' not supported."):
         gp.get_model({"model": {"type": "foo", "node_input_size": 2}})  # parse_parameters.py:162
+    with pytest.raises(ValueError, match="too small"):
+        gp.GraphNetBlock(4, use_rope=True, rope_axes=3)  # layers.py:968-971
     with pytest.raises(NotImplementedError):
-        gp.GraphNetBlock(16, use_gate=True)  # N3 row: not silently mis-computed
+        gp.EncodeProcessDecode(1, 2, 2, 2, use_temporal_block=True)  # not built: never silently mis-computed
+    blk = gp.GraphNetBlock(16, use_rope=True)
+    with pytest.raises(ValueError, match="pos"):
+        blk(torch.zeros(3, 16), torch.zeros(2, 2, dtype=torch.int64), torch.zeros(2, 16))  # layers.py:1021-1024
+
+
+def test_block_variants_construct_with_reference_state_dict_keys():
+    """N3: the JSON keys use_silu_activation / use_gated_attention / use_gated_mlp / use_rope_embeddings
+    construct, with the reference's parameter names (layers.py:932-987, 213-278)."""
+    b = gp.GraphNetBlock(32, use_gate=True, use_rope=True, rope_axes=2)
+    keys = set(b.state_dict())
+    assert {"gate_pos", "gate_proj.weight", "gate_proj.bias"} <= keys and "_rope_inv_freq" not in keys
+    assert b._rope_inv_freq.numel() == 32 // 4 and abs(float(b._rope_inv_freq[1]) - 10000.0 ** (-1 / 8)) < 1e-7
+    g = gp.GraphNetBlock(32, use_gated_mlp=True)
+    assert {"edge_block.0.scale", "edge_block.1.linear1.weight", "edge_block.1.linear2.bias", "edge_block.2.weight"} <= set(g.state_dict())
+    assert g.edge_block[1].linear1.weight.shape == (96, 96) and g.node_block[2].weight.shape == (32, 96)
+    b3 = gp.GraphNetBlock(32, nb_of_layers=3, layer_norm=False)
+    assert set(b3.edge_block.state_dict()) == {"0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias"}
+    cfg = gp.cylinder_config(2, 32)
+    cfg["model"].update(use_silu_activation=True, use_gated_attention=True, use_rope_embeddings=True, rope_pos_dimension=2)
+    try:
+        net = gp.get_model(cfg)
+        assert net.processor_list[0].spec.act == "silu" and net.nodes_encoder.act == "silu"
+        assert net.processor_list[0].use_gate and net.processor_list[0].use_rope
+    finally:
+        gp.layers.set_use_silu_activation(False)
 
 
 def test_json_factory():

@@ -131,3 +131,48 @@ def test_faces_to_edges_oracle_on_reference_mesh():
     ea = O.edge_features_oracle(torch.from_numpy(d["pos"]), torch.from_numpy(ei))
     assert ea.shape == (11070, 3) and torch.allclose(ea[:, 2], ea[:, :2].norm(dim=1))
     assert torch.equal(ea, mesh.edge_features(torch.from_numpy(d["pos"]), torch.from_numpy(ei)))
+
+
+# ---------------------------------------------------------------- GraphNetBlock variants (N3)
+import pytest  # noqa: E402
+
+
+def variant_fixture():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "block_variants.npz"))
+    return {k: (str(z[k]) if z[k].dtype.kind == "U" else torch.from_numpy(z[k])) for k in z.files}
+
+
+@pytest.mark.parametrize("name", list(R.VARIANTS))
+def test_block_variants_oracle_vs_golden(name):
+    """the oracle's restatement of every GraphNetBlock variant (SiLU, gate, RoPE, gated MLP, 3 layers
+    without norm, combination) against the fixtures minted from the reference (make_golden_variants.py):
+    forward bit-exact, gradients 1e-5 (CPU index_put_ order)."""
+    import graph_physics_amd as gp
+
+    g = variant_fixture()
+    v = R.VARIANTS[name]
+    H, N, E, seed = 128, 40, 150, 300 + v["seed"]
+    ei = R.random_graph(N, E, seed)
+    keys = g[name + ".blk.keys"].split("|")
+    # parameter shapes from a freshly built product module: its layout must be the reference's
+    gp.layers.set_use_silu_activation(v["act"] == "silu")
+    try:
+        blk = gp.GraphNetBlock(H, **R.block_kwargs(v))
+    finally:
+        gp.layers.set_use_silu_activation(False)
+    assert list(blk.state_dict().keys()) == keys  # same names in the same order as the reference module
+    params = R.variant_params(blk.state_dict(), seed, keys)
+    p = {"processor_list.0." + k: t.clone().requires_grad_(True) for k, t in params.items()}
+    x, e = R.randn((N, H), seed + 1).requires_grad_(True), R.randn((E, H), seed + 2).requires_grad_(True)
+    pos = R.randn((N, 3), seed + 5, 0.3)
+    phi = R.randn((N,), seed + 6) if v.get("phi") else None
+    x2, e2 = O.graph_net_block(x, e, ei, p, "processor_list.0.", v["act"], variant=v["variant"], pos=pos, phi=phi)
+    assert torch.equal(x2.detach(), g[name + ".blk.x_out"]) and torch.equal(e2.detach()[:32], g[name + ".blk.e_out.rows32"])
+    ((x2 * R.randn((N, H), seed + 3)).sum() + (e2 * R.randn((E, H), seed + 4)).sum()).backward()
+    assert torch.allclose(x.grad, g[name + ".blk.dx"], rtol=1e-5, atol=1e-6)
+    for k in keys:
+        gr = p["processor_list.0." + k].grad
+        if f"{name}.blk.g.{k}" in g:
+            assert torch.allclose(gr, g[f"{name}.blk.g.{k}"], rtol=1e-5, atol=1e-6), k
+        elif f"{name}.blk.g.{k}.norm" in g:
+            assert abs(float(gr.norm()) - float(g[f"{name}.blk.g.{k}.norm"])) < 1e-5 * float(gr.norm()), k

@@ -40,15 +40,22 @@ def _worker(rank, world, port, q):
     x_in, e_in = R.randn((N, 11), 1), R.randn((ei.shape[1], 3), 2)
     tgt = R.randn((N, 2), 3)
     nt = torch.from_numpy((np.arange(N) % 3 == 0).astype(np.float32) * 5)
-    part = P.rcb_partition(pos.numpy(), world)
+    part = P.partition_nodes(pos.numpy(), ei, world)
     plan = P.build_rank_plan(ei, part, rank, world)
-    assert plan.n_ghost > 0
+    assert plan.n_ghost > 0 and 0 < plan.n_interior < plan.n_own and 0 < plan.n_interior_edges < plan.edge_ids.numel()
     net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H).to(dev)
     net.load_state_dict(params)
-    pm = D.PartitionedEPD(net, plan)  # default backend: the HIP engine
-    out = pm(x_in[plan.owned].to(dev), e_in[plan.edge_ids].to(dev))
-    loss = D.partitioned_loss(out, tgt[plan.owned].to(dev), nt[plan.owned].to(dev))
-    loss.backward()
+    pm = D.PartitionedEPD(net, plan)  # default backend: the HIP engine, halo exchange inside the processor node
+    runs = []
+    for _ in range(2):  # twice: the partitioned gradients are bit-reproducible (no atomics on the path)
+        net.zero_grad(set_to_none=True)
+        out = pm(x_in[plan.owned].to(dev), e_in[plan.edge_ids].to(dev))
+        loss = D.partitioned_loss(out, tgt[plan.owned].to(dev), nt[plan.owned].to(dev))
+        loss.backward()
+        runs.append({k: v.grad.clone() for k, v in net.named_parameters()})
+    assert pm._halo is not None and pm._halo.active
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
     D.GradAllReduce(average=False)(net.parameters())
     grads = {k: v.grad.cpu().numpy().copy() for k, v in net.named_parameters()}
     q.put((rank, plan.owned.numpy().copy(), out.detach().cpu().numpy().copy(), float(loss.detach()), grads))
