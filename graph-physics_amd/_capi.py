@@ -177,6 +177,8 @@ SYMBOLS = {
                                   C.c_int, C.c_void_p, C.c_void_p]),
     "mgn_rope_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgn_add_noise": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float),
+                                C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]),
     "mgn_prep_last_error": (C.c_char_p, []),
 }
 

@@ -770,3 +770,69 @@ extern "C" int mgn_rope_scatter(const float* T, const float* pos, int pos_w, con
                      pair_count, axes, src, dst, rowptr_src, perm_src, (long)N, H, resid, out);
   return pcheck("mgn_rope_scatter");
 }
+
+// ================================================================ noise injection (N2)
+// add_noise of the reference (dataset/preprocessing.py:177-238): Gaussian noise of standard deviation
+// scale[r] on the feature columns [start[r], end[r]) of the NORMAL nodes, in place.  The reference
+// draws torch.randn_like; here the stream is COUNTER-BASED so that any implementation can reproduce
+// it (the oracle does, in numpy): element (row n, column c, range r) of call `offset` takes
+//   (r0, r1, ..) = Philox4x32-10(key = seed, counter = (n_lo, n_hi, c | r << 16, offset))
+//   u1 = ((r0 >> 8) + 1) * 2^-24  in (0,1],   u2 = (r1 >> 8) * 2^-24  in [0,1)
+//   z  = sqrt(-2 ln u1) * cos(2 pi u2)                                   (Box-Muller)
+// One thread per (row, noised column).
+#define NOISE_MAX_RANGES 8
+struct NoiseRanges {
+  int n;
+  int start[NOISE_MAX_RANGES], end[NOISE_MAX_RANGES];
+  float scale[NOISE_MAX_RANGES];
+  int col0[NOISE_MAX_RANGES + 1];  // prefix sums of the range widths
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t& r0,
+                                              uint32_t& r1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1, c3 = (uint32_t)p0, c0 = n0, c2 = n2;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+  r0 = c0, r1 = c1;
+}
+
+__global__ void __launch_bounds__(256) k_add_noise(float* __restrict__ x, int x_w, long N, const NoiseRanges R, int type_idx, uint64_t seed,
+                                                  uint32_t offset) {
+  const int W = R.col0[R.n];
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = t / W;
+  const int j = (int)(t % W);
+  if (n >= N) return;
+  if ((int)(long)x[n * x_w + type_idx] != MGN_NODE_NORMAL) return;  // noise only on NORMAL nodes (:219-222,230-231)
+  int r = 0;
+  while (r + 1 < R.n && j >= R.col0[r + 1]) ++r;
+  const int c = R.start[r] + (j - R.col0[r]);
+  uint32_t r0, r1;
+  philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)c | ((uint32_t)r << 16), offset, r0, r1);
+  const float u1 = (float)((r0 >> 8) + 1u) * 5.9604644775390625e-8f;  // 2^-24
+  const float u2 = (float)(r1 >> 8) * 5.9604644775390625e-8f;
+  const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+  x[n * x_w + c] += z * R.scale[r];
+}
+
+extern "C" int mgn_add_noise(float* x, int x_w, int64_t N, int n_ranges, const int* starts, const int* ends, const float* scales, int type_idx,
+                             uint64_t seed, uint32_t offset, void* stream) {
+  if (x == nullptr || N < 0 || n_ranges < 1 || n_ranges > NOISE_MAX_RANGES || type_idx < 0 || type_idx >= x_w)
+    return pfail(1, "mgn_add_noise: bad arguments (1..8 ranges)");
+  NoiseRanges R;
+  R.n = n_ranges;
+  R.col0[0] = 0;
+  for (int r = 0; r < n_ranges; ++r) {
+    if (starts[r] < 0 || ends[r] < starts[r] || ends[r] > x_w || ends[r] > 65535) return pfail(1, "mgn_add_noise: column range outside x");
+    R.start[r] = starts[r], R.end[r] = ends[r], R.scale[r] = scales[r];
+    R.col0[r + 1] = R.col0[r] + (ends[r] - starts[r]);
+  }
+  const long tot = (long)N * R.col0[n_ranges];
+  if (tot == 0) return 0;
+  hipLaunchKernelGGL(k_add_noise, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_w, (long)N, R, type_idx, seed, offset);
+  return pcheck("mgn_add_noise");
+}

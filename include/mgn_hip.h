@@ -299,6 +299,17 @@ int mgn_add_world_edges(const float* x, int x_w, int pos_start, int D, int type_
 int mgn_edge_features(const float* pos, int D, const int64_t* src, const int64_t* dst, int64_t E,
                       float* edge_attr, void* stream);
 
+/* ------------------------------------------------------------ noise injection (N2)
+ * add_noise (graphphysics/dataset/preprocessing.py:177-238, wired by build_preprocessing :421-435):
+ * x[n, c] += scales[r] * z for every NORMAL node n and column c in [starts[r], ends[r]), r < n_ranges
+ * (<= 8), in place; z ~ N(0,1) from a counter-based stream any implementation can reproduce:
+ *   Philox4x32-10(key = seed, counter = (n_lo, n_hi, c | r << 16, offset)) -> r0, r1;
+ *   u1 = ((r0 >> 8) + 1) 2^-24, u2 = (r1 >> 8) 2^-24, z = sqrt(-2 ln u1) cos(2 pi u2).
+ * `offset` = the call / training-step counter.  The curriculum scale 10*std*(1+cos(t*pi)) (:226) is
+ * applied by the caller to scales[]. */
+int mgn_add_noise(float* x, int x_w, int64_t N, int n_ranges, const int* starts, const int* ends, const float* scales,
+                  int type_idx, uint64_t seed, uint32_t offset, void* stream);
+
 /* ------------------------------------------------- Simulator pre / post processing (N1)
  * Simulator._build_input_graph / build_outputs (graphphysics/models/simulator.py:112-191) with
  * the three Normalizers (models/layers.py:331-391) in one pass per tensor.  Streams:

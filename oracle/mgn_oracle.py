@@ -467,3 +467,58 @@ def add_world_edges_oracle(x, edge_index, world_pos_index_start: int, world_pos_
     dst = np.concatenate([b, a, ei[1], ei[0]])
     key = np.unique(src * np.int64(N) + dst)
     return np.stack([key // N, key % N], axis=0)
+
+
+def philox4x32_10(k0, k1, c0, c1, c2, c3):
+    """Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11), vectorised
+    in numpy uint64 arithmetic; returns the first two output words.  Integer work: bit-exact target for
+    the device stream of ``mgn_add_noise``."""
+    import numpy as np
+
+    M = np.uint64(0xFFFFFFFF)
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    c0, c1, c2, c3 = (np.asarray(v, dtype=np.uint64) & M for v in (c0, c1, c2, c3))
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M
+        c1, c3, c0, c2 = p1 & M, p0 & M, n0, n2
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    return c0.astype(np.uint32), c1.astype(np.uint32)
+
+
+def add_noise_oracle(x, noise_index_start, noise_index_end, noise_scale, node_type_index: int, t=None, seed: int = 0, offset: int = 0):
+    """add_noise, graphphysics/dataset/preprocessing.py:177-238 -- list handling (:200-217), NORMAL-only mask
+    (:219-222,230-231), curriculum scale (:226), in-place column update (:233-234) -- with the
+    counter-based noise stream the engine documents (include/mgn_hip.h, mgn_add_noise) in place of
+    torch.randn_like.  Returns (noised x, the standard-normal draws per range)."""
+    import numpy as np
+
+    if isinstance(noise_index_start, int):
+        noise_index_start = [noise_index_start]
+    if isinstance(noise_index_end, int):
+        noise_index_end = [noise_index_end]
+    if isinstance(noise_scale, (float, int)):
+        noise_scale = [float(noise_scale)] * len(noise_index_start)
+    if len(noise_index_start) != len(noise_index_end):
+        raise ValueError("noise_index_start and noise_index_end must have the same length.")
+    if len(noise_scale) != len(noise_index_start):
+        raise ValueError("noise_scale must have the same length as noise_index_start and noise_index_end.")
+    x = np.array(x, dtype=np.float32, copy=True)
+    N = x.shape[0]
+    normal = x[:, node_type_index].astype(np.int64) == NODE_NORMAL
+    rows = np.arange(N, dtype=np.uint64)
+    draws = []
+    for r, (s0, s1, sc) in enumerate(zip(noise_index_start, noise_index_end, noise_scale)):
+        sc = np.float32(10 * sc * (1 + math.cos(t * math.pi)) if t is not None else sc)
+        cols = np.arange(s0, s1, dtype=np.uint64)
+        n_, c_ = np.meshgrid(rows, cols, indexing="ij")
+        r0, r1 = philox4x32_10(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, n_ & np.uint64(0xFFFFFFFF), n_ >> np.uint64(32),
+                               c_ | np.uint64(r << 16), np.uint64(offset & 0xFFFFFFFF))
+        u1 = ((r0 >> 8).astype(np.float32) + np.float32(1)) * np.float32(2.0 ** -24)
+        u2 = (r1 >> 8).astype(np.float32) * np.float32(2.0 ** -24)
+        z = np.sqrt(np.float32(-2) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)
+        z = z.astype(np.float32)
+        draws.append(z)
+        x[:, s0:s1] = np.where(normal[:, None], x[:, s0:s1] + z * sc, x[:, s0:s1]).astype(np.float32)
+    return x, draws

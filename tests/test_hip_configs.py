@@ -282,7 +282,7 @@ def _grad_case(dev, g, L, seed, dtype64=True):
     flips, total, worst = 0, 0, 0.0
     inv = topo.inv_perm.cpu()
     for i in range(L):
-        x_, e_, agg_, He, Ue, Re, Hn, Un, Rn, Me, Mn = saved[i]
+        He, Hn = saved[i]["He"], saved[i]["Hn"]
         for l in range(3):
             for Hs, pre, perm in ((He, inter[i]["edge_pre"], inv), (Hn, inter[i]["node_pre"], None)):
                 hip = Hs[l].cpu() > 0
@@ -332,24 +332,32 @@ def test_gradients_at_batch16_size(dev):
 
 def test_training_steps_at_benchmark_mesh_size(dev):
     """3 optimiser steps at N=1885 / L=15 through Simulator + Engine against O.train_steps: loss and
-    gradient norm per step, every parameter after the last step."""
-    L, seed = 15, 79
+    gradient norm per step, and the weights after the last step.  AdamW moves EVERY weight by ~lr whatever
+    the size of its gradient, so an element whose gradient is rounding noise takes a step of random sign
+    on either side: weights are compared through the fraction of elements whose update differs, and the
+    later steps' losses carry the tolerance that leaves."""
+    L, seed, lr = 15, 79, 1e-4
     g = gp.cylinder_mesh(1885, 3)
     params = R.make_params(R.epd_param_shapes(L, 128, 11, 3, 2), seed)
-    eng = harness.Engine(gp.cylinder_config(L, 128), dev, learning_rate=1e-3, num_steps=100, warmup=4)
+    eng = harness.Engine(gp.cylinder_config(L, 128), dev, learning_rate=lr, num_steps=100, warmup=4)
     eng.model.load_state_dict(params)
     gd = g.to(dev)
     logs = [(float(eng.train_step(gd)), float(eng.last_grad_norm)) for _ in range(3)]
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     ref = O.train_steps(p, O.SimulatorOracle(gp.cylinder_config()["index"], 11, 3, 2), [(g.x, g.y, g.edge_attr, g.edge_index)] * 3,
-                        L, 1e-3, 4, 100)
-    for t in range(3):
-        assert abs(logs[t][0] - ref[t][0]) < 5e-5 * ref[t][0], (t, logs, ref)
-        assert abs(logs[t][1] - ref[t][1]) < 3e-4 * ref[t][1], (t, logs, ref)
+                        L, lr, 4, 100)
+    for t, (ltol, gtol) in enumerate(((2e-5, 3e-4), (3e-4, 1e-3), (3e-4, 1e-3))):
+        assert abs(logs[t][0] - ref[t][0]) < ltol * ref[t][0], (t, logs, ref)
+        assert abs(logs[t][1] - ref[t][1]) < gtol * ref[t][1], (t, logs, ref)
     sd = eng.model.state_dict()
-    for k in p:  # AdamW moves every weight by ~lr per step: compare the MOVEMENT, not the weight
-        moved = (p[k].detach() - params[k]).abs().max()
-        assert float((sd[k].cpu() - p[k].detach()).abs().max()) < 0.02 * float(moved) + 1e-7, k
+    step = lr * 0.25  # the first (smallest) step of the warm-up
+    off = tot = 0
+    for k in p:
+        d = (sd[k].cpu() - p[k].detach()).abs()
+        off += int((d > 0.2 * step).sum())
+        tot += d.numel()
+        assert float(d.max()) < 8 * lr, k          # never farther apart than the sum of the three steps, both ways
+    assert off < 5e-3 * tot, (off, tot)
 
 
 # ------------------------------------------------ the exact-fp32 MFMA generation

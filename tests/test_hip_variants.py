@@ -78,13 +78,35 @@ def test_epd_variant_through_json_vs_reference_golden(dev, fx, name):
         g.phi = R.randn((N2,), seed2 + 6).to(dev)
     out = net(g)
     assert_close3(out, fx[name + ".epd.out"], FWD_TOL, name + " EPD")
-    (out * R.randn((N2, 2), seed2 + 3).to(dev)).sum().backward()
+    cot = R.randn((N2, 2), seed2 + 3)
+    (out * cot.to(dev)).sum().backward()
+    # gradients: the reference-minted values (fp32) where the fixture holds them; a gradient that misses
+    # GRAD_TOL must be as close to the oracle's fp64 evaluation as the reference's own fp32 arithmetic is
+    # (a pre-activation at rounding distance from 0 flips its ReLU mask on either side)
+    from oracle import mgn_oracle as O
+
+    sd0 = R.variant_params(net.state_dict(), seed2, keys)
+    g64 = {}
+
+    def oracle64():
+        if not g64:
+            p64 = {k: t.double().requires_grad_(True) for k, t in sd0.items()}
+            o = O.epd_forward(x_in.double(), e_in.double(), ei2, p64, L, act=v["act"], variant=vv, pos=pos2.double(),
+                              phi=g.phi.cpu().double() if v.get("phi") else None)
+            (o * cot.double()).sum().backward()
+            g64.update({k: t.grad for k, t in p64.items()})
+        return g64
+
     for k, p in net.state_dict(keep_vars=True).items():
+        if f"{name}.epd.g.{k}" in fx:
+            ref = fx[f"{name}.epd.g.{k}"]
+            e32 = rel_err(p.grad, ref)
+            assert e32 < GRAD_TOL or rel_err(p.grad, oracle64()[k]) < 1.25 * rel_err(ref, oracle64()[k]) + 1e-6, (k, e32)
         if f"{name}.epd.gnorm.{k}" in fx:
             gn = float(fx[f"{name}.epd.gnorm.{k}"])
-            assert abs(float(p.grad.norm()) - gn) < 2 * GRAD_TOL * gn + 1e-7, k
-        if f"{name}.epd.g.{k}" in fx:
-            assert rel_err(p.grad, fx[f"{name}.epd.g.{k}"]) < 2 * GRAD_TOL, k
+            dn = abs(float(p.grad.norm()) - gn) / gn
+            g6 = float(oracle64()[k].norm()) if dn >= GRAD_TOL else gn
+            assert dn < GRAD_TOL or abs(float(p.grad.norm()) - g6) < 1.25 * abs(gn - g6) + 1e-6 * g6, (k, dn)
 
 
 def test_silu_narrow_and_generic_widths_vs_oracle(dev):
@@ -109,3 +131,71 @@ def test_silu_narrow_and_generic_widths_vs_oracle(dev):
     assert_close3(out, ref, FWD_TOL, "silu H=32")
     for k, q in net.named_parameters():
         assert rel_err(q.grad, p[k].grad) < GRAD_TOL, k
+
+
+# ------------------------------------------------------------------ N2: noise injection
+def test_add_noise_vs_oracle_stream(dev):
+    """mgn_add_noise against the numpy oracle over the same counter-based stream: the integer stream is
+    identical, so the added noise agrees to float rounding of log / cos / sqrt (<= 4 ulp of the draw);
+    non-NORMAL rows and untouched columns stay bit-identical; curriculum / list forms; offsets differ."""
+    import numpy as np
+    from graph_physics_amd import preprocess as PP
+    from oracle import mgn_oracle as O
+
+    rng = np.random.default_rng(3)
+    n = 50_000
+    x = rng.standard_normal((n, 6)).astype(np.float32)
+    x[:, 4] = rng.choice([0, 0, 1, 4, 6], size=n)
+    for kw in (dict(noise_index_start=0, noise_index_end=3, noise_scale=0.003), dict(noise_index_start=[0, 2], noise_index_end=[1, 4], noise_scale=[10.0, 0.5]),
+               dict(noise_index_start=0, noise_index_end=2, noise_scale=0.1, t=0.25)):
+        g = gp.Graph(x=torch.from_numpy(x).to(dev))
+        PP.add_noise(g, node_type_index=4, seed=11, offset=5, **kw)
+        want, _ = O.add_noise_oracle(x, node_type_index=4, seed=11, offset=5, **kw)
+        got = g.x.cpu().numpy()
+        normal = x[:, 4] == 0
+        assert np.array_equal(got[~normal], x[~normal]) and np.array_equal(got[:, 4:], x[:, 4:])
+        d_got, d_want = got - x, want - x
+        scale = np.abs(d_want).max()
+        assert np.abs(d_got - d_want).max() < 2e-6 * scale + 1e-7 * np.abs(x).max(), kw
+        assert np.abs(d_want[normal]).max() > 0
+    g2 = gp.Graph(x=torch.from_numpy(x).to(dev))
+    PP.add_noise(g2, 0, 3, 0.003, 4, seed=11, offset=6)
+    assert not torch.equal(g2.x, g.x)
+    with pytest.raises(ValueError):
+        PP.add_noise(gp.Graph(x=torch.from_numpy(x).to(dev)), [0, 1], [1], 0.1, 4)
+
+
+def test_build_preprocessing_widths_like_the_reference_tests(dev):
+    """the device-side build_preprocessing: the widths the reference's own tests assert
+    (tests/graphphysics/dataset/test_preprocessing.py:52-56,76-90,156-195,182-195): 3-D mesh -> edge_attr
+    width 4; with world positions x gains 3 columns and edge_attr 4 more; noise at position 1 changes
+    only NORMAL rows."""
+    import numpy as np
+    from graph_physics_amd import preprocess as PP
+    from scipy.spatial import Delaunay
+
+    rng = np.random.default_rng(5)
+    n = 400
+    pts = rng.random((n, 3)).astype(np.float32)
+    types = rng.choice([0, 0, 1, 6], size=n).astype(np.float32)
+    x = np.concatenate([pts, types[:, None]], axis=1)                 # [world_pos(3), node_type]
+    y = (pts + 0.01).astype(np.float32)
+    tri = Delaunay(pts[:, :2]).simplices.T.astype(np.int64)            # triangles [3, F]
+
+    def graph():
+        return gp.Graph(x=torch.from_numpy(x).to(dev), y=torch.from_numpy(y).to(dev), pos=torch.from_numpy(pts).to(dev),
+                        face=torch.from_numpy(tri).to(dev))
+
+    g = PP.build_preprocessing(add_edges_features=True)(graph())
+    assert g.edge_attr.shape[1] == 4 and g.edge_index.shape[0] == 2 and g.x.shape[1] == 4
+    noise = {"noise_index_start": 0, "noise_index_end": 3, "noise_scale": 0.1, "node_type_index": 3}
+    # with world positions the node-type index is the one AFTER add_obstacles_next_pos inserted its 3 columns
+    # (preprocessing.py:78-80): both transforms read x[:, 6] from then on
+    world = {"world_pos_index_start": 0, "world_pos_index_end": 3, "node_type_index": 6, "radius": 0.1}
+    g2 = PP.build_preprocessing(dict(noise, node_type_index=6), world, seed=3)(graph(), step=2)
+    assert g2.x.shape[1] == 4 + 3 and g2.edge_attr.shape[1] == 8 and g2.edge_index.shape[1] >= g.edge_index.shape[1]
+    # noise (inserted after add_obstacles_next_pos) touched the first 3 columns of the NORMAL rows only
+    moved = (g2.x[:, :3].cpu() - torch.from_numpy(pts)).abs().amax(dim=1) > 0
+    assert bool(moved[torch.from_numpy(types == 0)].all()) and not bool(moved[torch.from_numpy(types != 0)].any())
+    g3 = PP.build_preprocessing(noise_parameters=noise)(graph())
+    assert g3.edge_attr.shape[1] == 4 and g3.x.shape[1] == 4
