@@ -153,6 +153,7 @@ SYMBOLS = {
     "mgn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(WgradJob)]),
     "mgn_wgrad": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_wgrad_p": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "mgn_debug_occupancy": (C.c_int, [C.POINTER(C.c_int)]),
     "mgn_transpose_blocks": (C.c_int, [C.c_int, C.POINTER(TBlock), C.c_int, C.c_void_p]),
     "mgn_wpack": (C.c_int, [C.c_int, C.POINTER(WpackBlock), C.c_void_p]),
     "mgn_faces_to_edges_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),

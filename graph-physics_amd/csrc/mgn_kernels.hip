@@ -1947,7 +1947,7 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
   if (p.lds && bwd_x6(a)) {
     static thread_local bool attr_done = false;
     if (!attr_done) {
-      const int lds = X6_BWD_LDS_BYTES(LDS_MAX_NL);
+      const int lds = X6_BWD_LDS_BYTES(LDS_MAX_NL + 1);
       if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
           hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
           hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
@@ -1957,7 +1957,9 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
         return 1;
       attr_done = true;
     }
-    const size_t lds = X6_BWD_LDS_BYTES(a.NL);
+    int nused = (a.scale != nullptr && a.dscale != nullptr) ? 1 : 0;
+    for (int l = 0; l < a.NL; ++l) nused += (a.db[l] != nullptr) ? 1 : 0;
+    const size_t lds = X6_BWD_LDS_BYTES(nused);
     const bool front = a.n_front > 0;
     if (a.act == MGN_ACT_SILU) {
       if (a.precision == 1)
@@ -2314,6 +2316,32 @@ int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes,
     hipLaunchKernelGGL(k_wgrad_red, dim3((L.H * L.H + L.H + 63) / 64, L.njobs), dim3(256), 0, s, L);
     if (int rc = check_launch("mgn_wgrad/reduce")) return rc;
   }
+  return 0;
+}
+
+// Resident workgroups per CU of the persistent kernels at their launch configuration (HIP occupancy
+// query): what the 512-workgroup plans assume.  out[0..5] = fwd_x6<6,4>, fwd_x6<1,4>, bwd_x6<6> with one
+// column-sum slot, bwd_x6<6> with five (the round-1 footprint), wgrad_x6<6>, fwd_x6<6,8>.
+int mgn_debug_occupancy(int* out) {
+  int n = 0;
+  if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<6, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(4)) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<1, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(4)) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_mlp_fwd_x6<6, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(8)) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_BWD_LDS_BYTES(LDS_MAX_NL + 1)) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_BWD_LDS_BYTES(LDS_MAX_NL + 1)) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_wgrad_x6<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_TILE_BYTES) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_fwd_x6<6, 4, 0>, 256, X6_FWD_LDS_BYTES(4)) != hipSuccess) return 2;
+  out[0] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_fwd_x6<1, 4, 0>, 256, X6_FWD_LDS_BYTES(4)) != hipSuccess) return 2;
+  out[1] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_bwd_x6<6, false, 0>, 256, X6_BWD_LDS_BYTES(1)) != hipSuccess) return 2;
+  out[2] = n;  // one column-sum slot (dscale only: what the processor launches)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_bwd_x6<6, false, 0>, 256, X6_BWD_LDS_BYTES(5)) != hipSuccess) return 2;
+  out[3] = n;  // all five slots (the round-1 footprint)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wgrad_x6<6>, 256, 4 * WG_TILE_BYTES) != hipSuccess) return 2;
+  out[4] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_fwd_x6<6, 8, 0>, 512, X6_FWD_LDS_BYTES(8)) != hipSuccess) return 2;
+  out[5] = n;
   return 0;
 }
 

@@ -242,6 +242,11 @@ int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, v
 /* same with an explicit matrix precision for the full 128x128 jobs (0 / 1 as in mgn_mlp_fwd_args) */
 int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, int precision, void* stream);
 
+/* Diagnostic: resident workgroups per CU (HIP occupancy query) of the persistent kernels at their launch
+ * configuration -- out[0..5] = forward chain (fp32-grade, 4 waves), forward chain (bf16), backward chain
+ * with one column-sum slot, backward chain with five, weight gradients, forward chain (8 waves). */
+int mgn_debug_occupancy(int* out);
+
 /* ------------------------------------------------------- batched block transpose
  * dst[k, j] = src[j, k] for n square H x H blocks (leading dimensions ld_src / ld_dst; a block
  * may be a column slab of a wider matrix).  Prepares the W^T operands of mgn_mlp_bwd for all
