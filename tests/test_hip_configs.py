@@ -298,27 +298,45 @@ def _grad_case(dev, g, L, seed, dtype64=True):
     return out.detach().cpu(), grads, (o32, g32), (o64, g64), (flips, total, worst)
 
 
-def _check_grads(grads, g32, g64, L):
-    bad = []
-    for k in grads:
-        e32 = rel_err(grads[k], g32[k])
-        ok = e32 < GRAD_TOL
-        if not ok and g64 is not None:  # as close to fp64 as the reference's own fp32 arithmetic is
-            ok = rel_err(grads[k], g64[k]) < 1.25 * rel_err(g32[k], g64[k]) + 1e-6
-        if not ok:
-            bad.append((k, e32))
-    assert not bad, bad[:5]
+def _check_grads(grads, g32, g64, flips, worst):
+    """Gradient bar at depth.  Measured on the MI355X (tools/diag_grads.py): with NO differing ReLU mask the
+    engine tracks the fp32 oracle to 3e-6 at L=15 while BOTH sit 3e-3 from the fp64 oracle (rounding
+    amplified by 30 MLPs: the reference's own fp32 arithmetic is that far from exact); 13 of 75.7 M masks
+    differ at N=1885 (every one at |z| < 4e-7 of the layer's scale) and move the engine and the CPU to
+    the same distance from fp64.  Hence: no differing mask -> GRAD_TOL against the fp32 oracle; otherwise
+    every differing mask must sit at rounding distance from zero, and the engine must be as close to the
+    fp64 oracle as the fp32 oracle itself is (x2: both distances are dominated by a handful of flips)."""
+    e32 = {k: rel_err(grads[k], g32[k]) for k in grads}
+    if flips == 0:
+        bad = [(k, v) for k, v in e32.items() if v >= GRAD_TOL]
+        assert not bad, bad[:5]
+        return
+    assert worst < 1e-5, worst
+    h64 = max(rel_err(grads[k], g64[k]) for k in grads)
+    c64 = max(rel_err(g32[k], g64[k]) for k in grads)
+    assert h64 < 2.0 * c64 + 1e-6, (h64, c64, flips)
+    assert max(e32.values()) < 4.0 * c64 + GRAD_TOL, (max(e32.values()), c64)
 
 
 def test_gradients_at_benchmark_mesh_size(dev):
-    """N=1885, L=15 (configs[0]/[1] mesh): every parameter gradient within GRAD_TOL of the fp32 oracle
-    or as close to the fp64 oracle as the fp32 oracle itself; forward at 1e-5; flipped masks counted."""
+    """N=1885, L=15 (configs[0]/[1] mesh): forward at 1e-5 in all three readings; gradients by the
+    flip-aware bar of _check_grads; the differing masks are counted (<= 1e-6 of all activations)."""
     g = gp.cylinder_mesh(1885, 0)
     out, grads, (o32, g32), (o64, g64), (flips, total, worst) = _grad_case(dev, g, 15, 77)
     assert_close3(out, o32, FWD_TOL, "forward N=1885 L=15")
-    _check_grads(grads, g32, g64, 15)
-    # masks: a handful of 21M activations, each with |pre-activation| < 1e-5 of the layer's scale
-    assert flips <= 1e-5 * total and worst < 1e-5, (flips, total, worst)
+    assert flips <= 1e-6 * total, (flips, total)
+    _check_grads(grads, g32, g64, flips, worst)
+
+
+def test_gradients_small_mesh_deep_net_no_flips_tight(dev):
+    """N=400, L=15: a case without a single differing mask -- every gradient within GRAD_TOL (measured 3e-6)
+    of the fp32 oracle although both are 3e-3 from fp64."""
+    g = gp.cylinder_mesh(400, 1)
+    out, grads, (o32, g32), (o64, g64), (flips, total, worst) = _grad_case(dev, g, 15, 79)
+    assert_close3(out, o32, FWD_TOL, "forward N=400 L=15")
+    _check_grads(grads, g32, g64, flips, worst)
+    if flips == 0:
+        assert max(rel_err(grads[k], g32[k]) for k in grads) < 2e-5
 
 
 def test_gradients_at_batch16_size(dev):
@@ -326,8 +344,31 @@ def test_gradients_at_batch16_size(dev):
     g = gp.cylinder_batch(16, 1885, 0)
     out, grads, (o32, g32), (o64, g64), (flips, total, worst) = _grad_case(dev, g, 15, 78)
     assert_close3(out, o32, FWD_TOL, "forward batch-16 L=15")
-    _check_grads(grads, g32, g64, 15)
-    assert flips <= 1e-5 * total and worst < 1e-5, (flips, total, worst)
+    assert flips <= 1e-6 * total, (flips, total)
+    _check_grads(grads, g32, g64, flips, worst)
+
+
+def test_gradients_silu_at_benchmark_mesh_size_tight(dev):
+    """The same depth and size with SiLU (smooth: no masks to flip): every gradient within 5e-5 of the fp32
+    oracle (measured 1e-5) -- the backward arithmetic itself holds the bar at depth."""
+    gp.layers.set_use_silu_activation(True)
+    try:
+        net = gp.EncodeProcessDecode(15, 11, 3, 2, hidden_size=128).to(dev)
+    finally:
+        gp.layers.set_use_silu_activation(False)
+    g = gp.cylinder_mesh(1885, 0)
+    N, E = g.x.shape[0], g.edge_index.shape[1]
+    params = R.make_params(R.epd_param_shapes(15, 128, 11, 3, 2), 77)
+    net.load_state_dict(params)
+    x_in, e_in, cot = R.randn((N, 11), 78), R.randn((E, 3), 79), R.randn((N, 2), 80)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.epd_forward(x_in, e_in, g.edge_index, p, 15, act="silu")
+    (ref * cot).sum().backward()
+    out = net(gp.Graph(x=x_in.to(dev), edge_attr=e_in.to(dev), edge_index=g.edge_index.to(dev)))
+    (out * cot.to(dev)).sum().backward()
+    assert_close3(out, ref, FWD_TOL, "SiLU forward N=1885 L=15")
+    for k, q in net.named_parameters():
+        assert rel_err(q.grad, p[k].grad) < 5e-5, k
 
 
 def test_training_steps_at_benchmark_mesh_size(dev):
