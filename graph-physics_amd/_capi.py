@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _REPO = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("MGN_LIB") or os.path.join(_CSRC, "libmgn_hip.so")
-SOURCES = [os.path.join(_CSRC, "mgn_kernels.hip"), os.path.join(_CSRC, "mgn_prep.hip")]
+SOURCES = [os.path.join(_CSRC, "mgn_kernels.hip"), os.path.join(_CSRC, "mgn_prep.hip"), os.path.join(_CSRC, "mgn_attn.hip")]
 DEPS = [os.path.join(_CSRC, "mgn_x6.inc")]  # included by the source
 HEADER = os.path.join(_REPO, "include", "mgn_hip.h")
 
@@ -181,6 +181,9 @@ SYMBOLS = {
     "mgn_add_noise": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float),
                                 C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]),
     "mgn_prep_last_error": (C.c_char_p, []),
+    "mgn_sparse_attn_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgn_sparse_attn_bwd": (C.c_int, [C.c_void_p] * 11 + [C.c_int64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]),
+    "mgn_attn_last_error": (C.c_char_p, []),
 }
 
 _lib = None
@@ -292,7 +295,8 @@ def lib():
     return _lib
 
 
-def check(rc: int, what: str, prep: bool = False):
+def check(rc: int, what: str, prep: bool = False, attn: bool = False):
     if rc != 0:
-        msg = (lib().mgn_prep_last_error() if prep else lib().mgn_last_error()).decode("utf-8", "replace")
+        fn = lib().mgn_attn_last_error if attn else (lib().mgn_prep_last_error if prep else lib().mgn_last_error)
+        msg = fn().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,214 @@
+// MI355X (gfx950) kernels of the sparse-attention Transformer processor: edge-masked
+// scaled dot-product attention over the mesh adjacency,
+//     score[e,h] = sum_d q[i_e, d, h] k[j_e, d, h] / sqrt(D),   attn = softmax over the edges of row i,
+//     y[i, d, h] = sum_{e in row i} attn[e,h] v[j_e, d, h]
+// (reference: scaled_query_key_softmax / scaled_dot_product_attention, graphphysics/models/layers.py:
+// 493-559, through DGL's bsddmm -> SparseMatrix.softmax -> bspmm with the adjacency
+// dglsp.spmatrix(indices=edge_index), processors.py:352 -- rows are edge_index[0], columns edge_index[1]).
+// Head layout as the reference reshapes it: q.reshape(N, head_dim, num_heads) (layers.py:673-675), i.e.
+// the HEAD index is the fastest axis: feature f = d * num_heads + h.
+//
+// HBM-bound gather work (two 4*hidden-byte rows per edge), no matrix cores: one group of hidden/4 lanes
+// per row, 16-byte lanes, online softmax (one pass over the row's edges), CSR order => deterministic,
+// atomics-free.  The backward is two passes: by ROW (dq, per-edge attn / dscore) and by COLUMN (dk, dv)
+// through the column-grouped CSR of the same edges.
+// Third translation unit of libmgn_hip.so.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "mgn_hip.h"
+
+static thread_local char g_aerr[256] = "";
+extern "C" const char* mgn_attn_last_error(void) { return g_aerr; }
+static int afail(int code, const char* msg) {
+  snprintf(g_aerr, sizeof(g_aerr), "%s", msg);
+  return code;
+}
+static int acheck(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_aerr, sizeof(g_aerr), "%s: %s", what, hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
+// Lane l of a row group holds features 4l .. 4l+3; feature f belongs to head f % NH.  head_reduce turns the
+// per-feature partial products p[r] into the full per-HEAD sums, delivered to every lane for the heads of
+// its own four features: butterfly over the lanes that share the same heads (stride >= NH/4), then a fold
+// inside the lane when NH < 4.  LPR = lanes per row (hidden / 4), a power of two <= 32.
+template <int LPR>
+__device__ __forceinline__ void head_reduce(float (&p)[4], int NH) {
+  const int gs = (NH >= 4) ? (NH >> 2) : 1;
+#pragma unroll
+  for (int m = LPR >> 1; m >= 1; m >>= 1) {
+    if (m >= gs) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r] += __shfl_xor(p[r], m, LPR);
+    }
+  }
+  if (NH == 2) {
+    const float a = p[0] + p[2], b = p[1] + p[3];
+    p[0] = p[2] = a, p[1] = p[3] = b;
+  } else if (NH == 1) {
+    const float a = (p[0] + p[1]) + (p[2] + p[3]);
+    p[0] = p[1] = p[2] = p[3] = a;
+  }
+}
+
+// y[i] and lse[i] (per feature: log-sum-exp of its head's scores) for every row i
+template <int LPR>
+__global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
+                                                 float scale, float* __restrict__ y, float* __restrict__ lse) {
+  constexpr int H = 4 * LPR;
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const int l = threadIdx.x % LPR;
+  if (i >= N) return;
+  const float4 qv = *(const float4*)(q + (size_t)i * H + 4 * l);
+  const float qq[4] = {qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale};
+  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    const size_t j = (size_t)col[e];
+    const float4 kv = *(const float4*)(k + j * H + 4 * l);
+    const float4 vv = *(const float4*)(v + j * H + 4 * l);
+    float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
+    head_reduce<LPR>(p, NH);
+    const float vr[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float nm = fmaxf(m[r], p[r]);
+      const float corr = expf(m[r] - nm), w = expf(p[r] - nm);   // first edge: exp(-inf) = 0
+      s[r] = s[r] * corr + w;
+      acc[r] = acc[r] * corr + w * vr[r];
+      m[r] = nm;
+    }
+  }
+  float4 o, ls;
+  float* op = &o.x;
+  float* lp = &ls.x;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    op[r] = (s[r] > 0.f) ? acc[r] / s[r] : 0.f;        // a row without edges attends to nothing: zeros
+    lp[r] = (s[r] > 0.f) ? m[r] + logf(s[r]) : 0.f;
+  }
+  *(float4*)(y + (size_t)i * H + 4 * l) = o;
+  if (lse != nullptr) *(float4*)(lse + (size_t)i * H + 4 * l) = ls;
+}
+
+// backward, pass A (by row): dq[i]; per edge and head the attention weight a and the score gradient ds
+//   D[h] = sum_d dy[i,d,h] y[i,d,h];  a = exp(score - lse);  dA = sum_d dy[i,d,h] v[j,d,h];  ds = a (dA - D)
+//   dq[i,f] = scale * sum_e ds[e,h(f)] k[j_e,f]
+template <int LPR>
+__global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                     const float* __restrict__ y, const float* __restrict__ lse, const float* __restrict__ dy,
+                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
+                                                     float scale, float* __restrict__ dq, float* __restrict__ a_out, float* __restrict__ ds_out) {
+  constexpr int H = 4 * LPR;
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const int l = threadIdx.x % LPR;
+  if (i >= N) return;
+  const size_t ro = (size_t)i * H + 4 * l;
+  const float4 qv = *(const float4*)(q + ro), yv = *(const float4*)(y + ro), gv = *(const float4*)(dy + ro), lv = *(const float4*)(lse + ro);
+  const float qq[4] = {qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale};
+  const float g[4] = {gv.x, gv.y, gv.z, gv.w}, ls[4] = {lv.x, lv.y, lv.z, lv.w};
+  float D[4] = {gv.x * yv.x, gv.y * yv.y, gv.z * yv.z, gv.w * yv.w};
+  head_reduce<LPR>(D, NH);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int gs = (NH >= 4) ? (NH >> 2) : 1;     // lanes 0 .. gs-1 hold one copy of every head between them
+  const int nr = (NH >= 4) ? 4 : NH;
+  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    const size_t j = (size_t)col[e];
+    const float4 kv = *(const float4*)(k + j * H + 4 * l);
+    const float4 vv = *(const float4*)(v + j * H + 4 * l);
+    const float kr[4] = {kv.x, kv.y, kv.z, kv.w};
+    float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
+    float dA[4] = {g[0] * vv.x, g[1] * vv.y, g[2] * vv.z, g[3] * vv.w};
+    head_reduce<LPR>(p, NH);
+    head_reduce<LPR>(dA, NH);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a = expf(p[r] - ls[r]);
+      const float ds = a * (dA[r] - D[r]);
+      acc[r] += ds * kr[r];
+      if (l < gs && r < nr) {  // head h = 4l + r (NH >= 4) or r (NH < 4)
+        a_out[(size_t)e * NH + 4 * l + r] = a;
+        ds_out[(size_t)e * NH + 4 * l + r] = ds;
+      }
+    }
+  }
+  *(float4*)(dq + ro) = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
+}
+
+// backward, pass B (by column j through the column-grouped CSR: cptr / cperm index the row-sorted edges):
+//   dk[j,f] = scale * sum_e ds[e,h(f)] q[i_e,f];   dv[j,f] = sum_e a[e,h(f)] dy[i_e,f]
+template <int LPR>
+__global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ q, const float* __restrict__ dy, const float* __restrict__ a_in,
+                                                     const float* __restrict__ ds_in, const int32_t* __restrict__ cptr,
+                                                     const int32_t* __restrict__ cperm, const int32_t* __restrict__ row_of_edge, long N, int NH,
+                                                     float scale, float* __restrict__ dk, float* __restrict__ dv) {
+  constexpr int H = 4 * LPR;
+  const long j = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const int l = threadIdx.x % LPR;
+  if (j >= N) return;
+  float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int t = cptr[j]; t < cptr[j + 1]; ++t) {
+    const size_t e = (size_t)cperm[t];
+    const size_t i = (size_t)row_of_edge[e];
+    const float4 qv = *(const float4*)(q + i * H + 4 * l);
+    const float4 gv = *(const float4*)(dy + i * H + 4 * l);
+    const float qr[4] = {qv.x, qv.y, qv.z, qv.w}, gr[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = (4 * l + r) % NH;
+      ak[r] += ds_in[e * NH + h] * qr[r];
+      av[r] += a_in[e * NH + h] * gr[r];
+    }
+  }
+  *(float4*)(dk + (size_t)j * H + 4 * l) = make_float4(ak[0] * scale, ak[1] * scale, ak[2] * scale, ak[3] * scale);
+  *(float4*)(dv + (size_t)j * H + 4 * l) = make_float4(av[0], av[1], av[2], av[3]);
+}
+
+static int attn_args_ok(int64_t N, int H, int NH) {
+  if (N < 0) return 0;
+  if (!(H == 16 || H == 32 || H == 64 || H == 128)) return 0;
+  if (!(NH == 1 || NH == 2 || NH == 4 || NH == 8 || NH == 16) || H % NH != 0 || NH > H / 4 * 4) return 0;
+  return 1;
+}
+
+#define ATTN_DISPATCH(KERNEL, ...)                                                                               \
+  do {                                                                                                           \
+    const unsigned grid = (unsigned)(((long)N * (H / 4) + 255) / 256);                                           \
+    switch (H) {                                                                                                 \
+      case 128: hipLaunchKernelGGL((KERNEL<32>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;               \
+      case 64: hipLaunchKernelGGL((KERNEL<16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                \
+      case 32: hipLaunchKernelGGL((KERNEL<8>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                 \
+      default: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                 \
+    }                                                                                                            \
+  } while (0)
+
+extern "C" int mgn_sparse_attn_fwd(const float* q, const float* k, const float* v, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
+                                   int num_heads, float* y, float* lse, void* stream) {
+  if (!attn_args_ok(N, H, num_heads)) return afail(1, "mgn_sparse_attn_fwd: hidden must be 16/32/64/128 and num_heads 1/2/4/8/16 dividing it");
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const float scale = 1.0f / sqrtf((float)(H / num_heads));
+  ATTN_DISPATCH(k_attn_fwd, q, k, v, rowptr, col, (long)N, num_heads, scale, y, lse);
+  return acheck("mgn_sparse_attn_fwd");
+}
+
+extern "C" int mgn_sparse_attn_bwd(const float* q, const float* k, const float* v, const float* y, const float* lse, const float* dy,
+                                   const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
+                                   const int32_t* row_of_edge, int64_t N, int64_t E, int H, int num_heads, float* dq, float* dk, float* dv,
+                                   float* ws, size_t ws_bytes, void* stream) {
+  if (!attn_args_ok(N, H, num_heads) || E < 0) return afail(1, "mgn_sparse_attn_bwd: bad arguments");
+  if (ws_bytes < (size_t)2 * E * num_heads * sizeof(float)) return afail(1, "mgn_sparse_attn_bwd: workspace too small (2 * E * num_heads floats)");
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const float scale = 1.0f / sqrtf((float)(H / num_heads));
+  float* a_e = ws;
+  float* ds_e = ws + (size_t)E * num_heads;
+  ATTN_DISPATCH(k_attn_bwd_row, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, dq, a_e, ds_e);
+  ATTN_DISPATCH(k_attn_bwd_col, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, row_of_edge, (long)N, num_heads, scale, dk, dv);
+  return acheck("mgn_sparse_attn_bwd");
+}

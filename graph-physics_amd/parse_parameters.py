@@ -33,8 +33,23 @@ def get_model(param: Dict[str, Any], only_processor: bool = False):
             rope_base=model.get("rope_base", 10000.0),
             use_temporal_block=training.get("use_temporal_block", False),
         )
-    if model_type in ("transformer", "transolver"):
-        raise NotImplementedError(f"model type '{model_type}' is outside the MeshGraphNet hot path (SURVEY.md N4)")
+    if model_type == "transformer":  # parse_parameters.py:129-142
+        from .transformer import EncodeTransformDecode
+        return EncodeTransformDecode(
+            message_passing_num=param["model"]["message_passing_num"],
+            node_input_size=node_input_size,
+            output_size=param["model"]["output_size"],
+            hidden_size=param["model"]["hidden_size"],
+            num_heads=param["model"]["num_heads"],
+            only_processor=only_processor,
+            use_rope_embeddings=model.get("use_rope_embeddings", False),
+            use_gated_attention=model.get("use_gated_attention", False),
+            rope_pos_dimension=model.get("rope_pos_dimension", 3),
+            rope_base=model.get("rope_base", 10000.0),
+            use_temporal_block=training.get("use_temporal_block", False),
+        )
+    if model_type == "transolver":
+        raise NotImplementedError("model type 'transolver' is outside the message-passing hot path (SURVEY.md 7b)")
     raise ValueError(f"Model type '{model_type}' not supported.")
 
 

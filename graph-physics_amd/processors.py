@@ -29,10 +29,11 @@ class EncodeProcessDecode(nn.Module):
         self.rope_base = rope_base
         if self.use_rope and self.rope_axes not in (2, 3):
             raise ValueError("rope_pos_dimension must be 2 or 3 when use_rope_embeddings=True.")
-        if use_temporal_block:
-            raise NotImplementedError("TemporalAttention tail (training.use_temporal_block) is not built yet (SURVEY.md N3/N4: "
-                                      "it runs on the sparse-attention kernels of the Transformer processor)")
-        self.temporal_block = None
+        if use_temporal_block:  # processors.py:122-126
+            from .transformer import TemporalAttention
+            self.temporal_block = TemporalAttention(hidden_size=hidden_size)
+        else:
+            self.temporal_block = None
         if not self.only_processor:
             self.nodes_encoder = build_mlp(node_input_size, hidden_size, hidden_size)
             self.edges_encoder = build_mlp(edge_input_size, hidden_size, hidden_size)
@@ -60,17 +61,26 @@ class EncodeProcessDecode(nn.Module):
         blocks = list(self.processor_list)
         pos = getattr(graph, "pos", None) if self.use_rope else None
         phi = getattr(graph, "phi", None) if self.use_gate else None
-        if self.use_gated_mlp:
-            from .gated import gated_block_forward
-            for block in blocks:
-                x, e = gated_block_forward(block, x, e, topo, pos, phi)
-        elif blocks:
-            params = []
-            for block in blocks:
-                params += _block_params(block)
-            b0 = blocks[0]
-            x, _ = ops.processor_apply(x, e, topo, len(blocks), *params, spec=b0.spec, pos=pos, phi=phi,
-                                       rope_inv_freq=b0._rope_inv_freq if self.use_rope else None)
+        # the temporal block (processors.py:193-209) needs the node latents BEFORE the last round too
+        groups = [blocks] if not (self.use_temporal_block and len(blocks) > 1) else [blocks[:-1], blocks[-1:]]
+        prev_x = x
+        for grp in groups:
+            prev_x = x
+            if self.use_gated_mlp:
+                from .gated import gated_block_forward
+                for block in grp:
+                    prev_x = x
+                    x, e = gated_block_forward(block, x, e, topo, pos, phi)
+            elif grp:
+                params = []
+                for block in grp:
+                    params += _block_params(block)
+                b0 = grp[0]
+                x, e = ops.processor_apply(x, e, topo, len(grp), *params, spec=b0.spec, pos=pos, phi=phi,
+                                           rope_inv_freq=b0._rope_inv_freq if self.use_rope else None)
+        if self.use_temporal_block and self.temporal_block is not None:
+            from .transformer import get_attn_topology
+            x = self.temporal_block(prev_x, x, get_attn_topology(edge_index, n))
         if self.only_processor:
             return x
         return self.decode_module(x)

@@ -1,0 +1,256 @@
+"""Sparse-attention Transformer processor (BASELINE.json configs[4]): ``Attention``,
+``Transformer``, ``TemporalAttention`` and ``EncodeTransformDecode`` with the reference's constructor
+signatures, attribute names and ``state_dict`` keys (graphphysics/models/layers.py:562-887,
+processors.py:218-384).
+
+The attention itself -- edge-masked QK^T, per-row softmax over the mesh adjacency, AV -- is the SPARSE
+half and runs on the HIP kernels of csrc/mgn_attn.hip (CSR by row, online softmax, atomics-free two-pass
+backward).  It follows the reference's DGL branch (``HAS_DGL_SPARSE``): adjacency
+``dglsp.spmatrix(indices=edge_index)`` (rows = edge_index[0]), ``bsddmm`` -> ``softmax`` -> ``bspmm`` with
+the head index as the fastest axis of the hidden dimension.  Encoder / decoder are the engine's fused MLP
+kernels; the per-node projections and the gated MLP of a block are plain dense GEMMs (rocBLAS through
+``torch.nn.functional.linear``), as in ``gated.py``.  CUDA tensors only."""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _capi, ops
+from .gated import build_gated_mlp
+from .layers import RMSNorm, build_mlp
+
+
+class AttnTopology:
+    """CSR of the attention mask: rows = edge_index[0] (the attending node), columns = edge_index[1]."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+        t = ops.Topology(edge_index.flip(0), num_nodes)  # "dst"-sorted by edge_index[0]
+        self.N, self.E = t.N, t.E
+        self.rowptr, self.col, self.row = t.rowptr_dst, t.src_s, t.dst_s
+        self.cptr, self.cperm = t.rowptr_src, t.perm_src
+
+
+_attn_cache: dict = {}
+
+
+def get_attn_topology(edge_index: torch.Tensor, num_nodes: int) -> AttnTopology:
+    import weakref
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes), str(edge_index.device))
+    hit = _attn_cache.get(key)
+    if hit is not None and hit[0]() is edge_index:
+        return hit[1]
+    topo = AttnTopology(edge_index, num_nodes)
+    if len(_attn_cache) > 64:
+        _attn_cache.clear()
+    _attn_cache[key] = (weakref.ref(edge_index), topo)
+    return topo
+
+
+class SparseAttentionFn(torch.autograd.Function):
+    """y = softmax_rows(mask . q k^T / sqrt(D)) v on the HIP kernels (mgn_sparse_attn_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, topo: AttnTopology, num_heads: int):
+        ops._require_device(q, k, v)
+        q, k, v = (t.float().contiguous() for t in (q, k, v))
+        N, H = q.shape
+        y = torch.empty_like(q)
+        lse = torch.empty_like(q)
+        with torch.cuda.device(q.device):
+            rc = _capi.lib().mgn_sparse_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), topo.rowptr.data_ptr(), topo.col.data_ptr(),
+                                                 N, H, num_heads, y.data_ptr(), lse.data_ptr(), ops._stream(q.device))
+        _capi.check(rc, "mgn_sparse_attn_fwd", attn=True)
+        ctx.save_for_backward(q, k, v, y, lse)
+        ctx.topo, ctx.num_heads = topo, num_heads
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        q, k, v, y, lse = ctx.saved_tensors
+        topo, nh = ctx.topo, ctx.num_heads
+        dy = dy.float().contiguous()
+        N, H = q.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        ws = torch.empty(max(2 * topo.E * nh, 1), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            rc = _capi.lib().mgn_sparse_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(), lse.data_ptr(), dy.data_ptr(),
+                                                 topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.cptr.data_ptr(), topo.cperm.data_ptr(),
+                                                 topo.row.data_ptr(), N, topo.E, H, nh, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                                 ws.data_ptr(), ws.numel() * 4, ops._stream(q.device))
+        _capi.check(rc, "mgn_sparse_attn_bwd", attn=True)
+        return dq, dk, dv, None, None
+
+
+def sparse_attention(q, k, v, topo: AttnTopology, num_heads: int):
+    return SparseAttentionFn.apply(q, k, v, topo, num_heads)
+
+
+def _make_inv_freq(m: int, base: float) -> torch.Tensor:
+    """layers.py:410-417"""
+    if m <= 0:
+        return torch.empty(0, dtype=torch.float32)
+    step = math.log(base) / max(m, 1)
+    return torch.exp(-torch.arange(m, dtype=torch.float32) * step)
+
+
+def _apply_rope_with_inv(q, k, pos, inv_freq):
+    """Absolute RoPE on q / k in the [N, head_dim, num_heads] layout (layers.py:420-490): per position axis
+    a, pair i of the next 2m head dims rotates by pos[n, a] * inv_freq[i], the same for every head.
+    Elementwise device ops on N x hidden values."""
+    N, D, Hh = q.shape
+    pd = pos.shape[1]
+    m = D // (pd * 2)
+    if m == 0 or inv_freq.numel() == 0:
+        return q, k
+    d_rope = pd * 2 * m
+    ang = pos[:, :pd].to(torch.float32).unsqueeze(-1) * inv_freq.to(pos.device, torch.float32).view(1, 1, m)
+    cos, sin = torch.cos(ang).unsqueeze(-1), torch.sin(ang).unsqueeze(-1)   # [N, pd, m, 1]
+
+    def app(x):
+        part = x[:, :d_rope, :].reshape(N, pd, m, 2, Hh)
+        even, odd = part[..., 0, :], part[..., 1, :]
+        rot = torch.stack((even * cos - odd * sin, even * sin + odd * cos), dim=3).reshape(N, d_rope, Hh)
+        return torch.cat([rot, x[:, d_rope:, :]], dim=1) if D > d_rope else rot
+
+    return app(q), app(k)
+
+
+class Attention(nn.Module):
+    """layers.py:562-697"""
+
+    def __init__(self, input_dim=512, output_dim=512, num_heads=4, pos_dimension: int = 3, use_proj_bias: bool = True,
+                 use_separate_proj_weight: bool = True, use_rope_embeddings: bool = False, use_gated_attention: bool = False,
+                 rope_base: float = 10000.0):
+        super().__init__()
+        assert output_dim % num_heads == 0, "Output dimension must be divisible by number of heads."
+        self.hidden_size, self.num_heads, self.head_dim = output_dim, num_heads, output_dim // num_heads
+        self.use_rope_embeddings, self.use_gated_attention = use_rope_embeddings, use_gated_attention
+        self.pos_dimension, self.rope_base = pos_dimension, rope_base
+        self.q_proj = nn.Linear(input_dim, output_dim, bias=use_proj_bias)
+        self.k_proj = nn.Linear(input_dim, output_dim, bias=use_proj_bias)
+        self.v_proj = nn.Linear(input_dim, output_dim, bias=use_proj_bias)
+        self.proj = nn.Linear(output_dim, output_dim, bias=use_proj_bias)
+        if self.use_rope_embeddings:
+            self.m = self.head_dim // max(self.pos_dimension * 2, 1)
+            self.register_buffer("rope_inv_freq", _make_inv_freq(self.m, self.rope_base), persistent=True)
+        else:
+            self.m = 0
+            self.register_buffer("rope_inv_freq", torch.empty(0, dtype=torch.float32), persistent=False)
+        self.gate_proj = nn.Linear(input_dim, output_dim, bias=use_proj_bias) if use_gated_attention else None
+        if not use_separate_proj_weight:
+            with torch.no_grad():
+                self.k_proj.weight = self.q_proj.weight
+                self.v_proj.weight = self.q_proj.weight
+
+    def forward(self, x: torch.Tensor, adj, pos: Optional[torch.Tensor] = None, return_attention: bool = False):
+        """``adj``: an :class:`AttnTopology` (or an edge_index tensor, converted and cached)."""
+        if return_attention:
+            raise NotImplementedError("return_attention is not provided by the fused sparse-attention kernel")
+        if self.use_rope_embeddings and pos is None:
+            raise ValueError("RoPE embeddings require positional information when enabled.")
+        ops._require_device(x)
+        N = x.size(0)
+        topo = adj if isinstance(adj, AttnTopology) else get_attn_topology(adj, N)
+        q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        if self.use_rope_embeddings and self.rope_inv_freq.numel() > 0:
+            q3, k3 = _apply_rope_with_inv(q.reshape(N, self.head_dim, self.num_heads), k.reshape(N, self.head_dim, self.num_heads),
+                                          pos, self.rope_inv_freq)
+            q, k = q3.reshape(N, -1), k3.reshape(N, -1)
+        y = sparse_attention(q, k, v, topo, self.num_heads)
+        if self.use_gated_attention and self.gate_proj is not None:
+            y = y * torch.sigmoid(self.gate_proj(x))   # same flat layout as reshape(N, head_dim, num_heads)
+        return self.proj(y)
+
+
+class Transformer(nn.Module):
+    """layers.py:700-819: x + Attention(norm1(x)); x + gated_mlp(norm2(x))"""
+
+    def __init__(self, input_dim: int, output_dim: int, num_heads: int, activation_layer=nn.ReLU, use_proj_bias: bool = True,
+                 use_separate_proj_weight: bool = True, use_rope_embeddings: bool = False, use_gated_attention: bool = False,
+                 pos_dimension: int = 3, rope_base: float = 10000.0):
+        super().__init__()
+        self.use_rope_embeddings, self.use_gated_attention, self.pos_dimension = use_rope_embeddings, use_gated_attention, pos_dimension
+        self.attention = Attention(input_dim=input_dim, output_dim=output_dim, num_heads=num_heads, pos_dimension=pos_dimension,
+                                   use_proj_bias=use_proj_bias, use_separate_proj_weight=use_separate_proj_weight,
+                                   use_rope_embeddings=use_rope_embeddings, use_gated_attention=use_gated_attention, rope_base=rope_base)
+        self.activation = activation_layer()
+        self.norm1, self.norm2 = RMSNorm(output_dim), RMSNorm(output_dim)
+        self.gated_mlp = build_gated_mlp(in_size=output_dim, hidden_size=output_dim, out_size=output_dim)
+        self.use_adjacency = True
+
+    def forward(self, x: torch.Tensor, adj, pos: Optional[torch.Tensor] = None, return_attention: bool = False) -> torch.Tensor:
+        if self.use_rope_embeddings and pos is None:
+            raise ValueError("Transformer blocks require node positions when use_rope_embeddings=True.")
+        x = x + self.attention(self.norm1(x), adj, pos=pos, return_attention=return_attention)
+        return x + self.gated_mlp(self.norm2(x))
+
+
+class TemporalAttention(nn.Module):
+    """Temporal corrector as sparse cross-attention (layers.py:822-887): queries / values from the predicted
+    state, keys from the previous one; optional sigmoid gate; SiLU mixer."""
+
+    def __init__(self, hidden_size: int, num_heads: int = 4, use_gate: bool = True):
+        super().__init__()
+        assert hidden_size % num_heads == 0, "hidden_size must be divisible by num_heads"
+        self.h, self.H, self.d, self.use_gate = hidden_size, num_heads, hidden_size // num_heads, use_gate
+        self.q_proj = nn.Linear(self.h, self.h, bias=True)
+        self.k_proj = nn.Linear(self.h, self.h, bias=True)
+        self.v_proj = nn.Linear(self.h, self.h, bias=True)
+        self.out_proj = nn.Linear(self.h, self.h, bias=True)
+        if use_gate:
+            self.gate = nn.Sequential(nn.Linear(2 * self.h, self.h), nn.SiLU(), nn.Linear(self.h, self.h), nn.Sigmoid())
+        self.mixer = nn.Sequential(nn.Linear(2 * self.h, self.h), nn.SiLU(), nn.Linear(self.h, self.h))
+
+    def forward(self, h_prev: torch.Tensor, h_pred: torch.Tensor, adj=None) -> torch.Tensor:
+        ops._require_device(h_prev, h_pred)
+        if adj is None:
+            raise NotImplementedError("TemporalAttention runs over the mesh adjacency (the reference's DGL branch)")
+        topo = adj if isinstance(adj, AttnTopology) else get_attn_topology(adj, h_prev.size(0))
+        y = sparse_attention(self.q_proj(h_pred), self.k_proj(h_prev), self.v_proj(h_pred), topo, self.H)
+        out = self.out_proj(y)
+        if self.use_gate:
+            out = self.gate(torch.cat([h_pred, h_prev], dim=-1)) * out
+        h_corr = h_prev + out
+        return h_corr + self.mixer(torch.cat([h_corr, h_prev], dim=-1))
+
+
+class EncodeTransformDecode(nn.Module):
+    """processors.py:218-384 (the DGL branch: Transformer blocks over the sparse adjacency)"""
+
+    def __init__(self, message_passing_num: int, node_input_size: int, output_size: int, hidden_size: int = 128, num_heads: int = 4,
+                 only_processor: bool = False, use_proj_bias: bool = True, use_separate_proj_weight: bool = True,
+                 use_rope_embeddings: bool = False, use_gated_attention: bool = False, rope_pos_dimension: int = 3,
+                 rope_base: float = 10000.0, use_temporal_block: bool = False):
+        super().__init__()
+        self.hidden_size, self.only_processor, self.d = hidden_size, only_processor, output_size
+        self.use_rope_embeddings, self.use_gated_attention = use_rope_embeddings, use_gated_attention
+        self._requested_rope, self.use_temporal_block = use_rope_embeddings, use_temporal_block
+        if not self.only_processor:
+            self.nodes_encoder = build_mlp(node_input_size, hidden_size, hidden_size)
+            self.decode_module = build_mlp(hidden_size, hidden_size, output_size, layer_norm=False)
+        self.processor_list = nn.ModuleList([
+            Transformer(input_dim=hidden_size, output_dim=hidden_size, num_heads=num_heads, use_proj_bias=use_proj_bias,
+                        use_separate_proj_weight=use_separate_proj_weight, use_rope_embeddings=use_rope_embeddings,
+                        use_gated_attention=use_gated_attention, pos_dimension=rope_pos_dimension, rope_base=rope_base)
+            for _ in range(message_passing_num)])
+        self.temporal_block = TemporalAttention(hidden_size=hidden_size, num_heads=num_heads) if use_temporal_block else None
+
+    def forward(self, graph) -> torch.Tensor:
+        x = graph.x if self.only_processor else self.nodes_encoder(graph.x)
+        pos = getattr(graph, "pos", None)
+        if self.use_rope_embeddings and pos is None:
+            raise ValueError("use_rope_embeddings=True requires 'pos' attribute in the input graph.")
+        topo = getattr(graph, "mgn_attn_topology", None)
+        if topo is None:
+            topo = get_attn_topology(graph.edge_index, x.shape[0])
+        prev_x = last_x = x
+        for block in self.processor_list:
+            prev_x = x
+            last_x = block(prev_x, topo, pos=pos)
+            x = last_x
+        if self.use_temporal_block and self.temporal_block is not None:
+            x = self.temporal_block(prev_x, last_x, topo)
+        return x if self.only_processor else self.decode_module(x)

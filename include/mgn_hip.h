@@ -411,6 +411,28 @@ int mgn_rope_scatter(const float* T, const float* pos, int pos_w, const float* i
 /* text of the last error of the entry points in this section */
 const char* mgn_prep_last_error(void);
 
+/* ================================================================================
+ * Sparse-attention Transformer processor -- csrc/mgn_attn.hip
+ * ================================================================================
+ * Edge-masked scaled dot-product attention (graphphysics/models/layers.py:493-559 through DGL's
+ * bsddmm -> SparseMatrix.softmax -> bspmm over dglsp.spmatrix(indices=edge_index), processors.py:352):
+ *   score[e,h] = sum_d q[i_e,d,h] k[j_e,d,h] / sqrt(D);  attn = softmax over the edges of row i;
+ *   y[i,d,h]   = sum_{e in row i} attn[e,h] v[j_e,d,h]
+ * q, k, v, y are [N, H] row-major with the reference's head layout reshape(N, head_dim, num_heads)
+ * (layers.py:673-675): feature f = d * num_heads + h.  The edges come as a CSR grouped by ROW
+ * (rowptr[N+1], col[E] = j_e; rows = edge_index[0], columns = edge_index[1]).  lse ([N,H], optional)
+ * receives per feature the log-sum-exp of its head's scores (what the backward needs).  Rows without
+ * edges produce zeros.  H in {16,32,64,128}; num_heads in {1,2,4,8,16} dividing H.
+ * Backward: dq, dk, dv from dy; cptr[N+1] / cperm[E] group the same (row-sorted) edge positions by
+ * COLUMN, row_of_edge[E] = i_e; ws = 2 * E * num_heads floats.  Deterministic, atomics-free. */
+int mgn_sparse_attn_fwd(const float* q, const float* k, const float* v, const int32_t* rowptr, const int32_t* col,
+                        int64_t N, int H, int num_heads, float* y, float* lse, void* stream);
+int mgn_sparse_attn_bwd(const float* q, const float* k, const float* v, const float* y, const float* lse, const float* dy,
+                        const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
+                        const int32_t* row_of_edge, int64_t N, int64_t E, int H, int num_heads,
+                        float* dq, float* dk, float* dv, float* ws, size_t ws_bytes, void* stream);
+const char* mgn_attn_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

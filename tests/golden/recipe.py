@@ -153,6 +153,9 @@ def variant_params(state_dict, seed: int, key_order=None) -> "OrderedDict[str, t
     assert set(order) == set(state_dict.keys()), sorted(set(order) ^ set(state_dict.keys()))
     for k in order:
         t = state_dict[k]
+        if k.endswith("inv_freq"):  # persistent RoPE buffer (layers.py:617-619): a constant, not a weight
+            out[k] = t.detach().clone()
+            continue
         s = tuple(t.shape)
         if k.endswith("scale"):
             v = 1.0 + 0.1 * rng.standard_normal(size=s)
@@ -163,3 +166,13 @@ def variant_params(state_dict, seed: int, key_order=None) -> "OrderedDict[str, t
             v = rng.uniform(-0.1, 0.1, size=s)
         out[k] = torch.from_numpy(v.astype(np.float32))
     return out
+
+
+# ------------------------------------------------ sparse-attention Transformer cases (N4)
+TRANSFORMER_CASES = {
+    "etd_h64": dict(model="etd", hidden=64, heads=4, L=2, N=150, seed=501),                       # coarse-aneurysm.json shape
+    "etd_h128_rope_gate": dict(model="etd", hidden=128, heads=4, L=2, N=120, seed=502, rope=True, gate=True, pos_dim=3),
+    "etd_h32_heads8_temporal": dict(model="etd", hidden=32, heads=8, L=3, N=100, seed=503, temporal=True),
+    "etd_h64_heads2_rope2d": dict(model="etd", hidden=64, heads=2, L=2, N=100, seed=504, rope=True, pos_dim=2),
+    "epd_temporal": dict(model="epd", hidden=128, heads=4, L=3, N=120, seed=505),
+}

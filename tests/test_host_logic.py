@@ -44,8 +44,10 @@ def test_error_conventions():
         gp.get_model({"model": {"type": "foo", "node_input_size": 2}})  # parse_parameters.py:162
     with pytest.raises(ValueError, match="too small"):
         gp.GraphNetBlock(4, use_rope=True, rope_axes=3)  # layers.py:968-971
-    with pytest.raises(NotImplementedError):
-        gp.EncodeProcessDecode(1, 2, 2, 2, use_temporal_block=True)  # not built: never silently mis-computed
+    with pytest.raises(NotImplementedError, match="transolver"):
+        gp.get_model({"model": {"type": "transolver", "node_input_size": 2}})  # outside the message-passing path
+    with pytest.raises(AssertionError):
+        gp.Attention(64, 64, num_heads=5)  # layers.py:600-602
     blk = gp.GraphNetBlock(16, use_rope=True)
     with pytest.raises(ValueError, match="pos"):
         blk(torch.zeros(3, 16), torch.zeros(2, 2, dtype=torch.int64), torch.zeros(2, 16))  # layers.py:1021-1024
@@ -71,6 +73,16 @@ def test_block_variants_construct_with_reference_state_dict_keys():
         assert net.processor_list[0].use_gate and net.processor_list[0].use_rope
     finally:
         gp.layers.set_use_silu_activation(False)
+    # N4: the Transformer family through the same factory, reference parameter names
+    t = gp.get_model({"model": {"type": "transformer", "message_passing_num": 2, "hidden_size": 64, "node_input_size": 14, "output_size": 3,
+                                "edge_input_size": 0, "num_heads": 4, "use_rope_embeddings": True, "use_gated_attention": True},
+                      "training": {"use_temporal_block": True}})   # training_config/coarse-aneurysm.json shape
+    keys = set(t.state_dict())
+    assert {"processor_list.0.attention.q_proj.weight", "processor_list.0.attention.rope_inv_freq", "processor_list.0.attention.gate_proj.bias",
+            "processor_list.1.norm2.scale", "processor_list.0.gated_mlp.1.linear2.weight", "temporal_block.mixer.2.bias",
+            "temporal_block.gate.0.weight", "decode_module.6.bias"} <= keys
+    assert not any(k.startswith("edges_encoder") for k in keys) and t.nodes_encoder[0].in_features == 14 + 9
+    assert gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_temporal_block=True).temporal_block.H == 4
 
 
 def test_json_factory():
