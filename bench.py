@@ -396,12 +396,35 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
                                                "onto sources through perm_src = gathered 512-byte rows)", t_seg2, b_seg2)
     del m, agg, agg2, topo
     torch.cuda.empty_cache()
+    # (b2) the whole-mesh TRAINING step on one GPU: the saves of 15 rounds (~280 GB) do not fit, so the
+    # processor recomputes each round's activations inside the backward pass (ops.set_activation_recompute,
+    # "auto" switches it on here) -- the N = 1 point of the strong-scaling curve
+    graph = gp.Graph(x=x_in.to(dev), edge_attr=g.edge_attr.to(dev), edge_index=g.edge_index.to(dev))
+    graph.mgn_topology = ops.Topology(graph.edge_index, n)
+    tg, ntg = tgt.to(dev), nt.to(dev)
+    opt = harness.FusedClipAdamW(net.parameters(), 1e-4, max_norm=1.0)
+
+    def whole_train_step():
+        loss = harness.l2_loss(net(graph), tg, ntg)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    torch.cuda.reset_peak_memory_stats(dev)
+    t_tr = timed(whole_train_step, max(2, args.c4_steps - 1))
+    rec["train_ms_per_step"] = round(1e3 * t_tr, 2)
+    rec["node_train_steps_per_s"] = round(n / t_tr, 1)
+    rec["train_peak_mem_gib"] = round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)
+    rec["train_activation_recompute"] = ops.get_activation_recompute() + (
+        " (on: saved activations would be %.0f GB)" % (ops.saved_activation_bytes(E, n, H, 4, args.rounds, 0) / 1e9))
+    del graph, tg, ntg, opt
+    torch.cuda.empty_cache()
     # (c) rank 0 of the 8-way partition, forward + backward + optimiser, ghost rows zero-filled
     share = partitioned(8, 0, False)
     rec["rank_share_of_8"] = dict(share, note="per-GPU compute of the 8-way partitioned step (no exchange on one GPU)",
                                   est_8gpu_node_train_steps_per_s_before_comms=round(n / (share["train_ms_per_step"] * 1e-3), 1))
-    rec["note"] = ("N=1: the whole-mesh TRAINING step does not fit one GPU (~270 GB of saved activations); the N>1 runs of this "
-                   "command carry train_ms_per_step / node_train_steps_per_s of the partitioned step")
+    rec["note"] = ("N=1: train_ms_per_step is the whole mesh on one GPU with activation recompute; the N>1 runs of this command carry "
+                   "the partitioned step (saves kept when they fit: recompute switches itself off)")
     return rec
 
 

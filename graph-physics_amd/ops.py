@@ -450,6 +450,44 @@ def processor_apply(x, e, topo, L, *params, spec: BlockSpec = DEFAULT_SPEC, halo
         _call.grad = True
 
 
+#: activation recompute of the processor: "off" (save every round's activations: 2.5 KB per edge + 3 KB per
+#: node and round), "on", or "auto" (default): on when the saves would not fit comfortably -- more than
+#: MGN_RECOMPUTE_FRACTION (0.5) of the free device memory.  The 1M-node / 6M-edge mesh needs ~270 GB of
+#: saves for 15 rounds: with recompute it trains on ONE MI355X (~50 GB), at the price of one extra
+#: training-mode forward per round inside the backward pass.
+_recompute_mode = _os.environ.get("MGN_RECOMPUTE", "auto")
+
+
+def set_activation_recompute(mode: str) -> None:
+    global _recompute_mode
+    if mode not in ("off", "on", "auto"):
+        raise ValueError("activation recompute mode must be 'off', 'on' or 'auto'")
+    _recompute_mode = mode
+
+
+def get_activation_recompute() -> str:
+    return _recompute_mode
+
+
+def saved_activation_bytes(E: int, Nn: int, H: int, NL: int, L: int, act: int) -> int:
+    """what ProcessorFunction keeps for the backward pass without recompute"""
+    per_row = 4 * H * ((NL - 1) * (2 if act == 1 else 1) + 2) + 16 * (NL - 1) + 4   # H1.., [Z1..], U, input | masks | rms
+    return L * (E * per_row + Nn * (per_row + 4 * H))                                  # + agg per node
+
+
+def _want_recompute(E, Nn, H, NL, L, act, dev) -> bool:
+    if _recompute_mode == "on":
+        return True
+    if _recompute_mode == "off":
+        return False
+    try:
+        free, _total = torch.cuda.mem_get_info(dev)
+    except Exception:  # noqa: BLE001
+        return False
+    frac = float(_os.environ.get("MGN_RECOMPUTE_FRACTION", "0.5"))
+    return saved_activation_bytes(E, Nn, H, NL, L, act) > frac * free
+
+
 # ------------------------------------------------------------ generic MLP (R2)
 class MlpFunction(torch.autograd.Function):
     """build_mlp forward/backward on the engine (encoders, decoder, stand-alone MLPs).
@@ -692,18 +730,18 @@ class ProcessorFunction(torch.autograd.Function):
                 W00 = P[0].data_ptr()
                 blocks += [(W00 + 4 * H, 3 * H, False, unit(L, 0)), (W00 + 8 * H, 3 * H, False, unit(L, 1))]
             wpack(blocks, dev)
-        Pd = Ps = None
-        pending = None  # halo exchange in flight
-        if split:
-            W0 = P[0]
-            Pd, Ps = torch.empty(Nn, H, **f), torch.empty(N, H, **f)
-            for slab, dst_t in ((1, Pd), (2, Ps)):
-                mlp_fwd(Nn, H, [(x, None, H)], [W0[:, slab * H:(slab + 1) * H].contiguous()], [None], None, H, None, dst_t,
-                        wpk=[unit(L, slab - 1)] if x6 else (), precision=prec)
-            if halo is not None:
-                pending = halo.start_forward(Ps)
-        saved = []
-        for i in range(L):
+        def project(i, xi):
+            """round i's node projections Pd = x W_d^T, Ps = x W_s^T from the node latents (two one-unit launches)"""
+            W0 = P[PB * i]
+            Pd_, Ps_ = torch.empty(Nn, H, **f), torch.empty(N, H, **f)
+            for slab, dst_t in ((1, Pd_), (2, Ps_)):
+                u = (unit(L, slab - 1) if i == 0 else unit(i - 1, up0 + slab - 1)) if x6 else None
+                mlp_fwd(Nn, H, [(xi, None, H)], [W0[:, slab * H:(slab + 1) * H].contiguous()], [None], None, H, None, dst_t,
+                        wpk=[u] if x6 else (), precision=prec)
+            return Pd_, Ps_
+
+        def run_round(i, x, e, Pd, Ps, save, make_posts, pending):
+            """one GraphNetBlock round on the engine; ``save``: training-mode launches, activations returned in S"""
             We, be, se, Wn, bn, sn, gpar = _split_block(P[PB * i: PB * (i + 1)], spec)
             e_new = torch.empty(E, H, **f)
             x_new = torch.empty(Nn, H, **f)
@@ -711,7 +749,7 @@ class ProcessorFunction(torch.autograd.Function):
             m = None if fuse_agg else torch.empty(E, H, **f)
             He = Hn = Me = Mn = Ze = Zn = None
             Ue = Re = Un = Rn = None
-            if need:
+            if save:
                 He = [torch.empty(E, H, **f) for _ in range(NL - 1)]
                 Hn = [torch.empty(Nn, H, **f) for _ in range(NL - 1)]
                 if spec.layer_norm:
@@ -781,11 +819,11 @@ class ProcessorFunction(torch.autograd.Function):
                 G = torch.empty(Nn, H, **f)
                 mlp_fwd(Nn, H, [(x, None, H)], [Wg], [bg], None, H, None, G, wpk=[unit(i, ug)] if x6 else (), precision=prec)
                 agg_in = torch.empty(Nn, H, **f)
-                gate_t = torch.empty(Nn, H, **f) if need else None
+                gate_t = torch.empty(Nn, H, **f) if save else None
                 gate_fwd(G, phi, gpos if phi is not None else None, agg, gate_t, agg_in)
             # R5: x' = x + node_block(cat[x, agg])                         (layers.py:1100-1101,1040)
             posts, Pd_n, Ps_n = (), None, None
-            if split and i + 1 < L:
+            if make_posts:
                 W0n = P[PB * (i + 1)]
                 Pd_n, Ps_n = torch.empty(Nn, H, **f), torch.empty(N, H, **f)
                 posts = [(W0n.data_ptr() + 4 * H, Pd_n), (W0n.data_ptr() + 8 * H, Ps_n)]
@@ -797,11 +835,29 @@ class ProcessorFunction(torch.autograd.Function):
                         posts=posts, post_ldw=3 * H, wpk=wn, saveM=Mn, saveZ=Zn, act=act, precision=prec)
             if halo is not None and Ps_n is not None:
                 pending = halo.start_forward(Ps_n)
+            S = None
+            if save:
+                S = dict(x=x, e=e, agg=agg, agg_in=agg_in, gate=gate_t, xj=xj, He=He, Ue=Ue, Re=Re, Hn=Hn, Un=Un, Rn=Rn,
+                         Me=Me, Mn=Mn, Ze=Ze, Zn=Zn)
+            return x_new, e_new, Pd_n, Ps_n, S, pending
+
+        # activation recompute (see set_activation_recompute): the forward keeps only every round's INPUTS
+        # and runs the inference-mode launches; the backward re-runs a round in training mode right before
+        # differentiating it.  2.5 KB per edge and round shrink to 0.5 KB.
+        recompute = need and _want_recompute(E, Nn, H, NL, L, act, dev) and halo is None
+        Pd = Ps = None
+        pending = None  # halo exchange in flight
+        if split:
+            Pd, Ps = project(0, x)
+            if halo is not None:
+                pending = halo.start_forward(Ps)
+        saved = []
+        for i in range(L):
+            x_in, e_in = x, e
+            x, e, Pd, Ps, S, pending = run_round(i, x, e, Pd, Ps, need and not recompute, split and i + 1 < L, pending)
             if need:
-                saved.append(dict(x=x, e=e, agg=agg, agg_in=agg_in, gate=gate_t, xj=xj, He=He, Ue=Ue, Re=Re, Hn=Hn, Un=Un, Rn=Rn,
-                                  Me=Me, Mn=Mn, Ze=Ze, Zn=Zn))
-            x, e = x_new, e_new
-            Pd, Ps = Pd_n, Ps_n
+                saved.append(S if not recompute else dict(x=x_in, e=e_in))
+        ctx.rerun = (run_round, project) if recompute else None
         ctx.topo, ctx.L, ctx.saved_acts, ctx.prec, ctx.spec, ctx.halo = topo, L, (saved if need else None), prec, spec, halo
         ctx.aux = (pos, phi, rope_inv_freq, x6, split)
         ctx.save_for_backward(*P)  # version-checked by autograd (an optimiser step in between is an error)
@@ -823,6 +879,8 @@ class ProcessorFunction(torch.autograd.Function):
         dev = P[0].device
         H = P[1].numel()
         Nn = saved[0]["x"].shape[0]
+        if ctx.rerun is not None and _os.environ.get("MGN_FRONT") is not None:
+            raise RuntimeError("MGN_FRONT and activation recompute are mutually exclusive")
         f = dict(dtype=torch.float32, device=dev)
         dx = _f32c(dx) if dx is not None else torch.zeros(Nn, H, **f)
         de = _f32c(de) if de is not None else torch.zeros(E, H, **f)
@@ -888,7 +946,7 @@ class ProcessorFunction(torch.autograd.Function):
         # rows -> one launch (front stage of mgn_mlp_bwd); dZn double buffered across rounds
         # (measured neutral at N = 30k rows -- 88 us fused vs 57 + 30 us: a launch costs as many tile
         # times as it has GEMM units -- so it is opt-in: MGN_FRONT=1; tests/test_hip_parity.py covers it)
-        fuse = (x6 and _os.environ.get("MGN_FRONT") is not None and spec == DEFAULT_SPEC and halo is None)
+        fuse = (x6 and _os.environ.get("MGN_FRONT") is not None and spec == DEFAULT_SPEC and halo is None and ctx.rerun is None)
         dZn_sets = [dZn, [torch.empty(Nn, H, **f) for _ in range(NL)] if fuse and L > 1 else dZn]
         node_done = False
         # scale-gradient partials of all chain launches, reduced by ONE launch at the end (MGN_NO_DEFER: per launch)
@@ -898,6 +956,11 @@ class ProcessorFunction(torch.autograd.Function):
             q = P[PB * i: PB * (i + 1)]
             We, be, se, Wn, bn, sn, gpar = _split_block(q, spec)
             S = saved[i]
+            if ctx.rerun is not None:  # activation recompute: this round's training-mode forward, now
+                run_round, project = ctx.rerun
+                Pd_i, Ps_i = project(i, S["x"]) if split else (None, None)
+                S = run_round(i, S["x"], S["e"], Pd_i, Ps_i, True, False, None)[4]
+                saved[i] = None
             x, e, agg, agg_in = S["x"], S["e"], S["agg"], S["agg_in"]
             He, Ue, Re, Hn, Un, Rn = S["He"], S["Ue"], S["Re"], S["Hn"], S["Un"], S["Rn"]
             g = gs[i]

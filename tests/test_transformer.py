@@ -68,7 +68,9 @@ def test_oracle_vs_reference_golden(name):
             if gn < 1e-4:   # without RoPE a key bias shifts every score of a row alike: softmax-invariant, gradient = rounding noise
                 assert k.endswith("k_proj.bias") and float(p[k].grad.norm()) < 1e-4, k
                 continue
-            assert abs(float(p[k].grad.norm()) - gn) < 2e-5 * gn + 1e-8, k
+            # ReLU encoders / decoder / blocks: a pre-activation at rounding distance from zero can take the other
+            # branch on another host CPU (thread count changes the GEMM summation order): norms within 2e-3
+            assert abs(float(p[k].grad.norm()) - gn) < 2e-3 * gn + 1e-8, k
 
 
 # ----------------------------------------------------------------------------- GPU
