@@ -441,8 +441,9 @@ print("ok")
 # ------------------------------------------------------- activation recompute
 def test_activation_recompute_bit_identical_and_smaller(dev):
     """ops.set_activation_recompute("on"): the forward keeps only each round's inputs and the backward
-    re-runs the round in training mode -- same kernels on the same operands, so outputs and every gradient
-    are BIT-identical to the saving path, with a fraction of the activation memory."""
+    re-runs the round in training mode -- same kernels on the same operands: outputs bit-identical, gradients
+    equal to rounding (the re-run takes its node projections from two stand-alone launches instead of the
+    previous node kernel's post-products), with a fraction of the activation memory."""
     L, N = 6, 6000
     g = gp.cylinder_mesh(N, 2)
     params = R.make_params(R.epd_param_shapes(L, 128, 11, 3, 2), 5)
@@ -464,7 +465,7 @@ def test_activation_recompute_bit_identical_and_smaller(dev):
             del out, net
         finally:
             ops.set_activation_recompute("auto")
-    assert torch.equal(res["on"][0], res["off"][0])
-    for k in res["off"][1]:
-        assert torch.equal(res["on"][1][k], res["off"][1][k]), k
+    assert torch.equal(res["on"][0], res["off"][0])          # same forward arithmetic: bit-identical outputs
+    worst = max(rel_err(res["on"][1][k], res["off"][1][k]) for k in res["off"][1])
+    assert worst < 2e-6, worst                                 # re-run rounds: gradients to fp32 rounding
     assert res["on"][2] < 0.45 * res["off"][2], (res["on"][2], res["off"][2])
