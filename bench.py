@@ -117,11 +117,42 @@ class EventTimer:
         return len(self.rec.get(tag, []))
 
 
+DEVICE_COPY_GBPS = None  # measured once per run: what a plain device copy (half reads, half writes) sustains
+
+
+def device_copy_rate(dev):
+    """GB/s (bytes read + bytes written) of a 1 GiB device-to-device copy, past the 256 MiB Infinity Cache: the
+    practical ceiling for read+write streaming on this box (8 TB/s is the read-only spec peak; the training-mode
+    kernels WRITE two thirds of their traffic)."""
+    global DEVICE_COPY_GBPS
+    if DEVICE_COPY_GBPS is None:
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        a.normal_()
+        for _ in range(2):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        DEVICE_COPY_GBPS = round(5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del a, b
+        torch.cuda.empty_cache()
+    return DEVICE_COPY_GBPS
+
+
 def hbm_obj(kernel, t_ms, nbytes, traffic=None, extra=None):
     ach = nbytes / (t_ms * 1e-3) / 1e9
     d = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM, "unit": "GB/s",
          "frac": round(ach / PEAK_HBM, 4), "traffic": traffic, "launch_ms": round(t_ms, 5),
          "algorithmic_bytes_per_launch": int(nbytes)}
+    if DEVICE_COPY_GBPS:
+        d["device_copy_gbps"] = DEVICE_COPY_GBPS
+        d["frac_of_device_copy"] = round(ach / DEVICE_COPY_GBPS, 4)
+        if traffic:
+            d["traffic_rate_vs_device_copy"] = round(traffic / (t_ms * 1e-3) / 1e9 / DEVICE_COPY_GBPS, 4)
     if extra:
         d.update(extra)
     return d
@@ -156,6 +187,8 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
     ops.mlp_bwd = tm.wrap("edge_bwd", orig[1], lambda a, k: a[0] == E and a[1] == H and a[4] is not None)
     ops.wgrad = tm.wrap("wgrad", orig[2], lambda a, k: len(a[0]) >= 8)
     ops.segsum2 = tm.wrap("segsum", orig[3], lambda a, k: a[0].shape[0] == E)
+    orig_segsum = ops.segsum
+    ops.segsum = tm.wrap("segsum_src", orig_segsum, lambda a, k: a[0].shape[0] == E and a[2] is not None)
     sync, eng.grad_sync = eng.grad_sync, None  # rank 0 steps alone here: no collective (the timed region is over)
     try:
         for _ in range(steps):
@@ -167,6 +200,7 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
         torch.cuda.synchronize()
     finally:
         ops.mlp_fwd, ops.mlp_bwd, ops.wgrad, ops.segsum2 = orig
+        ops.segsum = orig_segsum
         eng.grad_sync = sync
     traffic, tnote = load_traffic(capi)
     x6 = ops.X6_ENABLED and H == 128
@@ -202,10 +236,17 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
         others.append(hbm_obj(f"k_mlp_fwd_{t} (edge update, inference mode = the rollout's dominant kernel: nothing saved, "
                               "aggregation fused)", tm.ms("edge_inf"), b_inf, None,
                               dict(mfma(tm.ms("edge_inf"), nterm if x6 else 1), launches_per_rollout_step=tm.count("edge_inf") // 2)))
-    roof_seg = hbm_obj("k_segsum2<8> (CSR segment sums = the scatter-add of the backward pass onto destination and source nodes; "
-                       "the forward aggregation is fused into the edge kernel's epilogue). Working set 217 MB < 256 MiB Infinity "
-                       "Cache: see c4.roofline_scatter for the past-L3 measurement", tm.ms("segsum"), b_seg, traffic.get("segsum_bytes"),
-                       {"launches_per_step": per_step("segsum")})
+    if tm.ms("segsum"):
+        roof_seg = hbm_obj("k_segsum2<8> (CSR segment sums = the scatter-add of the backward pass onto destination and source nodes; "
+                           "the forward aggregation is fused into the edge kernel's epilogue). Working set 217 MB < 256 MiB Infinity "
+                           "Cache: see c4.roofline_scatter for the past-L3 measurement", tm.ms("segsum"), b_seg, traffic.get("segsum_bytes"),
+                           {"launches_per_step": per_step("segsum")})
+    else:  # the destination-side scatter is fused into the backward chain: only the source-side sum is a launch of its own
+        b_src = row * (E + N) + 4.0 * E + 4.0 * (N + 1)
+        roof_seg = hbm_obj("k_segsum<8> through perm_src (the scatter-add of the backward pass onto SOURCE nodes: gathered 512-byte rows, "
+                           "CSR order; the destination-side sums of both passes are fused into the edge kernels). Working set 108 MB < "
+                           "256 MiB Infinity Cache: see c4.roofline_scatter for the past-L3 measurement", tm.ms("segsum_src"), b_src,
+                           traffic.get("segsum_src_bytes"), {"launches_per_step": per_step("segsum_src")})
     return roof, roof_seg, others
 
 
@@ -546,6 +587,7 @@ def main():
                          "ms_per_step_rebuild_every_step": round(1e3 * dt_rb / k_rb, 3)},
         }
         if not args.no_kernel_timing:
+            device_copy_rate(dev)
             roof, roof_seg, others = kernel_rooflines(gp, ops, capi, eng, batch, dev)
             out["roofline"], out["roofline_scatter"], out["roofline_other_kernels"] = roof, roof_seg, others
     # free the configs[1] state before the 1M-node record

@@ -87,6 +87,7 @@ class MlpBwdArgs(C.Structure):
         ("defer_reduce", C.c_int),
         ("act", C.c_int),
         ("Zs", _f32p * MAX_LAYERS),
+        ("seg_key", C.c_void_p), ("seg_rowptr", C.c_void_p), ("seg_out", _f32p), ("seg_part", _f32p),
     ]
 
 

@@ -1930,6 +1930,9 @@ static bool bwd_x6(const mgn_mlp_bwd_args& a) {
   if (a.n_front > 0 && a.dOut2 != nullptr) return false;
   for (int u = 0; u < G; ++u)
     if (a.wpk[u] == nullptr) return false;
+  if (a.seg_out != nullptr && (a.seg_key == nullptr || a.seg_rowptr == nullptr || a.seg_part == nullptr || a.dZ[0] == nullptr ||
+                               a.n_front > 0 || a.act != MGN_ACT_RELU || a.precision != 0 || a.NL < 2))
+    return false;
   if (a.act == MGN_ACT_SILU) {
     if (a.n_front > 0 || (a.n_din == 0 && a.dOut2 != nullptr)) return false;  // see k_mlp_bwd_x6: pd2 carries the z rows
     for (int l = 1; l < a.NL; ++l)
@@ -1953,7 +1956,8 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
           hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
           hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
           hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return 1;
       attr_done = true;
     }
@@ -1961,7 +1965,9 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
     for (int l = 0; l < a.NL; ++l) nused += (a.db[l] != nullptr) ? 1 : 0;
     const size_t lds = X6_BWD_LDS_BYTES(nused);
     const bool front = a.n_front > 0;
-    if (a.act == MGN_ACT_SILU) {
+    if (a.seg_out != nullptr) {
+      hipLaunchKernelGGL((k_mlp_bwd_x6<6, false, 0, true>), dim3(p.grid), dim3(256), lds, s, a);
+    } else if (a.act == MGN_ACT_SILU) {
       if (a.precision == 1)
         hipLaunchKernelGGL((k_mlp_bwd_x6<1, false, 1>), dim3(p.grid), dim3(256), lds, s, a);
       else
@@ -2140,6 +2146,8 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
     return fail(1, "mgn_mlp_bwd: the front stage needs the packed split-bf16 path (H = 128, full widths, wpk, Ms, no dOut2)");
   if (a.precision == 1 && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
     return fail(1, "mgn_mlp_bwd: bf16 matrix mode needs the packed split-bf16 path (H = 128, full widths, wpk, Ms)");
+  if (a.seg_out != nullptr && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
+    return fail(1, "mgn_mlp_bwd: the fused segment sum of dZ[0] needs the packed split-bf16 path (fp32-grade, ReLU, dZ[0], no front stage)");
   if (a.M == 0) return 0;
   if (a.red_ws_bytes < mgn_mlp_bwd_workspace_bytes(a.M, a.H, a.NL)) return fail(1, "mgn_mlp_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;

@@ -224,8 +224,10 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
             din: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]],
             db: Sequence[Optional[torch.Tensor]], dscale: Optional[torch.Tensor], wpk: Sequence[int] = (),
             Ms: Optional[Sequence[torch.Tensor]] = None, precision: int = 0, front=None, defer: Optional[list] = None,
-            act: int = 0, Zs: Optional[Sequence[torch.Tensor]] = None):
-    """``front`` = (rows[<=3] each [M,H], resid[M,H] or None, out[M,H] or None): the fused front
+            act: int = 0, Zs: Optional[Sequence[torch.Tensor]] = None, seg=None):
+    """``seg`` = (key[M] int32 sorted, rowptr, out[n,H], part[ceil(M/16),2,H]): fused segment sum of dZ[0]
+    (finish with :func:`seg_fix`).
+    ``front`` = (rows[<=3] each [M,H], resid[M,H] or None, out[M,H] or None): the fused front
     stage of the packed kernel, dY = resid + sum_p wpk[p] . rows[p] (then ``dOut`` is ignored)."""
     L = _capi.lib()
     a = _capi.MlpBwdArgs()
@@ -252,6 +254,8 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
     if Zs is not None:
         for l, t in enumerate(Zs):
             a.Zs[l] = _ptr(t)
+    if seg is not None:
+        a.seg_key, a.seg_rowptr, a.seg_out, a.seg_part = (_ptr(t) for t in seg)
     if front is not None:
         rows, fres, fout = front
         a.n_front = len(rows)
@@ -999,9 +1003,18 @@ class ProcessorFunction(torch.autograd.Function):
                 gate_bwd(dAgg, agg, S["gate"], dAgg, dG)
             # edge MLP chain: dM = dE' + dAgg[dst] -> dZe[NL-1..0], dE = dE' + W0e[:, :H]^T dZe0
             de_new = de_buf[0] if de.data_ptr() != de_buf[0].data_ptr() else de_buf[1]
+            # ... with the destination-side scatter of dZe[0] fused into the chain (rows are dst-sorted: the
+            # forward's segmented scan), packed fp32-grade ReLU path only
+            fuse_sd = x6 and act == 0 and prec == 0 and E > 0 and _os.environ.get("MGN_NO_FUSED_SD") is None
             if E > 0:
+                seg = None
+                if fuse_sd:
+                    part_b = torch.empty((E + 15) // 16, 2, H, **f)
+                    seg = (topo.dst_s, topo.rowptr_dst, Sd, part_b)
                 mlp_bwd(E, H, NL, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
-                        [None] * NL, gse, wpk=ke, Ms=S["Me"], Zs=S["Ze"], act=act, precision=prec, defer=deferred)
+                        [None] * NL, gse, wpk=ke, Ms=S["Me"], Zs=S["Ze"], act=act, precision=prec, defer=deferred, seg=seg)
+                if fuse_sd:
+                    seg_fix(topo.rowptr_dst, part_b, Sd)
             else:
                 de_new = de
             # scatter of the first-layer pre-activations' grads onto dst / src nodes
@@ -1009,12 +1022,15 @@ class ProcessorFunction(torch.autograd.Function):
             if spec.rope:
                 # the source slab saw ROTATED rows: T = W_s^T dz0 per edge, rotated back and summed over
                 # the edges of each source node, straight into the residual of the dX launch
-                segsum(dZe[0], topo.rowptr_dst, None, Sd)
+                if not fuse_sd:
+                    segsum(dZe[0], topo.rowptr_dst, None, Sd)
                 T = torch.empty(E, H, **f)
                 WsT = None if x6 else Wcat[:, 2 * H:].contiguous()
                 mlp_fwd(E, H, [(dZe[0], None, H)], [WsT], [None], None, H, None, T, wpk=[kx[2]] if x6 else (), precision=prec)
                 dx_res = torch.empty(Nn, H, **f)
                 rope_scatter(T, pos, rope_inv_freq, topo, spec.rope_axes, dx, dx_res)
+            elif fuse_sd:
+                segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)
             elif H == 128:
                 segsum2(dZe[0], topo.rowptr_dst, None, Sd, topo.rowptr_src, topo.perm_src, Ss)
             else:

@@ -209,6 +209,14 @@ typedef struct {
    * (pre-activations) replaces Hs / Ms:  dZ[l-1] = (WT[l] dZ[l]) * silu'(Zs[l-1]). */
   int act;
   const float* Zs[MGN_MAX_LAYERS];
+  /* Fused segment sum of dZ[0] (split-bf16 kernel, fp32-grade / ReLU, no front stage; dZ[0] != NULL): the
+   * rows are sorted by seg_key (the CSR order) and the kernel adds dZ[0] up over every run of equal keys
+   * exactly as mgn_mlp_fwd does for its output (seg_out / seg_part, finish with mgn_seg_fix) -- the
+   * backward scatter of the first-layer gradients onto DESTINATION nodes without re-reading dZ[0]. */
+  const int32_t* seg_key;
+  const int32_t* seg_rowptr;
+  float* seg_out;
+  float* seg_part;
 } mgn_mlp_bwd_args;
 size_t mgn_mlp_bwd_workspace_bytes(int64_t M, int H, int NL);
 int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream);
