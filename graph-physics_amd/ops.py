@@ -861,7 +861,8 @@ class ProcessorFunction(torch.autograd.Function):
             x, e, Pd, Ps, S, pending = run_round(i, x, e, Pd, Ps, need and not recompute, split and i + 1 < L, pending)
             if need:
                 saved.append(S if not recompute else dict(x=x_in, e=e_in))
-        ctx.rerun = (run_round, project) if recompute else None
+        # the closures address the packed weights by raw pointer: keep the buffer alive with them
+        ctx.rerun = (run_round, project, pk if x6 else None) if recompute else None
         ctx.topo, ctx.L, ctx.saved_acts, ctx.prec, ctx.spec, ctx.halo = topo, L, (saved if need else None), prec, spec, halo
         ctx.aux = (pos, phi, rope_inv_freq, x6, split)
         ctx.save_for_backward(*P)  # version-checked by autograd (an optimiser step in between is an error)
@@ -961,7 +962,7 @@ class ProcessorFunction(torch.autograd.Function):
             We, be, se, Wn, bn, sn, gpar = _split_block(q, spec)
             S = saved[i]
             if ctx.rerun is not None:  # activation recompute: this round's training-mode forward, now
-                run_round, project = ctx.rerun
+                run_round, project = ctx.rerun[:2]
                 Pd_i, Ps_i = project(i, S["x"]) if split else (None, None)
                 S = run_round(i, S["x"], S["e"], Pd_i, Ps_i, True, False, None)[4]
                 saved[i] = None
@@ -1005,7 +1006,9 @@ class ProcessorFunction(torch.autograd.Function):
             de_new = de_buf[0] if de.data_ptr() != de_buf[0].data_ptr() else de_buf[1]
             # ... with the destination-side scatter of dZe[0] fused into the chain (rows are dst-sorted: the
             # forward's segmented scan), packed fp32-grade ReLU path only
-            fuse_sd = x6 and act == 0 and prec == 0 and E > 0 and _os.environ.get("MGN_NO_FUSED_SD") is None
+            # (measured neutral on the bench workload -- the chain kernel gains the 10 us the stand-alone sum
+            # loses -- so it is opt-in: MGN_FUSED_SD=1; tests/test_hip_parity.py covers it)
+            fuse_sd = x6 and act == 0 and prec == 0 and E > 0 and _os.environ.get("MGN_FUSED_SD") is not None
             if E > 0:
                 seg = None
                 if fuse_sd:

@@ -551,10 +551,10 @@ torch.save({"out": out.detach().cpu(), **{k: p.grad.cpu() for k, p in net.named_
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = code % (root, os.path.join(root, "tests", "golden"))
     res = {}
-    for tag, env in (("x6", {}), ("fp32", {"MGN_FP32_MFMA": "1"}), ("front", {"MGN_FRONT": "1"})):
+    for tag, env in (("x6", {}), ("fp32", {"MGN_FP32_MFMA": "1"}), ("front", {"MGN_FRONT": "1"}), ("fused_sd", {"MGN_FUSED_SD": "1"})):
         path = f"/tmp/_mgn_paths_{tag}_{os.getpid()}.pt"
         e = dict(os.environ, **env)
-        for k_ in ("MGN_FP32_MFMA", "MGN_FRONT"):
+        for k_ in ("MGN_FP32_MFMA", "MGN_FRONT", "MGN_FUSED_SD"):
             if k_ not in env:
                 e.pop(k_, None)
         r = subprocess.run([sys.executable, "-c", code, path], env=e, capture_output=True, text=True)
@@ -566,6 +566,8 @@ torch.save({"out": out.detach().cpu(), **{k: p.grad.cpu() for k, p in net.named_
         assert rel_err(res["x6"][k], res["fp32"][k]) < (2e-6 if k == "out" else 3e-4), k
         # the fused "dX of round i + node chain of round i-1" launch (MGN_FRONT=1) is the same arithmetic
         assert rel_err(res["front"][k], res["x6"][k]) < (1e-7 if k == "out" else 2e-5), k
+        # the destination-side scatter of dZ0 fused into the backward chain (MGN_FUSED_SD=1): tree-ordered sums
+        assert rel_err(res["fused_sd"][k], res["x6"][k]) < (1e-7 if k == "out" else 2e-5), k
 
 
 def test_rollout_graphed_equals_eager(dev):
