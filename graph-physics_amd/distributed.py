@@ -98,7 +98,10 @@ class HaloState:
         self.send_rowptr = plan.send_rowptr.to(**i32)
         self.send_perm = plan.send_perm.to(**i32)
         self.send_counts, self.recv_counts = list(plan.send_counts), list(plan.recv_counts)
-        self.active = plan.world > 1 and dist.is_initialized() and dist.get_world_size(group) > 1
+        # a collective is needed whenever rows are exchanged and a process group exists (a world-1 group is legal:
+        # the self-exchange plan of tests/test_halo_rccl_single.py runs the whole path over RCCL on one GPU)
+        self.active = dist.is_initialized() and dist.get_world_size(group) == plan.world and \
+            (self.n_ghost > 0 or int(plan.send_idx.numel()) > 0) and (plan.world > 1 or getattr(plan, "self_exchange", False))
         self._rowptr_bnd = None
 
     def rowptr_bnd(self, topo):
