@@ -7,7 +7,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fd, wd, tag = sys.argv[1:4]
-KEYS = {("k_mlp_fwd_x6", 512): "edge_fwd", ("k_mlp_bwd_x6", 512): "edge_bwd", ("k_wgrad_x6", 512): "wgrad",
+KEYS = {("k_mlp_fwd_x6<6, 4, 0>", 512): "edge_fwd", ("k_mlp_bwd_x6<6, false, 0", 512): "edge_bwd", ("k_wgrad_x6", 512): "wgrad",
         ("k_segsum2<8>", None): "segsum", ("__amd_rocclr_copyBuffer", None): "calibration_copy"}
 def collect(d, counter):
     acc = defaultdict(list)
@@ -40,6 +40,9 @@ with open(path, "w") as fh:
     fh.write("kernel,fetch_launches,fetch_avg_KB,write_launches,write_avg_KB,read_bytes_corrected,write_bytes,hbm_bytes_per_launch\n")
     for r in rows:
         fh.write(",".join(str(x) for x in r) + "\n")
+sys.path.insert(0, REPO)
+from graph_physics_amd import _capi  # noqa: E402
+out["csrc_hash"] = _capi.source_hash()   # bench.py refuses this file for any other build of csrc/
 out["source"] = f"profiles/{tag}_pmc_hbm_traffic.csv (rocprofv3 PMC passes over real training steps, FETCH_SIZE x{fcorr:.2f} per the calibration copy)"
 out["workload"] = "N=30160, E=180082 (bench default), per launch, averaged over the launches of 3 training steps"
 json.dump(out, open(os.path.join(REPO, "profiles", "pmc_traffic.json"), "w"), indent=1)
