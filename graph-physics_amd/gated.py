@@ -41,31 +41,33 @@ def build_gated_mlp(in_size: int, hidden_size: int, out_size: int, expansion_fac
 
 
 class _Gather(torch.autograd.Function):
-    """rows[idx] with the backward as a CSR segment sum (no atomics): ``seg`` = (rowptr, perm) of the
-    grouping of the edge rows by this index."""
+    """rows gathered by the dst- or src- index of the dst-sorted edges; the backward is the CSR segment sum of
+    the same grouping (no atomics, hub-safe)."""
 
     @staticmethod
-    def forward(ctx, x, idx, rowptr, perm):
-        ctx.seg = (rowptr, perm)
-        return ops.gather_rows(x.contiguous(), idx)
+    def forward(ctx, x, topo, by):
+        ctx.aux = (topo, by, x.shape[0])
+        return ops.gather_rows(x.contiguous(), topo.dst_s if by == "dst" else topo.src_s)
 
     @staticmethod
     def backward(ctx, g):
-        rowptr, perm = ctx.seg
-        return ops.segsum(g.contiguous(), rowptr, perm), None, None, None
+        topo, by, n = ctx.aux
+        out = torch.empty(n, g.shape[1], dtype=torch.float32, device=g.device)
+        return ops.segsum_topo(g.contiguous(), topo, by, out), None, None
 
 
 class _SegSum(torch.autograd.Function):
     """agg[i] = sum of the (dst-sorted) message rows of node i; backward = gather by dst."""
 
     @staticmethod
-    def forward(ctx, m, rowptr, dst_s):
-        ctx.dst_s = dst_s
-        return ops.segsum(m.contiguous(), rowptr, None)
+    def forward(ctx, m, topo):
+        ctx.topo = topo
+        out = torch.empty(topo.N, m.shape[1], dtype=torch.float32, device=m.device)
+        return ops.segsum_topo(m.contiguous(), topo, "dst", out)
 
     @staticmethod
     def backward(ctx, g):
-        return ops.gather_rows(g.contiguous(), ctx.dst_s), None, None
+        return ops.gather_rows(g.contiguous(), ctx.topo.dst_s), None
 
 
 class _Rope(torch.autograd.Function):
@@ -90,15 +92,15 @@ def gated_block_forward(block, x: torch.Tensor, e_sorted: torch.Tensor, topo, po
     returned edge latents are in the topology's dst-sorted order."""
     ops._require_device(x, e_sorted)
     x = x.float().contiguous()
-    x_i = _Gather.apply(x, topo.dst_s, topo.rowptr_dst, None)
+    x_i = _Gather.apply(x, topo, "dst")
     if block.use_rope:
         if pos is None:
             raise ValueError("Node positions `pos` must be provided when use_rope=True.")
         x_j = _Rope.apply(x, pos.float().contiguous(), block._rope_inv_freq, topo, block.rope_axes)
     else:
-        x_j = _Gather.apply(x, topo.src_s, topo.rowptr_src, topo.perm_src)
+        x_j = _Gather.apply(x, topo, "src")
     m = block.edge_block(torch.cat([e_sorted, x_i, x_j], dim=-1))          # edge_update, layers.py:1044-1060
-    agg = _SegSum.apply(m, topo.rowptr_dst, topo.dst_s)                    # propagate(aggr="add"), :1031-1037
+    agg = _SegSum.apply(m, topo)                                           # propagate(aggr="add"), :1031-1037
     if block.use_gate:                                                     # update, :1091-1098
         logits = block.gate_proj(x)
         if phi is not None:

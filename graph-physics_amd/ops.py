@@ -88,6 +88,22 @@ class Topology:
         self.dst_s = ei[1][p].to(torch.int32).contiguous()
         self.rowptr_src, self.perm_src = csr_build(self.src_s.long(), N)
         self._inv = None
+        # Hub nodes.  A segment is summed by ONE lane group walking it in order -- ideal for meshes (degree
+        # ~6), unbounded for the arbitrary edge_index the input contract allows (a node with 100 000 in-edges
+        # would serialise 100 000 row loads).  Segments longer than HUB_CHUNK are therefore cut into chunks
+        # summed in parallel, and a second small segment sum adds the chunk rows of each node (fixed order:
+        # still deterministic, no atomics).  The degree maxima cost one host read at topology build.
+        self.hub_dst = self.hub_src = None
+        if E > 0:
+            mx = torch.stack([(self.rowptr_dst[1:] - self.rowptr_dst[:-1]).max(), (self.rowptr_src[1:] - self.rowptr_src[:-1]).max()]).tolist()
+            if mx[0] > HUB_CHUNK:
+                self.hub_dst = _chunk_csr(self.rowptr_dst)
+            if mx[1] > HUB_CHUNK:
+                self.hub_src = _chunk_csr(self.rowptr_src)
+
+    @property
+    def has_hubs(self) -> bool:
+        return self.hub_dst is not None or self.hub_src is not None
 
     @property
     def inv_perm(self) -> torch.Tensor:
@@ -97,6 +113,43 @@ class Topology:
             inv[self.perm_dst.long()] = torch.arange(self.E, device=self.device)
             self._inv = inv
         return self._inv
+
+
+HUB_CHUNK = 1024  # longest segment one lane group sums on its own
+
+
+def _chunk_csr(rowptr: torch.Tensor):
+    """(chunk_rowptr[C+1], node_chunkptr[N+1]): every segment cut into chunks of at most HUB_CHUNK rows;
+    chunk c of node i covers rows chunk_rowptr[c] .. chunk_rowptr[c+1], the chunks of node i are
+    node_chunkptr[i] .. node_chunkptr[i+1].  One-time topology prep (torch index arithmetic on the device)."""
+    rp = rowptr.long()
+    deg = rp[1:] - rp[:-1]
+    nch = (deg + HUB_CHUNK - 1) // HUB_CHUNK
+    node_chunkptr = torch.zeros(rp.numel(), dtype=torch.int64, device=rp.device)
+    node_chunkptr[1:] = torch.cumsum(nch, 0)
+    C = int(node_chunkptr[-1])
+    owner = torch.repeat_interleave(torch.arange(deg.numel(), device=rp.device), nch)
+    k = torch.arange(C, device=rp.device) - node_chunkptr[owner]
+    start = rp[owner] + k * HUB_CHUNK
+    chunk_rowptr = torch.empty(C + 1, dtype=torch.int64, device=rp.device)
+    chunk_rowptr[:C] = start
+    chunk_rowptr[C] = rp[-1]
+    # chunk c ends where the next one starts, except the last chunk of a node: its segment end
+    end = torch.minimum(start + HUB_CHUNK, rp[owner + 1])
+    assert bool((end[:-1] == start[1:]).all()) if C > 1 else True
+    return chunk_rowptr.to(torch.int32), node_chunkptr.to(torch.int32)
+
+
+def segsum_topo(src: torch.Tensor, topo: "Topology", by: str, out: torch.Tensor, n_rows: Optional[int] = None) -> torch.Tensor:
+    """segment sum of the dst-sorted edge rows ``src`` onto nodes, ``by`` = "dst" (rows in segment order) or
+    "src" (through perm_src); hub-safe (see Topology)."""
+    rowptr, perm, hub = (topo.rowptr_dst, None, topo.hub_dst) if by == "dst" else (topo.rowptr_src, topo.perm_src, topo.hub_src)
+    n = out.shape[0] if n_rows is None else n_rows
+    if hub is None:
+        return segsum(src, rowptr[:n + 1], perm, out)
+    chunk_rowptr, node_chunkptr = hub
+    part = segsum(src, chunk_rowptr, perm)                      # one row per chunk
+    return segsum(part, node_chunkptr[:n + 1], None, out)       # chunks of a node, in order
 
 
 _topo_cache: dict = {}
@@ -699,7 +752,9 @@ class ProcessorFunction(torch.autograd.Function):
         prec = prec if x6 else 0
         if halo is not None and not (x6 and split):
             raise NotImplementedError("the partitioned path runs on the packed H = 128 kernels (no RoPE)")
-        fuse_agg = x6 and _os.environ.get("MGN_NO_FUSED_AGG") is None
+        # (the fused aggregation's second stage walks a node's tile partials serially: hub topologies take the
+        # stand-alone, chunked segment sum instead)
+        fuse_agg = x6 and _os.environ.get("MGN_NO_FUSED_AGG") is None and not topo.has_hubs
         relu_bits = x6 and act == 0
         # ---- packed units of all rounds, one launch.  Per round:
         #   edge  [We0|e (, We0|x_dst, We0|x_src with RoPE), We1 .. We_{NL-1}]
@@ -815,7 +870,7 @@ class ProcessorFunction(torch.autograd.Function):
                         agg[ni:].zero_()
             # R4: agg = segment-sum of m over dst                          (layers.py:1031-1037)
             if not fuse_agg:
-                segsum(m, topo.rowptr_dst[:Nn + 1], None, agg)
+                segsum_topo(m, topo, "dst", agg, Nn)
             # gate on the aggregate (layers.py:1091-1098): agg * sigmoid(gate_proj(x) + phi * gate_pos)
             agg_in, gate_t = agg, None
             if spec.gate:
@@ -1008,7 +1063,7 @@ class ProcessorFunction(torch.autograd.Function):
             # forward's segmented scan), packed fp32-grade ReLU path only
             # (measured neutral on the bench workload -- the chain kernel gains the 10 us the stand-alone sum
             # loses -- so it is opt-in: MGN_FUSED_SD=1; tests/test_hip_parity.py covers it)
-            fuse_sd = x6 and act == 0 and prec == 0 and E > 0 and _os.environ.get("MGN_FUSED_SD") is not None
+            fuse_sd = x6 and act == 0 and prec == 0 and E > 0 and _os.environ.get("MGN_FUSED_SD") is not None and not topo.has_hubs
             if E > 0:
                 seg = None
                 if fuse_sd:
@@ -1026,19 +1081,19 @@ class ProcessorFunction(torch.autograd.Function):
                 # the source slab saw ROTATED rows: T = W_s^T dz0 per edge, rotated back and summed over
                 # the edges of each source node, straight into the residual of the dX launch
                 if not fuse_sd:
-                    segsum(dZe[0], topo.rowptr_dst, None, Sd)
+                    segsum_topo(dZe[0], topo, "dst", Sd)
                 T = torch.empty(E, H, **f)
                 WsT = None if x6 else Wcat[:, 2 * H:].contiguous()
                 mlp_fwd(E, H, [(dZe[0], None, H)], [WsT], [None], None, H, None, T, wpk=[kx[2]] if x6 else (), precision=prec)
                 dx_res = torch.empty(Nn, H, **f)
                 rope_scatter(T, pos, rope_inv_freq, topo, spec.rope_axes, dx, dx_res)
             elif fuse_sd:
-                segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)
-            elif H == 128:
+                segsum_topo(dZe[0], topo, "src", Ss)
+            elif H == 128 and not topo.has_hubs:
                 segsum2(dZe[0], topo.rowptr_dst, None, Sd, topo.rowptr_src, topo.perm_src, Ss)
             else:
-                segsum(dZe[0], topo.rowptr_dst, None, Sd)
-                segsum(dZe[0], topo.rowptr_src, topo.perm_src, Ss)
+                segsum_topo(dZe[0], topo, "dst", Sd)
+                segsum_topo(dZe[0], topo, "src", Ss)
             back = None
             if halo is not None:  # ghost rows of Ss go back to their owners while the E-row weight gradients run
                 back = halo.start_backward(Ss)

@@ -469,3 +469,44 @@ def test_activation_recompute_bit_identical_and_smaller(dev):
     worst = max(rel_err(res["on"][1][k], res["off"][1][k]) for k in res["off"][1])
     assert worst < 2e-6, worst                                 # re-run rounds: gradients to fp32 rounding
     assert res["on"][2] < 0.45 * res["off"][2], (res["on"][2], res["off"][2])
+
+
+# ------------------------------------------------------------------ hub nodes (R0)
+def test_hub_nodes_take_the_chunked_segment_sums(dev):
+    """Arbitrary edge_index (input contract R0): a node with 30 000 in-edges and one with 20 000 out-edges.
+    The topology flags them, the processor switches to chunked, parallel segment sums (deterministic, two
+    levels) and forward / gradients still match the oracle."""
+    N, seed = 600, 9
+    rng = np.random.default_rng(seed)
+    base = R.delaunay_graph(N, seed)[1].numpy()
+    hub_in = np.stack([rng.integers(0, N, 30000), np.full(30000, 7)])       # everything points at node 7
+    hub_out = np.stack([np.full(20000, 11), rng.integers(0, N, 20000)])      # node 11 points everywhere
+    ei = torch.from_numpy(np.concatenate([base, hub_in, hub_out], axis=1).astype(np.int64))
+    E = ei.shape[1]
+    topo = ops.Topology(ei.to(dev), N)
+    assert topo.hub_dst is not None and topo.hub_src is not None and topo.has_hubs
+    crp, ncp = topo.hub_dst
+    assert int((crp[1:] - crp[:-1]).max()) <= ops.HUB_CHUNK and int(ncp[-1]) == crp.numel() - 1
+    # the chunked sum against the plain one
+    m = R.randn((E, 128), 3).to(dev)
+    out = torch.empty(N, 128, device=dev)
+    ops.segsum_topo(m, topo, "dst", out)
+    assert rel_err(out, ops.segsum(m, topo.rowptr_dst, None)) < 1e-6
+    ops.segsum_topo(m, topo, "src", out)
+    assert rel_err(out, ops.segsum(m, topo.rowptr_src, topo.perm_src)) < 1e-6
+    # end to end
+    L = 2
+    params = R.make_params(R.epd_param_shapes(L, 128, 11, 3, 2), seed)
+    x_in, e_in, cot = R.randn((N, 11), 1), 0.1 * R.randn((E, 3), 2), R.randn((N, 2), 3)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.epd_forward(x_in, e_in, ei, p, L)
+    (ref * cot).sum().backward()
+    net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=128).to(dev)
+    net.load_state_dict(params)
+    g = gp.Graph(x=x_in.to(dev), edge_attr=e_in.to(dev), edge_index=ei.to(dev))
+    g.mgn_topology = topo
+    o = net(g)
+    (o * cot.to(dev)).sum().backward()
+    assert_close3(o, ref, FWD_TOL, "hub graph forward")
+    for k, q in net.named_parameters():
+        assert rel_err(q.grad, p[k].grad) < 1e-3, k   # sums of 30 000 rows in another order + ReLU masks
