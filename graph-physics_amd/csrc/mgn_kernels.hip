@@ -40,12 +40,19 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { if (v[0] != v[0]) *(g_f
 #else
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *(g_f32x4*)p = v; }
 #endif
-// write-once data that is only read again much later (saved activations for the backward
-// pass): non-temporal, measured -2.7 % on the training-mode edge kernel
+// Write-once data that is only read again much later (saved activations for the backward pass).  A store
+// instruction covers 64 B of each of 16 rows -- HALF a 128-byte line -- and the other half follows one
+// instruction later: through plain stores the XCD's L2 merges the halves into whole-line write-backs;
+// non-temporal stores (the round-1 choice, -2.7 % on the exact-fp32 generation) let them leave separately
+// and cost the packed kernel 12 % more write traffic (545 vs 487 MB per launch, WRITE_SIZE) and 6 % of its
+// time (239/232/237 vs 224/222/221 us, alternating A/B in one GPU call).  -DMGN_EXP_NT_SAVES rebuilds the
+// non-temporal variant.
 #ifdef MGN_EXP_NOSTORE
 __device__ __forceinline__ void st4_stream(float* p, f32x4 v) { if (v[0] != v[0]) *(g_f32x4*)p = v; }
-#else
+#elif defined(MGN_EXP_NT_SAVES)
 __device__ __forceinline__ void st4_stream(float* p, f32x4 v) { __builtin_nontemporal_store(v, (g_f32x4*)p); }
+#else
+__device__ __forceinline__ void st4_stream(float* p, f32x4 v) { *(g_f32x4*)p = v; }
 #endif
 __device__ __forceinline__ float ld1(const float* p) { return *(g_cfloat*)p; }
 __device__ __forceinline__ void st1(float* p, float v) { *(g_float*)p = v; }
