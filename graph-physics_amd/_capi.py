@@ -144,6 +144,9 @@ SYMBOLS = {
     "mgn_last_error": (C.c_char_p, []),
     "mgn_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "mgn_csr_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_topology_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "mgn_topology_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 6 + [C.POINTER(C.c_int32), C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
     "mgn_segsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "mgn_seg_fix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mgn_segsum2": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_void_p]),

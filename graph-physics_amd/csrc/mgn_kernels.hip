@@ -2022,22 +2022,16 @@ int mgn_version(void) { return 120; }
 const char* mgn_last_error(void) { return g_err; }
 
 size_t mgn_csr_workspace_bytes(int64_t E, int64_t N) {
-  // cnt/cursor[N] + err + nbig (16 ints) | worklist[N] | tmp[E]
+  // cnt/cursor[N] + nbig (16 ints) | worklist[N] | tmp[E] | 16 spare ints (error flag of mgn_csr_build)
   return (size_t)(2 * N + E + 32) * sizeof(int);
 }
 
-int mgn_csr_build(const int64_t* key, int64_t E, int64_t N, int32_t* rowptr, int32_t* perm, void* ws,
-                  size_t ws_bytes, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  if (N < 0 || E < 0 || E > 2147483647LL || N > 2147483646LL) return fail(1, "mgn_csr_build: size out of int32 range");
-  if (ws_bytes < mgn_csr_workspace_bytes(E, N)) return fail(1, "mgn_csr_build: workspace too small");
+// the launches of one CSR build, no synchronisation; *err_dev is set to 1 on a key outside [0, N)
+static int csr_enqueue(const int64_t* key, int64_t E, int64_t N, int32_t* rowptr, int32_t* perm, void* ws, int* err_dev, hipStream_t s) {
   int* cnt = (int*)ws;
-  int* err = cnt + N;
   if (hipMemsetAsync(ws, 0, (size_t)(N + 16) * sizeof(int), s) != hipSuccess) return fail(2, "mgn_csr_build: memset");
-  if (E > 0) hipLaunchKernelGGL(k_csr_hist, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, key, (long)E, (long)N, cnt, err);
+  if (E > 0) hipLaunchKernelGGL(k_csr_hist, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, key, (long)E, (long)N, cnt, err_dev);
   hipLaunchKernelGGL(k_csr_scan, dim3(1), dim3(1024), 0, s, cnt, (long)N, rowptr);
-  int herr = 0;
-  if (hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return fail(2, "mgn_csr_build: memcpy");
   if (hipMemsetAsync(ws, 0, (size_t)N * sizeof(int), s) != hipSuccess) return fail(2, "mgn_csr_build: memset");
   if (E > 0) {
     hipLaunchKernelGGL(k_csr_fill, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, key, (long)E, (long)N, rowptr, cnt, perm);
@@ -2049,9 +2043,86 @@ int mgn_csr_build(const int64_t* key, int64_t E, int64_t N, int32_t* rowptr, int
       hipLaunchKernelGGL(k_csr_sortbig, dim3(512), dim3(256), 0, s, rowptr, perm, worklist, nbig, tmp);
     }
   }
-  if (int rc = check_launch("mgn_csr_build")) return rc;
+  return check_launch("mgn_csr_build");
+}
+
+int mgn_csr_build(const int64_t* key, int64_t E, int64_t N, int32_t* rowptr, int32_t* perm, void* ws,
+                  size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (N < 0 || E < 0 || E > 2147483647LL || N > 2147483646LL) return fail(1, "mgn_csr_build: size out of int32 range");
+  if (ws_bytes < mgn_csr_workspace_bytes(E, N)) return fail(1, "mgn_csr_build: workspace too small");
+  int* err = (int*)ws + 2 * N + E + 24;  // a word of the workspace tail the launches do not use
+  if (hipMemsetAsync(err, 0, sizeof(int), s) != hipSuccess) return fail(2, "mgn_csr_build: memset");
+  if (int rc = csr_enqueue(key, E, N, rowptr, perm, ws, err, s)) return rc;
+  int herr = 0;
+  if (hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return fail(2, "mgn_csr_build: memcpy");
   if (hipStreamSynchronize(s) != hipSuccess) return fail(2, "mgn_csr_build: sync failed");
   if (herr) return fail(3, "mgn_csr_build: edge index outside [0, N)");
+  return 0;
+}
+
+// src_s / dst_s (int32, dst-sorted order) and the int64 keys of the second CSR
+__global__ void k_topo_gather(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int32_t* __restrict__ perm, long E,
+                              int32_t* __restrict__ src_s, int32_t* __restrict__ dst_s, int64_t* __restrict__ key2) {
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E) return;
+  int e = perm[k];
+  if (e < 0 || e >= E) e = 0;  // rows past the valid count when an index is out of range (reported after the sync): any readable edge
+  const int64_t a = src[e];
+  src_s[k] = (int32_t)a;
+  dst_s[k] = (int32_t)dst[e];
+  key2[k] = a;
+}
+// out[0] = max in-degree, out[1] = max out-degree (one atomicMax per wave)
+__global__ void k_topo_maxdeg(const int32_t* __restrict__ rp0, const int32_t* __restrict__ rp1, long N, int* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int d0 = 0, d1 = 0;
+  if (i < N) {
+    d0 = rp0[i + 1] - rp0[i];
+    d1 = rp1[i + 1] - rp1[i];
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    d0 = max(d0, __shfl_xor(d0, m));
+    d1 = max(d1, __shfl_xor(d1, m));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&out[0], d0);  // integer maxima: order-independent
+    atomicMax(&out[1], d1);
+  }
+}
+
+size_t mgn_topology_workspace_bytes(int64_t E, int64_t N) {
+  return 2 * mgn_csr_workspace_bytes(E, N) + (size_t)E * sizeof(int64_t) + 256;
+}
+
+int mgn_topology_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* perm_dst,
+                       int32_t* src_s, int32_t* dst_s, int32_t* rowptr_src, int32_t* perm_src, int32_t* max_degree_host,
+                       void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (N < 0 || E < 0 || E > 2147483647LL || N > 2147483646LL) return fail(1, "mgn_topology_build: size out of int32 range");
+  if (ws_bytes < mgn_topology_workspace_bytes(E, N)) return fail(1, "mgn_topology_build: workspace too small");
+  const size_t csr_b = (mgn_csr_workspace_bytes(E, N) + 63) & ~(size_t)63;
+  char* w = (char*)ws;
+  int64_t* key2 = (int64_t*)(w + 2 * csr_b);
+  int* flags = (int*)(w + 2 * csr_b + (size_t)E * sizeof(int64_t));  // [0] err, [1] max in-degree, [2] max out-degree
+  if (hipMemsetAsync(flags, 0, 4 * sizeof(int), s) != hipSuccess) return fail(2, "mgn_topology_build: memset");
+  if (int rc = csr_enqueue(dst, E, N, rowptr_dst, perm_dst, w, flags, s)) return rc;
+  if (E > 0) {
+    hipLaunchKernelGGL(k_csr_hist, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, src, (long)E, (long)N, (int*)(w + csr_b), flags);  // range check of src
+    hipLaunchKernelGGL(k_topo_gather, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, src, dst, perm_dst, (long)E, src_s, dst_s, key2);
+  }
+  if (int rc = csr_enqueue(key2, E, N, rowptr_src, perm_src, w + csr_b, flags, s)) return rc;
+  if (N > 0) hipLaunchKernelGGL(k_topo_maxdeg, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rowptr_dst, rowptr_src, (long)N, flags + 1);
+  if (int rc = check_launch("mgn_topology_build")) return rc;
+  int h[3] = {0, 0, 0};
+  if (hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess) return fail(2, "mgn_topology_build: memcpy");
+  if (hipStreamSynchronize(s) != hipSuccess) return fail(2, "mgn_topology_build: sync failed");
+  if (h[0]) return fail(3, "mgn_topology_build: edge index outside [0, N)");
+  if (max_degree_host != nullptr) {
+    max_degree_host[0] = h[1];
+    max_degree_host[1] = h[2];
+  }
   return 0;
 }
 

@@ -82,24 +82,30 @@ class Topology:
         ei = edge_index.to(torch.int64).contiguous()
         E, N = int(ei.shape[1]), int(num_nodes)
         self.N, self.E, self.device = N, E, dev
-        self.rowptr_dst, self.perm_dst = csr_build(ei[1], N)
-        p = self.perm_dst.long()
-        self.src_s = ei[0][p].to(torch.int32).contiguous()
-        self.dst_s = ei[1][p].to(torch.int32).contiguous()
-        self.rowptr_src, self.perm_src = csr_build(self.src_s.long(), N)
+        # one engine call, one stream synchronisation (mgn_topology_build): both CSRs, the sorted index rows and
+        # the degree maxima
+        L = _capi.lib()
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.rowptr_dst, self.rowptr_src = torch.empty(N + 1, **i32), torch.empty(N + 1, **i32)
+        self.perm_dst, self.perm_src = torch.empty(E, **i32), torch.empty(E, **i32)
+        self.src_s, self.dst_s = torch.empty(E, **i32), torch.empty(E, **i32)
+        ws = torch.empty(max(L.mgn_topology_workspace_bytes(E, N), 16), dtype=torch.uint8, device=dev)
+        mx = (C.c_int32 * 2)()
+        with torch.cuda.device(dev):
+            rc = L.mgn_topology_build(ei[0].data_ptr(), ei[1].data_ptr(), E, N, _ptr(self.rowptr_dst), _ptr(self.perm_dst), _ptr(self.src_s),
+                                      _ptr(self.dst_s), _ptr(self.rowptr_src), _ptr(self.perm_src), mx, _ptr(ws), ws.numel(), _stream(dev))
+        if rc == 3:
+            raise IndexError(f"edge_index has entries outside [0, {N})")
+        _capi.check(rc, "mgn_topology_build")
+        self.max_in_degree, self.max_out_degree = int(mx[0]), int(mx[1])
         self._inv = None
         # Hub nodes.  A segment is summed by ONE lane group walking it in order -- ideal for meshes (degree
         # ~6), unbounded for the arbitrary edge_index the input contract allows (a node with 100 000 in-edges
         # would serialise 100 000 row loads).  Segments longer than HUB_CHUNK are therefore cut into chunks
         # summed in parallel, and a second small segment sum adds the chunk rows of each node (fixed order:
-        # still deterministic, no atomics).  The degree maxima cost one host read at topology build.
-        self.hub_dst = self.hub_src = None
-        if E > 0:
-            mx = torch.stack([(self.rowptr_dst[1:] - self.rowptr_dst[:-1]).max(), (self.rowptr_src[1:] - self.rowptr_src[:-1]).max()]).tolist()
-            if mx[0] > HUB_CHUNK:
-                self.hub_dst = _chunk_csr(self.rowptr_dst)
-            if mx[1] > HUB_CHUNK:
-                self.hub_src = _chunk_csr(self.rowptr_src)
+        # still deterministic, no atomics).  The degree maxima come back with the topology build's one host read.
+        self.hub_dst = _chunk_csr(self.rowptr_dst) if self.max_in_degree > HUB_CHUNK else None
+        self.hub_src = _chunk_csr(self.rowptr_src) if self.max_out_degree > HUB_CHUNK else None
 
     @property
     def has_hubs(self) -> bool:

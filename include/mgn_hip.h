@@ -56,6 +56,16 @@ size_t mgn_csr_workspace_bytes(int64_t E, int64_t N);
 int mgn_csr_build(const int64_t* key, int64_t E, int64_t N, int32_t* rowptr, int32_t* perm,
                   void* ws, size_t ws_bytes, void* stream);
 
+/* The whole topology of an edge_index in ONE call and ONE stream synchronisation: CSR by destination
+ * (rowptr_dst / perm_dst as mgn_csr_build), the source / destination index of every dst-sorted edge row
+ * (src_s / dst_s, int32), the CSR of those rows grouped by source (rowptr_src / perm_src), and on the host
+ * the maximum in- and out-degree (max_degree_host[2], may be NULL) -- what the engine needs per mesh (a
+ * new one every step under a shuffled loader).  Returns 3 on an index outside [0,N). */
+size_t mgn_topology_workspace_bytes(int64_t E, int64_t N);
+int mgn_topology_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* perm_dst,
+                       int32_t* src_s, int32_t* dst_s, int32_t* rowptr_src, int32_t* perm_src, int32_t* max_degree_host,
+                       void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------- segment sum
  * out[i,:] = sum_{k=rowptr[i]}^{rowptr[i+1]-1} src[perm ? perm[k] : k, :]
  * summed sequentially in k order (deterministic, atomics-free).  H in {16,32,64,128}. */

@@ -785,3 +785,23 @@ def test_add_world_edges_vs_oracle(dev):
     assert np.array_equal(got2.cpu().numpy(), want)
     with pytest.raises(RuntimeError):
         P.add_world_edges(torch.from_numpy(x).to(dev), torch.from_numpy(ei).to(dev), 0, 3, 3, radius=0.1, max_world_pairs=10)
+
+
+def test_topology_build_single_call_bit_exact(dev):
+    """mgn_topology_build (both CSRs, the sorted index rows, the degree maxima: one call, one
+    synchronisation) against the integer oracle on a multigraph, a mesh, an empty edge list; a bad source
+    or destination raises IndexError like the CSR build."""
+    for n, ei in ((300, R.random_graph(300, 5000, 3)), (1885, gp.cylinder_mesh(1885, 0).edge_index),
+                  (7, torch.zeros(2, 0, dtype=torch.int64))):
+        t = ops.Topology(ei.to(dev), n)
+        rp, pm = O.csr_by_key(ei[1], n)
+        assert torch.equal(t.rowptr_dst.cpu(), rp) and torch.equal(t.perm_dst.cpu(), pm)
+        assert torch.equal(t.src_s.cpu().long(), ei[0][pm.long()]) and torch.equal(t.dst_s.cpu().long(), ei[1][pm.long()])
+        rp2, pm2 = O.csr_by_key(ei[0][pm.long()], n)
+        assert torch.equal(t.rowptr_src.cpu(), rp2) and torch.equal(t.perm_src.cpu(), pm2)
+        if ei.shape[1]:
+            assert t.max_in_degree == int(torch.bincount(ei[1], minlength=n).max())
+            assert t.max_out_degree == int(torch.bincount(ei[0], minlength=n).max())
+    for bad in (torch.tensor([[0, 9], [1, 2]]), torch.tensor([[0, 1], [1, -1]])):
+        with pytest.raises(IndexError):
+            ops.Topology(bad.to(dev), 5)
