@@ -504,6 +504,16 @@ DEFAULT_SPEC = BlockSpec()
 PARAMS_PER_BLOCK = DEFAULT_SPEC.per_block  # 18: edge W0,b0..W3,b3,scale ; node W0,b0..W3,b3,scale
 
 
+_side_streams: dict = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    key = (dev.type, dev.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
+
+
 def processor_apply(x, e, topo, L, *params, spec: BlockSpec = DEFAULT_SPEC, halo=None, pos=None, phi=None, rope_inv_freq=None):
     """ProcessorFunction.apply with the caller's grad mode recorded."""
     _call.grad = torch.is_grad_enabled()
@@ -955,6 +965,16 @@ class ProcessorFunction(torch.autograd.Function):
         dZn = [mk(Nn, H, **f) for _ in range(NL)]
         dZe = [mk(E, H, **f) for _ in range(NL)]
         dAgg, Sd, Ss = mk(Nn, H, **f), mk(N, H, **f), mk(N, H, **f)
+        # Weight gradients on a SIDE STREAM (MGN_WGRAD_STREAM=1): dW of round i depends on nothing the rest of
+        # the backward pass waits for, so its launch can fill the bubbles of the main stream (launch gaps, the
+        # tail of the persistent chain kernels, the one-tile node launches).  Its operands (dZ, Sd, Ss) are then
+        # double-buffered across rounds and the streams are joined by events.
+        side = None
+        if _os.environ.get("MGN_WGRAD_STREAM") is not None and halo is None and not empty and not spec.gate:
+            side = _side_stream(dev)
+            wsets = [(dZn, dZe, Sd, Ss), ([mk(Nn, H, **f) for _ in range(NL)], [mk(E, H, **f) for _ in range(NL)], mk(N, H, **f), mk(N, H, **f))]
+            wdone = [None, None]
+            main = torch.cuda.current_stream(dev)
         dx_buf, de_buf = [mk(Nn, H, **f), mk(Nn, H, **f)], [mk(E, H, **f), mk(E, H, **f)]
         grads: List[Optional[torch.Tensor]] = [None] * (PB * L)
         nb = H // 16
@@ -1037,6 +1057,10 @@ class ProcessorFunction(torch.autograd.Function):
             gse = g[2 * NL] if spec.layer_norm else None
             gsn = g[k_ + 2 * NL] if spec.layer_norm else None
             dZn = dZn_sets[i & 1]
+            if side is not None:
+                dZn, dZe, Sd, Ss = wsets[i & 1]
+                if wdone[i & 1] is not None:  # the weight gradients of round i + 2 still read this set
+                    main.wait_event(wdone[i & 1])
             if x6:
                 # never dereferenced on the packed path
                 WTn = WTe = [None] * NL
@@ -1132,7 +1156,17 @@ class ProcessorFunction(torch.autograd.Function):
                 # scattered slabs, then the deeper layers alternating node / edge (same plan as round 1)
                 n_sc = 1 if spec.rope else 2
                 deep = [j for pair in zip(njobs[2 + n_sc:2 + n_sc + NL - 1], ejobs[len(ejobs) - (NL - 1):]) for j in pair]
-                wgrad(njobs[:2] + ejobs[:len(ejobs) - (NL - 1)] + njobs[2:2 + n_sc] + deep + (njobs[-1:] if spec.gate else []), dev, prec)
+                alljobs = njobs[:2] + ejobs[:len(ejobs) - (NL - 1)] + njobs[2:2 + n_sc] + deep + (njobs[-1:] if spec.gate else [])
+                if side is not None:
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        wgrad(alljobs, dev, prec)
+                        wdone[i & 1] = torch.cuda.Event()
+                        wdone[i & 1].record(side)
+                else:
+                    wgrad(alljobs, dev, prec)
             if spec.gate:
                 if phi is not None:  # d gate_pos = sum_n phi[n] * dG[n, :]  (a [H, 1] weight-gradient job)
                     tmp = torch.empty(H, 16, **f)
@@ -1167,6 +1201,10 @@ class ProcessorFunction(torch.autograd.Function):
                 dx_new = dx
             grads[PB * i: PB * (i + 1)] = g
             dx, de = dx_new, de_new
+        if side is not None:
+            for ev in wdone:
+                if ev is not None:
+                    main.wait_event(ev)
         colred_batch(deferred, dev)
         ctx.saved_acts = None
         return (dx, de, None, None, None, None, None, None, None, *grads)
