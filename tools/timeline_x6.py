@@ -4,9 +4,7 @@ edge-forward kernel (needs tools/libexp_TLX.so = the engine built with -DMGN_TIM
 import ctypes as C, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
-lib_path = os.path.join(R, "graph-physics_amd", "csrc", "libmgn_hip.so")
-shutil.copy(lib_path, "/tmp/libmgn_orig.so")
-shutil.copy(os.path.join(R, "tools", "libexp_TLX.so"), lib_path)
+os.environ["MGN_LIB"] = os.path.join(R, "tools", "libexp_TLX.so")  # build: hipcc ... -DMGN_TIMELINE -o tools/libexp_TLX.so csrc/*.hip
 try:
     import torch, graph_physics_amd as gp
     from graph_physics_amd import ops, _capi
@@ -26,6 +24,8 @@ try:
     node = len(sys.argv) > 1 and sys.argv[1] == "node"
     He = [torch.empty(E, H, **f) for _ in range(3)] if save else None
     Ue, Re = (torch.empty(E, H, **f), torch.empty(E, **f)) if save else (None, None)
+    Me = [torch.empty(E, 4, dtype=torch.int32, device=dev) for _ in range(3)] if save else None
+    agg, part = torch.empty(N, H, **f), torch.empty((E + 15) // 16, 2, H, **f)   # production shape: aggregation fused, no message store
     pk = torch.empty(4 * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
     units = [pk.data_ptr() + u * _capi.WPACK_BYTES for u in range(4)]
     ops.wpack([(W0.data_ptr(), 3 * H, False, units[0])] + [(Wh[l].data_ptr(), H, False, units[l + 1]) for l in range(3)], dev)
@@ -48,8 +48,8 @@ try:
             ops.mlp_fwd(N, H, [(x, None, H), (agg, None, H)], [Wn0] + Wh, bs, sc, H, x, x_new, None, Hn, Un, Rn,
                         posts=[(W0.data_ptr() + 4 * H, Pdn), (W0.data_ptr() + 8 * H, Psn)], post_ldw=3 * H, wpk=un)
         else:
-            ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, m, He, Ue, Re, ldw0=3 * H,
-                        adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units)
+            ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, None, He, Ue, Re, ldw0=3 * H,
+                        adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units, saveM=Me, seg=(topo.dst_s, topo.rowptr_dst, agg, part))
         torch.cuda.synchronize()
         L.mgn_debug_timeline(buf, pos)
     names = {1: "T", 3: "pre", 4: "bar", 5: "gemm", 6: "drain", 7: "epi", 8: "end"}
@@ -72,4 +72,4 @@ try:
                 print("  " + " ".join(line)); line = []
         print("  totals:", tot, "span", ev[n - 1][0] - ev[0][0])
 finally:
-    shutil.copy("/tmp/libmgn_orig.so", lib_path)
+    pass
