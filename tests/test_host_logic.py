@@ -155,3 +155,13 @@ def test_mesh_contract():
     assert g.edge_attr.shape == (ei.shape[1], 3) and g.x.shape == (300, 4)
     b = gp.collate([g, gp.cylinder_mesh(200, seed=4)])
     assert b.x.shape[0] == 500 and int(b.edge_index.max()) < 500 and int(b.edge_index[:, ei.shape[1]:].min()) >= 300
+
+
+def test_bench_refuses_a_gpus_flag_that_contradicts_the_launch():
+    """`--gpus N` must equal WORLD_SIZE under an external launcher (never silently ignored); checked before
+    anything touches a GPU."""
+    import os, subprocess, sys
+    from conftest import REPO as REPO_ROOT
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO_ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
