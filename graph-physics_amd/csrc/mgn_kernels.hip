@@ -644,9 +644,16 @@ __global__ void __launch_bounds__(1024) k_colred_batch(const ColredBatch B) {
 // (no VMEM traffic, position counter in a register) and dumped when the kernel ends
 __device__ unsigned long long g_timeline[8][512];
 __device__ int g_tlpos[8];
+// placement census: per workgroup {HW_ID, XCC_ID, first stamp, last stamp} (which workgroups share a CU / SIMD)
+__device__ unsigned long long g_census[1024][4];
 #define TL_DECL()                                                                            \
   __shared__ unsigned long long tl_buf_[512];                                                \
   int tl_n_ = 0;                                                                             \
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {                                               \
+    g_census[blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                     \
+    g_census[blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                    \
+    g_census[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();                              \
+  }                                                                                          \
   const int tl_slot_ = (blockIdx.x < 4) ? (int)blockIdx.x                                    \
                        : ((blockIdx.x + 4 >= gridDim.x) ? (int)(blockIdx.x + 8 - gridDim.x) : -1)
 #define TL_STAMP(tag)                                                                        \
@@ -656,11 +663,15 @@ __device__ int g_tlpos[8];
   } while (0)
 #define TL_DUMP()                                                                            \
   do {                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_census[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime(); \
     if (threadIdx.x == 0 && tl_slot_ >= 0) {                                                 \
       for (int i_ = 0; i_ < tl_n_; ++i_) g_timeline[tl_slot_][i_] = tl_buf_[i_];            \
       g_tlpos[tl_slot_] = tl_n_;                                                             \
     }                                                                                        \
   } while (0)
+extern "C" int mgn_debug_census(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_census), sizeof(unsigned long long) * 1024 * 4) != hipSuccess;
+}
 extern "C" int mgn_debug_timeline(unsigned long long* out, int* pos) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 8 * 512) != hipSuccess) return 1;
   if (hipMemcpyFromSymbol(pos, HIP_SYMBOL(g_tlpos), sizeof(int) * 8) != hipSuccess) return 1;
@@ -1858,9 +1869,23 @@ static bool fwd_x6(const mgn_mlp_fwd_args& a) {
     if (a.wpk[u] == nullptr) return false;
   return true;
 }
-template <int TERMS, int NW, int ACT>
+template <int TERMS, int NW, int ACT, class SH = ShDyn>
 static int set_fwd_x6_attr() {
-  return hipFuncSetAttribute((const void*)k_mlp_fwd_x6<TERMS, NW, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(NW)) != hipSuccess;
+  return hipFuncSetAttribute((const void*)k_mlp_fwd_x6<TERMS, NW, ACT, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_FWD_LDS_BYTES(NW)) != hipSuccess;
+}
+// The static-shape instantiations (mgn_x6.inc: unrolled unit loop, untracked operand loads) take a launch only
+// when it matches their shape field by field; MGN_X6_STATIC=0 keeps every launch on the dynamic kernel (A/B).
+static int fwd_static_shape(const mgn_mlp_fwd_args& a) {
+  static const bool off = [] { const char* e = getenv("MGN_X6_STATIC"); return e != nullptr && atoi(e) == 0; }();
+  if (off || a.act != MGN_ACT_RELU || a.precision != 0 || a.NL != 4 || a.resid == nullptr || a.scale == nullptr) return 0;
+  if (a.nphase == 1 && a.n_add == 2 && a.n_post == 0 && a.idx[0] == nullptr && a.add_idx[0] != nullptr && a.add_idx[1] != nullptr &&
+      a.seg_out != nullptr && a.seg_key == a.add_idx[0])
+    return 1;  // ShEdge
+  if (a.nphase == 2 && a.n_add == 0 && a.idx[0] == nullptr && a.idx[1] == nullptr && a.seg_out == nullptr) {
+    if (a.n_post == 2) return 2;  // ShNode<2>
+    if (a.n_post == 0) return 3;  // ShNode<0>
+  }
+  return 0;
 }
 
 template <int HB>
@@ -1877,7 +1902,8 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
     static thread_local bool attr_done = false;
     if (!attr_done) {
       if (set_fwd_x6_attr<6, 4, 0>() || set_fwd_x6_attr<1, 4, 0>() || set_fwd_x6_attr<6, 8, 0>() || set_fwd_x6_attr<1, 8, 0>() ||
-          set_fwd_x6_attr<6, 4, 1>() || set_fwd_x6_attr<1, 4, 1>())
+          set_fwd_x6_attr<6, 4, 1>() || set_fwd_x6_attr<1, 4, 1>() || set_fwd_x6_attr<6, 4, 0, ShEdge>() ||
+          set_fwd_x6_attr<6, 4, 0, ShNode<2>>() || set_fwd_x6_attr<6, 4, 0, ShNode<0>>())
         return 1;
       attr_done = true;
     }
@@ -1888,7 +1914,14 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
     if (const char* e = getenv("MGN_GRID")) {  // occupancy experiments: fewer persistent workgroups
       if (atoi(e) > 0 && (unsigned)atoi(e) < grid) grid = (unsigned)atoi(e);
     }
-    if (silu) {
+    const int shape = (nw == 4 && !silu) ? fwd_static_shape(a) : 0;
+    if (shape == 1) {
+      hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShEdge>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+    } else if (shape == 2) {
+      hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShNode<2>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+    } else if (shape == 3) {
+      hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShNode<0>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+    } else if (silu) {
       if (a.precision == 1)
         hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 1>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
       else
@@ -1964,7 +1997,8 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
           hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
           hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
           hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 0, false, SbEdge>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return 1;
       attr_done = true;
     }
@@ -1972,7 +2006,14 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
     for (int l = 0; l < a.NL; ++l) nused += (a.db[l] != nullptr) ? 1 : 0;
     const size_t lds = X6_BWD_LDS_BYTES(nused);
     const bool front = a.n_front > 0;
-    if (a.seg_out != nullptr) {
+    static const bool static_off = [] { const char* e = getenv("MGN_X6_STATIC"); return e != nullptr && atoi(e) == 0; }();
+    // static-shape instantiation (mgn_x6.inc, SbEdge): the edge chain of a round, matched field by field
+    const bool sb_edge = !static_off && !front && a.seg_out == nullptr && a.act == MGN_ACT_RELU && a.precision == 0 && a.NL == 4 &&
+                         a.n_din == 1 && a.din_resid[0] != nullptr && a.scale != nullptr && a.R != nullptr && a.U != nullptr &&
+                         a.dOut2 != nullptr && a.idx2 != nullptr;
+    if (sb_edge) {
+      hipLaunchKernelGGL((k_mlp_bwd_x6<6, false, 0, false, SbEdge>), dim3(p.grid), dim3(256), lds, s, a);
+    } else if (a.seg_out != nullptr) {
       hipLaunchKernelGGL((k_mlp_bwd_x6<6, false, 0, true>), dim3(p.grid), dim3(256), lds, s, a);
     } else if (a.act == MGN_ACT_SILU) {
       if (a.precision == 1)
@@ -2018,7 +2059,7 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
 
 extern "C" {
 
-int mgn_version(void) { return 120; }
+int mgn_version(void) { return 121; }
 const char* mgn_last_error(void) { return g_err; }
 
 size_t mgn_csr_workspace_bytes(int64_t E, int64_t N) {

@@ -52,6 +52,29 @@ try:
                         adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units, saveM=Me, seg=(topo.dst_s, topo.rowptr_dst, agg, part))
         torch.cuda.synchronize()
         L.mgn_debug_timeline(buf, pos)
+    if hasattr(L, "mgn_debug_census"):
+        cen = (C.c_ulonglong * (1024 * 4))()
+        L.mgn_debug_census(cen)
+        nwg = 512
+        t0 = min(cen[4 * b + 2] for b in range(nwg))
+        place = {}
+        for b in range(nwg):
+            hw, xcc = cen[4 * b], cen[4 * b + 1] & 15
+            key = (xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15)   # XCC, SE, SH, CU
+            place.setdefault(key, []).append((b, (hw >> 4) & 3, cen[4 * b + 2] - t0, cen[4 * b + 3] - t0))
+        print("placement census: %d distinct CUs hold the %d workgroups" % (len(place), nwg))
+        import collections
+        print("  workgroups per CU:", dict(collections.Counter(len(v) for v in place.values())))
+        diffs = collections.Counter()
+        for key, v in sorted(place.items())[:12]:
+            print("  CU", key, "-> (wg, simd of wave 0, start, end):", v)
+        for v in place.values():
+            if len(v) == 2:
+                diffs[abs(v[0][0] - v[1][0])] += 1
+        print("  blockIdx distance of co-resident pairs:", dict(diffs.most_common(8)))
+        sd = [abs(v[0][2] - v[1][2]) for v in place.values() if len(v) == 2]
+        if sd:
+            sd.sort(); print("  start-time distance of pairs (10 ns ticks): median %d, p10 %d, p90 %d" % (sd[len(sd) // 2], sd[len(sd) // 10], sd[9 * len(sd) // 10]))
     names = {1: "T", 3: "pre", 4: "bar", 5: "gemm", 6: "drain", 7: "epi", 8: "end"}
     firsts = [(buf[b * 512] >> 8) for b in range(8)]
     lasts = [(buf[b * 512 + max(pos[b] - 1, 0)] >> 8) for b in range(8)]
