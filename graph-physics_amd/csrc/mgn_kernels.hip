@@ -1877,7 +1877,7 @@ static int set_fwd_x6_attr() {
 // when it matches their shape field by field; MGN_X6_STATIC=0 keeps every launch on the dynamic kernel (A/B).
 static int fwd_static_shape(const mgn_mlp_fwd_args& a) {
   static const bool off = [] { const char* e = getenv("MGN_X6_STATIC"); return e != nullptr && atoi(e) == 0; }();
-  if (off || a.act != MGN_ACT_RELU || a.precision != 0 || a.NL != 4 || a.resid == nullptr || a.scale == nullptr) return 0;
+  if (off || a.act != MGN_ACT_RELU || a.NL != 4 || a.resid == nullptr || a.scale == nullptr) return 0;
   if (a.nphase == 1 && a.n_add == 2 && a.n_post == 0 && a.idx[0] == nullptr && a.add_idx[0] != nullptr && a.add_idx[1] != nullptr &&
       a.seg_out != nullptr && a.seg_key == a.add_idx[0])
     return 1;  // ShEdge
@@ -1903,7 +1903,8 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
     if (!attr_done) {
       if (set_fwd_x6_attr<6, 4, 0>() || set_fwd_x6_attr<1, 4, 0>() || set_fwd_x6_attr<6, 8, 0>() || set_fwd_x6_attr<1, 8, 0>() ||
           set_fwd_x6_attr<6, 4, 1>() || set_fwd_x6_attr<1, 4, 1>() || set_fwd_x6_attr<6, 4, 0, ShEdge>() ||
-          set_fwd_x6_attr<6, 4, 0, ShNode<2>>() || set_fwd_x6_attr<6, 4, 0, ShNode<0>>())
+          set_fwd_x6_attr<6, 4, 0, ShNode<2>>() || set_fwd_x6_attr<6, 4, 0, ShNode<0>>() || set_fwd_x6_attr<1, 4, 0, ShEdge>() ||
+          set_fwd_x6_attr<1, 4, 0, ShNode<2>>() || set_fwd_x6_attr<1, 4, 0, ShNode<0>>())
         return 1;
       attr_done = true;
     }
@@ -1916,11 +1917,20 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
     }
     const int shape = (nw == 4 && !silu) ? fwd_static_shape(a) : 0;
     if (shape == 1) {
-      hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShEdge>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+      if (a.precision == 1)
+        hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 0, ShEdge>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+      else
+        hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShEdge>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
     } else if (shape == 2) {
-      hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShNode<2>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+      if (a.precision == 1)
+        hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 0, ShNode<2>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+      else
+        hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShNode<2>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
     } else if (shape == 3) {
-      hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShNode<0>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+      if (a.precision == 1)
+        hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 0, ShNode<0>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
+      else
+        hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShNode<0>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
     } else if (silu) {
       if (a.precision == 1)
         hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 1>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
@@ -1998,7 +2008,8 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
           hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
           hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
           hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 0, false, SbEdge>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<6, false, 0, false, SbEdge>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_mlp_bwd_x6<1, false, 0, false, SbEdge>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return 1;
       attr_done = true;
     }
@@ -2008,11 +2019,14 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
     const bool front = a.n_front > 0;
     static const bool static_off = [] { const char* e = getenv("MGN_X6_STATIC"); return e != nullptr && atoi(e) == 0; }();
     // static-shape instantiation (mgn_x6.inc, SbEdge): the edge chain of a round, matched field by field
-    const bool sb_edge = !static_off && !front && a.seg_out == nullptr && a.act == MGN_ACT_RELU && a.precision == 0 && a.NL == 4 &&
+    const bool sb_edge = !static_off && !front && a.seg_out == nullptr && a.act == MGN_ACT_RELU && a.NL == 4 &&
                          a.n_din == 1 && a.din_resid[0] != nullptr && a.scale != nullptr && a.R != nullptr && a.U != nullptr &&
                          a.dOut2 != nullptr && a.idx2 != nullptr;
     if (sb_edge) {
-      hipLaunchKernelGGL((k_mlp_bwd_x6<6, false, 0, false, SbEdge>), dim3(p.grid), dim3(256), lds, s, a);
+      if (a.precision == 1)
+        hipLaunchKernelGGL((k_mlp_bwd_x6<1, false, 0, false, SbEdge>), dim3(p.grid), dim3(256), lds, s, a);
+      else
+        hipLaunchKernelGGL((k_mlp_bwd_x6<6, false, 0, false, SbEdge>), dim3(p.grid), dim3(256), lds, s, a);
     } else if (a.seg_out != nullptr) {
       hipLaunchKernelGGL((k_mlp_bwd_x6<6, false, 0, true>), dim3(p.grid), dim3(256), lds, s, a);
     } else if (a.act == MGN_ACT_SILU) {
@@ -2059,7 +2073,7 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
 
 extern "C" {
 
-int mgn_version(void) { return 121; }
+int mgn_version(void) { return 122; }
 const char* mgn_last_error(void) { return g_err; }
 
 size_t mgn_csr_workspace_bytes(int64_t E, int64_t N) {

@@ -7,7 +7,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fd, wd, tag = sys.argv[1:4]
-KEYS = {("k_mlp_fwd_x6<6, 4, 0>", 512): "edge_fwd", ("k_mlp_bwd_x6<6, false, 0", 512): "edge_bwd", ("k_wgrad_x6", 512): "wgrad",
+KEYS = {("k_mlp_fwd_x6<6, 4, 0", 512): "edge_fwd", ("k_mlp_bwd_x6<6, false, 0", 512): "edge_bwd", ("k_wgrad_x6", 512): "wgrad",
         ("k_segsum2<8>", None): "segsum", ("__amd_rocclr_copyBuffer", None): "calibration_copy"}
 def collect(d, counter):
     acc = defaultdict(list)
