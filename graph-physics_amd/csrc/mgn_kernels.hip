@@ -1876,7 +1876,8 @@ static int set_fwd_x6_attr() {
 // The static-shape instantiations (mgn_x6.inc: unrolled unit loop, untracked operand loads) take a launch only
 // when it matches their shape field by field; MGN_X6_STATIC=0 keeps every launch on the dynamic kernel (A/B).
 static int fwd_static_shape(const mgn_mlp_fwd_args& a) {
-  static const int mode = [] { const char* e = getenv("MGN_X6_STATIC"); return e != nullptr ? atoi(e) : 1; }();  // 0 none, 2 edge only
+  const char* env = getenv("MGN_X6_STATIC");  // read per launch: the cross-check test flips it inside one process
+  const int mode = env != nullptr ? atoi(env) : 1;  // 0 none, 2 edge only
   if (mode == 0 || a.act != MGN_ACT_RELU || a.NL != 4 || a.resid == nullptr || a.scale == nullptr) return 0;
   if (a.nphase == 1 && a.n_add == 2 && a.n_post == 0 && a.idx[0] == nullptr && a.add_idx[0] != nullptr && a.add_idx[1] != nullptr &&
       a.seg_out != nullptr && a.seg_key == a.add_idx[0])
@@ -2019,7 +2020,8 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
     for (int l = 0; l < a.NL; ++l) nused += (a.db[l] != nullptr) ? 1 : 0;
     const size_t lds = X6_BWD_LDS_BYTES(nused);
     const bool front = a.n_front > 0;
-    static const bool static_off = [] { const char* e = getenv("MGN_X6_STATIC"); return e != nullptr && atoi(e) == 0; }();
+    const char* st_env = getenv("MGN_X6_STATIC");
+    const bool static_off = st_env != nullptr && atoi(st_env) == 0;
     // static-shape instantiation (mgn_x6.inc, SbEdge): the edge chain of a round, matched field by field
     const bool sb_edge = !static_off && !front && a.seg_out == nullptr && a.act == MGN_ACT_RELU && a.NL == 4 &&
                          a.n_din == 1 && a.din_resid[0] != nullptr && a.scale != nullptr && a.R != nullptr && a.U != nullptr &&

@@ -805,3 +805,68 @@ def test_topology_build_single_call_bit_exact(dev):
     for bad in (torch.tensor([[0, 9], [1, 2]]), torch.tensor([[0, 1], [1, -1]])):
         with pytest.raises(IndexError):
             ops.Topology(bad.to(dev), 5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_static_shape_kernels_equal_the_dynamic_kernels_bit_for_bit(dev, prec):
+    """csrc/mgn_x6.inc: the static-shape instantiations (unrolled unit loop, untracked operand loads ordered by the
+    DMA drains) run the same arithmetic in the same order as the dynamic kernels.  A ragged multi-mesh batch large
+    enough for several tiles per workgroup, training mode (saves + backward) and inference mode; MGN_X6_STATIC is
+    read per launch."""
+    import os
+    g = gp.cylinder_batch(6, 1885, 3).to(dev)           # E ~ 67 k rows: 2 tiles per persistent workgroup, ragged tail
+    L, H = 3, 128
+    params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), 91)
+    x_in, e_in = R.randn((g.x.shape[0], 11), 5).to(dev), R.randn((g.edge_index.shape[1], 3), 6).to(dev)
+    res = {}
+    old = os.environ.get("MGN_X6_STATIC")
+    ops.set_matrix_precision(prec)
+    try:
+        for mode in ("0", "1"):
+            os.environ["MGN_X6_STATIC"] = mode
+            net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H).to(dev)
+            net.load_state_dict(params)
+            out = net(gp.Graph(x=x_in, edge_attr=e_in, edge_index=g.edge_index))
+            out.square().sum().backward()
+            with torch.no_grad():
+                inf = net(gp.Graph(x=x_in, edge_attr=e_in, edge_index=g.edge_index))
+            res[mode] = {"out": out.detach().clone(), "inf": inf.clone(), **{k: p.grad.clone() for k, p in net.named_parameters()}}
+    finally:
+        ops.set_matrix_precision("fp32")
+        if old is None:
+            os.environ.pop("MGN_X6_STATIC", None)
+        else:
+            os.environ["MGN_X6_STATIC"] = old
+    assert torch.isfinite(res["1"]["out"]).all()
+    for k in res["0"]:
+        assert torch.equal(res["0"][k], res["1"][k]), (k, float((res["0"][k] - res["1"][k]).abs().max()))
+
+
+@pytest.mark.gpu
+def test_static_node_shape_equals_the_dynamic_kernel_on_a_multi_tile_launch(dev):
+    """The node update takes its static shape only above 131 072 rows (one tile per workgroup would make the unrolled
+    body pure instruction fetch): a 72-mesh batch (135 720 nodes, 810 k edges), forward + backward, both routes."""
+    import os
+    g = gp.cylinder_batch(72, 1885, 11).to(dev)
+    assert g.x.shape[0] >= 4 * 512 * 64
+    L, H = 2, 128
+    params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), 92)
+    x_in, e_in = R.randn((g.x.shape[0], 11), 7).to(dev), R.randn((g.edge_index.shape[1], 3), 8).to(dev)
+    res = {}
+    old = os.environ.get("MGN_X6_STATIC")
+    try:
+        for mode in ("0", "1"):
+            os.environ["MGN_X6_STATIC"] = mode
+            net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H).to(dev)
+            net.load_state_dict(params)
+            out = net(gp.Graph(x=x_in, edge_attr=e_in, edge_index=g.edge_index))
+            out.square().sum().backward()
+            res[mode] = {"out": out.detach().clone(), **{k: p.grad.clone() for k, p in net.named_parameters()}}
+    finally:
+        if old is None:
+            os.environ.pop("MGN_X6_STATIC", None)
+        else:
+            os.environ["MGN_X6_STATIC"] = old
+    for k in res["0"]:
+        assert torch.equal(res["0"][k], res["1"][k]), (k, float((res["0"][k] - res["1"][k]).abs().max()))

@@ -75,7 +75,7 @@ try:
         sd = [abs(v[0][2] - v[1][2]) for v in place.values() if len(v) == 2]
         if sd:
             sd.sort(); print("  start-time distance of pairs (10 ns ticks): median %d, p10 %d, p90 %d" % (sd[len(sd) // 2], sd[len(sd) // 10], sd[9 * len(sd) // 10]))
-    names = {1: "T", 3: "pre", 4: "bar", 5: "gemm", 6: "drain", 7: "epi", 8: "end"}
+    names = {1: "T", 3: "pre", 4: "bar", 5: "gemm", 6: "drain", 7: "epi", 8: "end", 9: "norm+st", 10: "nbk"}
     firsts = [(buf[b * 512] >> 8) for b in range(8)]
     lasts = [(buf[b * 512 + max(pos[b] - 1, 0)] >> 8) for b in range(8)]
     print("census (100 MHz ticks = 10 ns): first stamp rel. to WG0:", [f - firsts[0] for f in firsts])
