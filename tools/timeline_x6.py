@@ -4,12 +4,13 @@ edge-forward kernel (needs tools/libexp_TLX.so = the engine built with -DMGN_TIM
 import ctypes as C, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
-os.environ["MGN_LIB"] = os.path.join(R, "tools", "libexp_TLX.so")  # build: hipcc ... -DMGN_TIMELINE -o tools/libexp_TLX.so csrc/*.hip
+os.environ["MGN_LIB"] = os.path.join(R, "tools", os.environ.get("TL_LIB", "libexp_TLX.so"))  # build: hipcc ... -DMGN_TIMELINE -o tools/libexp_TLX.so csrc/*.hip
 try:
     import torch, graph_physics_amd as gp
     from graph_physics_amd import ops, _capi
     dev = torch.device("cuda:0")
-    g = gp.cylinder_batch(16, 1885, 0).to(dev)
+    nb = int(os.environ.get("TL_BATCH", "16"))  # meshes in the batch (1: the single-tile latency regime)
+    g = gp.cylinder_batch(nb, 1885, 0).to(dev)
     topo = ops.Topology(g.edge_index, g.x.shape[0])
     N, E, H = topo.N, topo.E, 128
     f = dict(dtype=torch.float32, device=dev)
@@ -55,7 +56,7 @@ try:
     if hasattr(L, "mgn_debug_census"):
         cen = (C.c_ulonglong * (1024 * 4))()
         L.mgn_debug_census(cen)
-        nwg = 512
+        nwg = min(512, (E + 63) // 64)
         t0 = min(cen[4 * b + 2] for b in range(nwg))
         place = {}
         for b in range(nwg):
