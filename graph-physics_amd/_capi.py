@@ -147,6 +147,8 @@ SYMBOLS = {
     "mgn_topology_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "mgn_topology_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 6 + [C.POINTER(C.c_int32), C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
+    "mgn_topology_build_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 6 + [C.c_void_p, C.c_void_p,
+                                           C.c_size_t, C.c_void_p]),
     "mgn_segsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "mgn_seg_fix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mgn_segsum2": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_void_p]),
@@ -184,6 +186,8 @@ SYMBOLS = {
                                    C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgn_add_noise": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float),
                                 C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "mgn_morton_order_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "mgn_morton_order": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_prep_last_error": (C.c_char_p, []),
     "mgn_sparse_attn_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgn_sparse_attn_bwd": (C.c_int, [C.c_void_p] * 11 + [C.c_int64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]),
@@ -195,7 +199,7 @@ _lock = threading.Lock()
 
 #: ABI version this binding was written against (mgn_version() of the library must match: the
 #: ctypes structs above mirror exactly that header)
-EXPECTED_VERSION = 122
+EXPECTED_VERSION = 130
 HASH_PATH = os.path.join(_CSRC, "libmgn_hip.srchash")
 LOCK_PATH = os.path.join(_CSRC, ".build.lock")
 

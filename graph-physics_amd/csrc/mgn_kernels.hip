@@ -2077,7 +2077,7 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
 
 extern "C" {
 
-int mgn_version(void) { return 122; }
+int mgn_version(void) { return 130; }
 const char* mgn_last_error(void) { return g_err; }
 
 size_t mgn_csr_workspace_bytes(int64_t E, int64_t N) {
@@ -2121,16 +2121,25 @@ int mgn_csr_build(const int64_t* key, int64_t E, int64_t N, int32_t* rowptr, int
 }
 
 // src_s / dst_s (int32, dst-sorted order) and the int64 keys of the second CSR
-__global__ void k_topo_gather(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int32_t* __restrict__ perm, long E,
-                              int32_t* __restrict__ src_s, int32_t* __restrict__ dst_s, int64_t* __restrict__ key2) {
+__global__ void k_topo_gather(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int32_t* __restrict__ perm,
+                              const int32_t* __restrict__ rowptr, long E, long N, int32_t* __restrict__ src_s, int32_t* __restrict__ dst_s,
+                              int64_t* __restrict__ key2) {
   const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= E) return;
+  // An index outside [0, N) is REPORTED through the error flag (read by the host after a synchronisation, or lazily by
+  // mgn_topology_build_async's caller); until then every array this build hands out must be safe to compute on: rows
+  // past the valid count (their edges were dropped by the histogram) point at edge 0, stray node ids at node 0.
   int e = perm[k];
-  if (e < 0 || e >= E) e = 0;  // rows past the valid count when an index is out of range (reported after the sync): any readable edge
-  const int64_t a = src[e];
+  if (k >= rowptr[N] || e < 0 || e >= E) {
+    e = 0;
+    perm[k] = 0;
+  }
+  int64_t a = src[e], b = dst[e];
+  a = (a < 0 || a >= N) ? 0 : a;
+  b = (b < 0 || b >= N) ? 0 : b;
   src_s[k] = (int32_t)a;
-  dst_s[k] = (int32_t)dst[e];
-  key2[k] = a;
+  dst_s[k] = (int32_t)b;
+  key2[k] = (k < rowptr[N]) ? src[e] : (int64_t)-1;  // dropped rows take no part in the source-side CSR either
 }
 // out[0] = max in-degree, out[1] = max out-degree (one atomicMax per wave)
 __global__ void k_topo_maxdeg(const int32_t* __restrict__ rp0, const int32_t* __restrict__ rp1, long N, int* __restrict__ out) {
@@ -2155,25 +2164,34 @@ size_t mgn_topology_workspace_bytes(int64_t E, int64_t N) {
   return 2 * mgn_csr_workspace_bytes(E, N) + (size_t)E * sizeof(int64_t) + 256;
 }
 
-int mgn_topology_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* perm_dst,
-                       int32_t* src_s, int32_t* dst_s, int32_t* rowptr_src, int32_t* perm_src, int32_t* max_degree_host,
-                       void* ws, size_t ws_bytes, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+static int topology_enqueue(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* perm_dst,
+                            int32_t* src_s, int32_t* dst_s, int32_t* rowptr_src, int32_t* perm_src, int* flags, void* ws, size_t ws_bytes,
+                            hipStream_t s) {
   if (N < 0 || E < 0 || E > 2147483647LL || N > 2147483646LL) return fail(1, "mgn_topology_build: size out of int32 range");
   if (ws_bytes < mgn_topology_workspace_bytes(E, N)) return fail(1, "mgn_topology_build: workspace too small");
   const size_t csr_b = (mgn_csr_workspace_bytes(E, N) + 63) & ~(size_t)63;
   char* w = (char*)ws;
   int64_t* key2 = (int64_t*)(w + 2 * csr_b);
-  int* flags = (int*)(w + 2 * csr_b + (size_t)E * sizeof(int64_t));  // [0] err, [1] max in-degree, [2] max out-degree
   if (hipMemsetAsync(flags, 0, 4 * sizeof(int), s) != hipSuccess) return fail(2, "mgn_topology_build: memset");
   if (int rc = csr_enqueue(dst, E, N, rowptr_dst, perm_dst, w, flags, s)) return rc;
   if (E > 0) {
     hipLaunchKernelGGL(k_csr_hist, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, src, (long)E, (long)N, (int*)(w + csr_b), flags);  // range check of src
-    hipLaunchKernelGGL(k_topo_gather, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, src, dst, perm_dst, (long)E, src_s, dst_s, key2);
+    hipLaunchKernelGGL(k_topo_gather, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, src, dst, perm_dst, rowptr_dst, (long)E, (long)N,
+                       src_s, dst_s, key2);
   }
   if (int rc = csr_enqueue(key2, E, N, rowptr_src, perm_src, w + csr_b, flags, s)) return rc;
   if (N > 0) hipLaunchKernelGGL(k_topo_maxdeg, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rowptr_dst, rowptr_src, (long)N, flags + 1);
-  if (int rc = check_launch("mgn_topology_build")) return rc;
+  return check_launch("mgn_topology_build");
+}
+
+int mgn_topology_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* perm_dst,
+                       int32_t* src_s, int32_t* dst_s, int32_t* rowptr_src, int32_t* perm_src, int32_t* max_degree_host,
+                       void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (ws_bytes < mgn_topology_workspace_bytes(E < 0 ? 0 : E, N < 0 ? 0 : N)) return fail(1, "mgn_topology_build: workspace too small");
+  const size_t csr_b = (mgn_csr_workspace_bytes(E, N) + 63) & ~(size_t)63;
+  int* flags = (int*)((char*)ws + 2 * csr_b + (size_t)E * sizeof(int64_t));  // [0] err, [1] max in-degree, [2] max out-degree
+  if (int rc = topology_enqueue(src, dst, E, N, rowptr_dst, perm_dst, src_s, dst_s, rowptr_src, perm_src, flags, ws, ws_bytes, s)) return rc;
   int h[3] = {0, 0, 0};
   if (hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess) return fail(2, "mgn_topology_build: memcpy");
   if (hipStreamSynchronize(s) != hipSuccess) return fail(2, "mgn_topology_build: sync failed");
@@ -2183,6 +2201,13 @@ int mgn_topology_build(const int64_t* src, const int64_t* dst, int64_t E, int64_
     max_degree_host[1] = h[2];
   }
   return 0;
+}
+
+int mgn_topology_build_async(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* perm_dst,
+                             int32_t* src_s, int32_t* dst_s, int32_t* rowptr_src, int32_t* perm_src, int32_t* flags_dev,
+                             void* ws, size_t ws_bytes, void* stream) {
+  if (flags_dev == nullptr) return fail(1, "mgn_topology_build_async: flags_dev is required");
+  return topology_enqueue(src, dst, E, N, rowptr_dst, perm_dst, src_s, dst_s, rowptr_src, perm_src, flags_dev, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int mgn_segsum(const float* src, const int32_t* rowptr, const int32_t* perm, float* out, int64_t N, int H, void* stream) {

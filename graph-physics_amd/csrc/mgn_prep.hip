@@ -122,6 +122,127 @@ extern "C" int mgn_faces_to_edges(const int64_t* face, int K, int64_t F, int64_t
   return 0;
 }
 
+// ======================================================================= node renumbering
+// Locality order of the nodes of ONE mesh for the message-passing rounds: the gathers Pd[dst], Ps[src] and the
+// source-grouped backward scatter read 512-byte node rows through the edge list; with a numbering that follows
+// space (neighbours in the mesh = neighbours in memory) those rows come from a few L2-resident lines, with the
+// raw numbering of a mesh generator (uniform random points) every row is a fresh HBM request.  The reference has
+// no counterpart (PyTorch indexes whatever numbering the dataset has, layers.py:1017-1018); the engine renumbers
+// on entry and un-does it on exit (ops.Topology(renumber=...)).
+// order[i] = old id of the node at new position i (sorted by Morton key of its position, ties by old id:
+// radix sort is stable); rank[old] = new.  Keys: D = 2 -> 2 x 31 bits, D = 3 -> 3 x 21 bits, quantised on the
+// bounding box (computed on the device: no host round trip).
+__device__ __forceinline__ unsigned f2ord(float f) {  // order-preserving map float -> unsigned (NaN sorts last)
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+__global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ pos, int ld, int D, long N, unsigned* __restrict__ box) {
+  unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256)
+    for (int d = 0; d < D; ++d) {
+      const float v = pos[i * ld + d];
+      if (v == v && fabsf(v) <= 3.0e38f) {
+        const unsigned o = f2ord(v);
+        lo[d] = o < lo[d] ? o : lo[d];
+        hi[d] = o > hi[d] ? o : hi[d];
+      }
+    }
+  for (int d = 0; d < D; ++d) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned a = __shfl_xor(lo[d], off), b = __shfl_xor(hi[d], off);
+      lo[d] = a < lo[d] ? a : lo[d];
+      hi[d] = b > hi[d] ? b : hi[d];
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(box + d, lo[d]);
+      atomicMax(box + 3 + d, hi[d]);
+    }
+  }
+}
+__device__ __forceinline__ uint64_t spread2(uint64_t v) {  // 31 bits -> every second bit
+  v &= 0x7fffffffull;
+  v = (v | (v << 16)) & 0x0000ffff0000ffffull;
+  v = (v | (v << 8)) & 0x00ff00ff00ff00ffull;
+  v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0full;
+  v = (v | (v << 2)) & 0x3333333333333333ull;
+  v = (v | (v << 1)) & 0x5555555555555555ull;
+  return v;
+}
+__device__ __forceinline__ uint64_t spread3(uint64_t v) {  // 21 bits -> every third bit
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x001f00000000ffffull;
+  v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+__global__ void __launch_bounds__(256) k_morton_keys(const float* __restrict__ pos, int ld, int D, long N, const unsigned* __restrict__ box,
+                                                    uint64_t* __restrict__ keys, int32_t* __restrict__ ids) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int bits = (D == 2) ? 31 : 21;
+  const double top = (double)((1ull << bits) - 1);
+  uint64_t q[3] = {0, 0, 0};
+  for (int d = 0; d < D; ++d) {
+    const float lo = ord2f(box[d]), hi = ord2f(box[3 + d]);
+    const float v = pos[i * ld + d];
+    double t = 0.0;
+    if (v == v && hi > lo) t = ((double)v - (double)lo) / ((double)hi - (double)lo);
+    t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+    q[d] = (uint64_t)(t * top);
+  }
+  keys[i] = (D == 2) ? (spread2(q[0]) | (spread2(q[1]) << 1)) : (spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2));
+  ids[i] = (int32_t)i;
+}
+__global__ void __launch_bounds__(256) k_inverse_perm(const int32_t* __restrict__ order, long N, int32_t* __restrict__ rank) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < N) rank[order[i]] = (int32_t)i;
+}
+struct MortonPlan {
+  size_t keys, keys2, ids, box, tmp, tmp_bytes, total;
+};
+static MortonPlan morton_plan(int64_t N) {
+  MortonPlan p;
+  size_t t = 0;
+  rocprim::radix_sort_pairs(nullptr, t, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)N, 0, 64, (hipStream_t)0);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  p.tmp_bytes = t + 256;
+  p.keys = 0;
+  p.keys2 = al((size_t)N * 8);
+  p.ids = al(p.keys2 + (size_t)N * 8);
+  p.box = al(p.ids + (size_t)N * 4);
+  p.tmp = al(p.box + 64);
+  p.total = p.tmp + p.tmp_bytes;
+  return p;
+}
+extern "C" size_t mgn_morton_order_workspace_bytes(int64_t N) { return N < 0 ? 0 : morton_plan(N).total + 256; }
+extern "C" int mgn_morton_order(const float* pos, int ld, int D, int64_t N, int32_t* order, int32_t* rank, void* ws, size_t ws_bytes,
+                                void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (pos == nullptr || order == nullptr || rank == nullptr || (D != 2 && D != 3) || ld < D || N < 0 || N > 2147483647LL)
+    return pfail(1, "mgn_morton_order: bad arguments (positions with 2 or 3 coordinates)");
+  if (N == 0) return 0;
+  const MortonPlan p = morton_plan(N);
+  const size_t base = ((size_t)ws + 255) & ~(size_t)255;
+  if (ws == nullptr || ws_bytes < (base - (size_t)ws) + p.total) return pfail(1, "mgn_morton_order: workspace too small");
+  char* w = (char*)base;
+  uint64_t *keys = (uint64_t*)(w + p.keys), *keys2 = (uint64_t*)(w + p.keys2);
+  int32_t* ids = (int32_t*)(w + p.ids);
+  unsigned* box = (unsigned*)(w + p.box);
+  if (hipMemsetAsync(box, 0xff, 12, s) != hipSuccess || hipMemsetAsync(box + 3, 0, 12, s) != hipSuccess)
+    return pfail(2, "mgn_morton_order: memset");
+  const unsigned nb = (unsigned)((N + 255) / 256);
+  hipLaunchKernelGGL(k_bbox, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, pos, ld, D, (long)N, box);
+  hipLaunchKernelGGL(k_morton_keys, dim3(nb), dim3(256), 0, s, pos, ld, D, (long)N, box, keys, ids);
+  size_t tb = p.tmp_bytes;
+  if (rocprim::radix_sort_pairs(w + p.tmp, tb, keys, keys2, ids, order, (size_t)N, 0, 64, s) != hipSuccess)
+    return pfail(2, "mgn_morton_order: sort");
+  hipLaunchKernelGGL(k_inverse_perm, dim3(nb), dim3(256), 0, s, order, (long)N, rank);
+  return pcheck("mgn_morton_order");
+}
+
 // ======================================================================= world edges
 // add_world_edges of the reference (dataset/preprocessing.py:92-140): all node pairs whose WORLD
 // positions are within `radius` (scipy cKDTree.query_pairs: Euclidean distance <= r, evaluated in
@@ -807,7 +928,7 @@ __global__ void __launch_bounds__(256) k_add_noise(float* __restrict__ x, int x_
   const long n = t / W;
   const int j = (int)(t % W);
   if (n >= N) return;
-  if ((int)(long)x[n * x_w + type_idx] != MGN_NODE_NORMAL) return;  // noise only on NORMAL nodes (:219-222,230-231)
+  if (x[n * x_w + type_idx] != (float)MGN_NODE_NORMAL) return;  // noise only on NORMAL nodes; the FLOAT is compared (:219-222,230-231)
   int r = 0;
   while (r + 1 < R.n && j >= R.col0[r + 1]) ++r;
   const int c = R.start[r] + (j - R.col0[r]);
@@ -831,8 +952,31 @@ extern "C" int mgn_add_noise(float* x, int x_w, int64_t N, int n_ranges, const i
     R.start[r] = starts[r], R.end[r] = ends[r], R.scale[r] = scales[r];
     R.col0[r + 1] = R.col0[r] + (ends[r] - starts[r]);
   }
-  const long tot = (long)N * R.col0[n_ranges];
-  if (tot == 0) return 0;
-  hipLaunchKernelGGL(k_add_noise, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_w, (long)N, R, type_idx, seed, offset);
+  // the node-type column is read by every thread while the noised columns are written: it must not be noised itself
+  // (the reference takes its mask BEFORE the loop, :219-222 -- a noised type column has no meaning there either)
+  bool overlap = false;
+  for (int r = 0; r < n_ranges; ++r) {
+    if (type_idx >= starts[r] && type_idx < ends[r]) return pfail(1, "mgn_add_noise: node_type_index lies inside a noised column range");
+    for (int q = 0; q < r; ++q) overlap = overlap || (starts[r] < ends[q] && starts[q] < ends[r]);
+  }
+  if (R.col0[n_ranges] == 0 || N == 0) return 0;
+  if (!overlap) {
+    const long tot = (long)N * R.col0[n_ranges];
+    hipLaunchKernelGGL(k_add_noise, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_w, (long)N, R, type_idx, seed, offset);
+    return pcheck("mgn_add_noise");
+  }
+  // overlapping ranges: the reference applies them one after the other (:224-236); one launch per range keeps every
+  // `+=` of a launch on a distinct element (no race), the stream orders the launches.  The random stream of range r is
+  // keyed by r (counter word 2), so the values equal the single-launch ones.
+  for (int r = 0; r < n_ranges; ++r) {
+    NoiseRanges R1 = R;
+    for (int q = 0; q < n_ranges; ++q)
+      if (q != r) R1.end[q] = R1.start[q];                      // empty: every other range contributes no column
+    R1.col0[0] = 0;
+    for (int q = 0; q < n_ranges; ++q) R1.col0[q + 1] = R1.col0[q] + (R1.end[q] - R1.start[q]);
+    const long tot = (long)N * R1.col0[n_ranges];
+    if (tot == 0) continue;
+    hipLaunchKernelGGL(k_add_noise, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_w, (long)N, R1, type_idx, seed, offset);
+  }
   return pcheck("mgn_add_noise");
 }

@@ -100,9 +100,12 @@ class HaloState:
         self.send_counts, self.recv_counts = list(plan.send_counts), list(plan.recv_counts)
         # a collective is needed whenever rows are exchanged and a process group exists (a world-1 group is legal:
         # the self-exchange plan of tests/test_halo_rccl_single.py runs the whole path over RCCL on one GPU)
+        # (all_to_all_single is a collective of the WHOLE group: a rank without boundary nodes -- a mesh component of
+        # its own -- still has to enter it, with empty splits, or its peers wait for ever)
         self.active = dist.is_initialized() and dist.get_world_size(group) == plan.world and \
-            (self.n_ghost > 0 or int(plan.send_idx.numel()) > 0) and (plan.world > 1 or getattr(plan, "self_exchange", False))
+            (plan.world > 1 or (getattr(plan, "self_exchange", False) and (self.n_ghost > 0 or int(plan.send_idx.numel()) > 0)))
         self._rowptr_bnd = None
+        self._back = None  # receive buffer of the backward exchange (one per state: 30 exchanges a step re-use it)
 
     def rowptr_bnd(self, topo):
         """rowptr_dst shifted to the first boundary edge row: the boundary launch numbers its rows from 0"""
@@ -113,10 +116,9 @@ class HaloState:
     # ---- forward: owners' rows -> ghost rows of the same buffer
     def start_forward(self, buf: torch.Tensor):
         from . import ops
-        if self.n_ghost == 0 and self.send_idx.numel() == 0:
-            return None
         if not self.active:  # a single process holding a multi-rank plan (timing rehearsal): ghosts read as zeros
-            buf[self.n_own:].zero_()
+            if self.n_ghost > 0:
+                buf[self.n_own:].zero_()
             return None
         send = ops.gather_rows(buf, self.send_idx)
         work = dist.all_to_all_single(buf[self.n_own:], send, output_split_sizes=self.recv_counts,
@@ -129,9 +131,13 @@ class HaloState:
 
     # ---- backward: ghost-row gradients -> summed into their owners
     def start_backward(self, Ss: torch.Tensor):
-        if not self.active or (self.n_ghost == 0 and self.send_idx.numel() == 0):
+        if not self.active:
             return None
-        back = torch.empty(self.send_idx.numel(), Ss.shape[1], dtype=Ss.dtype, device=Ss.device)
+        # allocated once: the unpack of round i has consumed it (same stream) before round i-1's exchange is
+        # started after it, and the collective itself is ordered behind the compute stream
+        if self._back is None or self._back.shape[1] != Ss.shape[1] or self._back.dtype != Ss.dtype:
+            self._back = torch.empty(self.send_idx.numel(), Ss.shape[1], dtype=Ss.dtype, device=Ss.device)
+        back = self._back
         work = dist.all_to_all_single(back, Ss[self.n_own:], output_split_sizes=self.send_counts,
                                       input_split_sizes=self.recv_counts, group=self.group, async_op=True)
         return (work, back)
@@ -221,10 +227,20 @@ class PartitionedEPD(torch.nn.Module):
         self.backend = backend if backend is not None else HipBackend()
         self._ctx = None
         self._halo = None
+        # what the un-partitioned forward would apply and this path does not: refuse instead of silently
+        # computing another function (processors.py:203-209 temporal block; layers.py:1020-1026 RoPE needs the
+        # positions of ghost nodes)
+        if getattr(model, "use_temporal_block", False) or getattr(model, "temporal_block", None) is not None:
+            raise NotImplementedError("PartitionedEPD: use_temporal_block is not supported on a partitioned mesh")
+        if getattr(model, "use_rope", False):
+            raise NotImplementedError("PartitionedEPD: use_rope_embeddings is not supported on a partitioned mesh")
 
-    def forward(self, x_in_own: torch.Tensor, edge_attr_loc: torch.Tensor) -> torch.Tensor:
+    def forward(self, x_in_own: torch.Tensor, edge_attr_loc: torch.Tensor, phi_own: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``phi_own``: the owned rows of ``graph.phi`` (only read by blocks with the sigmoid gate, layers.py:1091-1098)."""
         plan, be, m = self.plan, self.backend, self.model
         dev = x_in_own.device
+        if phi_own is not None and phi_own.reshape(-1).shape[0] != plan.n_own:
+            raise ValueError("phi_own must hold one value per owned node")
         if self._ctx is None:
             self._ctx = be.prepare(plan.edge_index.to(dev), plan.n_own + plan.n_ghost)
         x_own = be.mlp(m.nodes_encoder, x_in_own)
@@ -240,8 +256,10 @@ class PartitionedEPD(torch.nn.Module):
             for blk in blocks:
                 params += _block_params(blk)
             x_own, _ = ops.processor_apply(x_own, e, self._ctx, len(blocks), *params, spec=blocks[0].spec, halo=self._halo,
-                                           phi=None)
+                                           phi=phi_own)
         else:
+            if phi_own is not None:
+                raise NotImplementedError("PartitionedEPD: graph.phi is only supported on the fused H = 128 path")
             for blk in blocks:
                 x_gh = HaloExchange.apply(x_own, plan, self.group)
                 x_full = torch.cat([x_own, x_gh], dim=0)

@@ -179,7 +179,10 @@ class GraphNetBlock(nn.Module):
             x_new, e_new = ops.processor_apply(x, e_sorted, topo, 1, *_block_params(self), spec=self.spec,
                                                pos=pos if self.use_rope else None, phi=phi if self.use_gate else None,
                                                rope_inv_freq=self._rope_inv_freq if self.use_rope else None)
-        return x_new, e_new[topo.inv_perm]
+        out = (x_new, e_new[topo.inv_perm])
+        if not topo.resolved:  # lazily built topology: launches are queued, now look at its flags (IndexError on a stray index)
+            topo.resolve()
+        return out
 
 
 class Normalizer(nn.Module):

@@ -112,10 +112,35 @@ def cylinder_mesh(n_nodes: int = 1885, seed: int = 0) -> Graph:
     )
 
 
-def square_mesh(n_nodes: int, seed: int = 0, spatial_sort: bool = True) -> Graph:
-    """Config C4: 2-D Delaunay of ``n_nodes`` uniform points in the unit square
-    (~3 undirected edges per node).  ``spatial_sort`` renumbers nodes along a
-    Morton curve so that neighbouring rows are close in memory."""
+def plate_mesh(n_nodes: int = 1300, seed: int = 61, radius: float = 0.1, device=None) -> Graph:
+    """DeformingPlate-shaped sample (BASELINE configs[2]; training_config/plate.json:23-29): x = [world_pos(3),
+    obstacle displacement(3), node_type], y = next world_pos; a block of OBSTACLE nodes hovering next to the NORMAL
+    plate nodes; tetrahedra of a 3-D Delaunay.  The reference's per-sample transforms run ON THE DEVICE
+    (FaceToEdge -> add_world_edges -> Cartesian + Distance, dataset/preprocessing.py:92-140,16-23), so ``device``
+    must be a GPU."""
+    from scipy.spatial import Delaunay
+
+    from . import preprocess as PP
+
+    rng = np.random.default_rng(seed)
+    pts = (rng.random((n_nodes, 3)) * np.array([1.0, 0.3, 0.3])).astype(np.float32)
+    types = np.where(pts[:, 0] < 0.25, float(int(NodeType.OBSTACLE)), float(int(NodeType.NORMAL))).astype(np.float32)
+    types[rng.integers(0, n_nodes, 40)] = float(int(NodeType.HANDLE))
+    disp = (0.01 * rng.standard_normal((n_nodes, 3))).astype(np.float32)
+    x = torch.from_numpy(np.concatenate([pts, disp, types[:, None]], axis=1))
+    y = torch.from_numpy((pts + 0.01 * rng.standard_normal((n_nodes, 3))).astype(np.float32))
+    cells = torch.from_numpy(Delaunay(pts).simplices.T.astype(np.int64))
+    xd, pos = x.to(device), torch.from_numpy(pts).to(device)
+    ei = PP.add_world_edges(xd, PP.faces_to_edges(cells.to(device), n_nodes), 0, 3, 6, radius=radius)
+    return Graph(x=xd, y=y.to(device), pos=pos, face=cells.to(device), edge_index=ei, edge_attr=PP.edge_features(pos, ei))
+
+
+def square_mesh(n_nodes: int, seed: int = 0, spatial_sort: bool = False) -> Graph:
+    """Config C4: 2-D Delaunay of ``n_nodes`` uniform points in the unit square, seed 0
+    (~3 undirected edges per node), nodes numbered in the order the generator drew them -- NO locality.
+    Locality renumbering is the ENGINE's job (ops.set_node_renumbering / Topology(renumber=...)), applied to any
+    input and timed with the topology build.  ``spatial_sort=True`` pre-sorts the points along a Morton curve
+    inside the generator (the round-2 behaviour; kept for A/B measurements only)."""
     from scipy.spatial import Delaunay
 
     rng = np.random.default_rng(seed)

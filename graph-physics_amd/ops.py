@@ -68,13 +68,91 @@ def pad16(n: int) -> int:
 
 
 # --------------------------------------------------------------------- topology
+#: node renumbering of EncodeProcessDecode.forward: "off", "on" (Morton order of graph.pos when the graph has
+#: positions, otherwise reverse Cuthill-McKee of the edge list, computed on the host), or "auto" (default): on
+#: from RENUMBER_MIN_NODES nodes -- below that every node row the edge kernels gather is L2-resident whatever the
+#: numbering.  The reference has no counterpart (it gathers x[col], x[row] in the dataset's numbering,
+#: layers.py:1017-1018); results are un-permuted on exit.  The forward aggregation still sums a node's incoming
+#: messages in ascending ORIGINAL edge id (the CSR build is a stable sort of edge ids by destination, whatever the
+#: destination is called), so it equals the un-renumbered result up to the association of partial sums at tile
+#: boundaries; the source-side scatter of the backward pass walks the dst-sorted rows, whose order does change.
+_renumber_mode = _os.environ.get("MGN_RENUMBER", "auto")
+RENUMBER_MIN_NODES = 200_000
+
+
+def set_node_renumbering(mode: str) -> None:
+    global _renumber_mode
+    if mode not in ("off", "on", "auto"):
+        raise ValueError("node renumbering mode must be 'off', 'on' or 'auto'")
+    _renumber_mode = mode
+
+
+def get_node_renumbering() -> str:
+    return _renumber_mode
+
+
+def want_renumbering(num_nodes: int) -> bool:
+    return _renumber_mode == "on" or (_renumber_mode == "auto" and num_nodes >= RENUMBER_MIN_NODES)
+
+
+def morton_order(pos: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(order[N] int32: old id at new position i, rank[N] int32: new position of old id) along a Morton curve of
+    the first 2 or 3 columns of ``pos`` -- on the device, no host synchronisation (mgn_morton_order)."""
+    _require_device(pos)
+    pos = _f32c(pos)
+    if pos.dim() != 2 or pos.shape[1] < 2:
+        raise ValueError("pos must be [N, >= 2]")
+    N, D = int(pos.shape[0]), min(int(pos.shape[1]), 3)
+    dev = pos.device
+    L = _capi.lib()
+    order = torch.empty(N, dtype=torch.int32, device=dev)
+    rank = torch.empty(N, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(L.mgn_morton_order_workspace_bytes(N), 16), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.mgn_morton_order(_ptr(pos), int(pos.shape[1]), D, N, _ptr(order), _ptr(rank), _ptr(ws), ws.numel(), _stream(dev))
+    _capi.check(rc, "mgn_morton_order", prep=True)
+    return order, rank
+
+
+def rcm_order(edge_index: torch.Tensor, num_nodes: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(order, rank) by reverse Cuthill-McKee of the symmetrised edge list: the fallback when a graph carries no
+    positions.  One-time topology preparation on the HOST (scipy.sparse.csgraph): one device->host copy of the
+    edge list, ~1 s per million nodes; cached with the topology."""
+    import numpy as np
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+    ei = edge_index.detach().to("cpu", torch.int64).numpy()
+    ok = (ei >= 0).all(axis=0) & (ei < num_nodes).all(axis=0)   # stray indices are reported by the topology build
+    ei = ei[:, ok]
+    a = coo_matrix((np.ones(ei.shape[1], dtype=np.int8), (ei[0], ei[1])), shape=(num_nodes, num_nodes)).tocsr()
+    order = np.asarray(reverse_cuthill_mckee(a, symmetric_mode=False), dtype=np.int64)
+    rank = np.empty(num_nodes, dtype=np.int64)
+    rank[order] = np.arange(num_nodes, dtype=np.int64)
+    dev = edge_index.device
+    return torch.from_numpy(order).to(dev, torch.int32), torch.from_numpy(rank).to(dev, torch.int32)
+
+
 class Topology:
     """dst-sorted (CSR) edge order of one ``edge_index`` plus the src-grouped view
-    the backward scatter needs.  Built on the device by ``mgn_csr_build``; cached
+    the backward scatter needs.  Built on the device by ``mgn_topology_build[_async]``; cached
     per ``edge_index`` tensor by :func:`get_topology` (mesh topology is static
-    along a trajectory)."""
+    along a trajectory).
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+    ``lazy=True``: the build is queued WITHOUT a host synchronisation (a shuffled loader hands the engine a new
+    edge_index every step).  The error flag and the degree maxima travel to pinned host memory behind an event;
+    :meth:`resolve` (called by ``EncodeProcessDecode.forward`` once its launches are queued, and by any later
+    query) waits for that event only -- by then the GPU has the whole forward pass in its queue, so the wait
+    never starves it.  Until resolved the topology is used OPTIMISTICALLY as hub-free: always correct (the
+    arrays are safe even with stray indices, a long segment is merely summed serially), and deterministic --
+    the first forward pass of a fresh topology takes the hub-free launches, every later use the resolved ones.
+
+    ``renumber`` ("morton" with ``pos``, "rcm", or None): the CSRs are built over RENUMBERED node ids;
+    ``node_order`` / ``node_rank`` (int64) map new -> old / old -> new.  Callers gather their node rows with
+    ``node_order`` on entry and with ``node_rank`` on exit (processors.EncodeProcessDecode.forward does)."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, lazy: bool = False, renumber: Optional[str] = None,
+                 pos: Optional[torch.Tensor] = None):
         _require_device(edge_index)
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must have shape [2, E]")
@@ -82,14 +160,44 @@ class Topology:
         ei = edge_index.to(torch.int64).contiguous()
         E, N = int(ei.shape[1]), int(num_nodes)
         self.N, self.E, self.device = N, E, dev
-        # one engine call, one stream synchronisation (mgn_topology_build): both CSRs, the sorted index rows and
-        # the degree maxima
+        self.node_order = self.node_rank = None
+        if renumber is not None and N > 0:
+            if renumber == "morton":
+                if pos is None or pos.shape[0] != N:
+                    raise ValueError("Morton renumbering needs one position per node")
+                order, rank = morton_order(pos)
+            elif renumber == "rcm":
+                order, rank = rcm_order(ei, N)
+            else:
+                raise ValueError("renumber must be 'morton', 'rcm' or None")
+            self.node_order, self.node_rank = order.long(), rank.long()
+            # relabel the edge list (stray indices stay stray: the build reports them)
+            okm = (ei >= 0) & (ei < N)
+            ei = torch.where(okm, self.node_rank[ei.clamp(0, max(N - 1, 0))], ei).contiguous()
         L = _capi.lib()
         i32 = dict(dtype=torch.int32, device=dev)
         self.rowptr_dst, self.rowptr_src = torch.empty(N + 1, **i32), torch.empty(N + 1, **i32)
         self.perm_dst, self.perm_src = torch.empty(E, **i32), torch.empty(E, **i32)
         self.src_s, self.dst_s = torch.empty(E, **i32), torch.empty(E, **i32)
         ws = torch.empty(max(L.mgn_topology_workspace_bytes(E, N), 16), dtype=torch.uint8, device=dev)
+        self._inv = None
+        self._pending = None
+        self._uses = 0
+        self.hub_dst = self.hub_src = None
+        if lazy:
+            flags = torch.zeros(4, **i32)
+            with torch.cuda.device(dev):
+                rc = L.mgn_topology_build_async(ei[0].data_ptr(), ei[1].data_ptr(), E, N, _ptr(self.rowptr_dst), _ptr(self.perm_dst),
+                                                _ptr(self.src_s), _ptr(self.dst_s), _ptr(self.rowptr_src), _ptr(self.perm_src),
+                                                _ptr(flags), _ptr(ws), ws.numel(), _stream(dev))
+                _capi.check(rc, "mgn_topology_build_async")
+                host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+                host.copy_(flags, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+            self._pending = (ev, host, flags, ws)   # flags / ws stay referenced until the copy has run
+            self.max_in_degree = self.max_out_degree = None
+            return
         mx = (C.c_int32 * 2)()
         with torch.cuda.device(dev):
             rc = L.mgn_topology_build(ei[0].data_ptr(), ei[1].data_ptr(), E, N, _ptr(self.rowptr_dst), _ptr(self.perm_dst), _ptr(self.src_s),
@@ -97,15 +205,42 @@ class Topology:
         if rc == 3:
             raise IndexError(f"edge_index has entries outside [0, {N})")
         _capi.check(rc, "mgn_topology_build")
-        self.max_in_degree, self.max_out_degree = int(mx[0]), int(mx[1])
-        self._inv = None
+        self._set_degrees(int(mx[0]), int(mx[1]))
+
+    def _set_degrees(self, din: int, dout: int):
+        self.max_in_degree, self.max_out_degree = din, dout
         # Hub nodes.  A segment is summed by ONE lane group walking it in order -- ideal for meshes (degree
         # ~6), unbounded for the arbitrary edge_index the input contract allows (a node with 100 000 in-edges
         # would serialise 100 000 row loads).  Segments longer than HUB_CHUNK are therefore cut into chunks
         # summed in parallel, and a second small segment sum adds the chunk rows of each node (fixed order:
-        # still deterministic, no atomics).  The degree maxima come back with the topology build's one host read.
-        self.hub_dst = _chunk_csr(self.rowptr_dst) if self.max_in_degree > HUB_CHUNK else None
-        self.hub_src = _chunk_csr(self.rowptr_src) if self.max_out_degree > HUB_CHUNK else None
+        # still deterministic, no atomics).
+        self.hub_dst = _chunk_csr(self.rowptr_dst) if din > HUB_CHUNK else None
+        self.hub_src = _chunk_csr(self.rowptr_src) if dout > HUB_CHUNK else None
+
+    @property
+    def resolved(self) -> bool:
+        return self._pending is None
+
+    def resolve(self) -> "Topology":
+        """wait for the build's flags (lazy builds): raises IndexError on a stray index, sets the hub tables"""
+        if self._pending is not None:
+            ev, host, _flags, _ws = self._pending
+            ev.synchronize()
+            self._pending = None
+            err, din, dout = int(host[0]), int(host[1]), int(host[2])
+            if err:
+                self.max_in_degree = self.max_out_degree = 0
+                raise IndexError(f"edge_index has entries outside [0, {self.N})")
+            self._set_degrees(din, dout)
+        return self
+
+    def begin_use(self) -> bool:
+        """hub state for ONE pass over this topology (see the class docstring): a fresh lazy build is taken
+        as hub-free by its first user, later users wait for the flags"""
+        if self._pending is not None and self._uses > 0:
+            self.resolve()
+        self._uses += 1
+        return self.has_hubs
 
     @property
     def has_hubs(self) -> bool:
@@ -161,14 +296,21 @@ def segsum_topo(src: torch.Tensor, topo: "Topology", by: str, out: torch.Tensor,
 _topo_cache: dict = {}
 
 
-def get_topology(edge_index: torch.Tensor, num_nodes: int) -> Topology:
-    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes), str(edge_index.device))
+def get_topology(edge_index: torch.Tensor, num_nodes: int, pos: Optional[torch.Tensor] = None, renumber: bool = False) -> Topology:
+    """cached Topology of an ``edge_index`` tensor (lazy build: no host synchronisation).  ``renumber``: let the
+    engine renumber the nodes for locality when :func:`want_renumbering` says so (Morton order of ``pos`` when
+    given, reverse Cuthill-McKee otherwise)."""
+    ren = None
+    if renumber and want_renumbering(int(num_nodes)):
+        ren = "morton" if (pos is not None and pos.dim() == 2 and pos.shape[1] >= 2 and pos.shape[0] == num_nodes and pos.is_cuda) else "rcm"
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes), str(edge_index.device), ren,
+           (pos.data_ptr(), pos._version) if ren == "morton" else None)
     hit = _topo_cache.get(key)
     if hit is not None and hit[0]() is edge_index:
         return hit[1]
     import weakref
 
-    topo = Topology(edge_index, num_nodes)
+    topo = Topology(edge_index, num_nodes, lazy=True, renumber=ren, pos=pos)
     if len(_topo_cache) > 64:
         _topo_cache.clear()
     try:
@@ -746,14 +888,22 @@ class ProcessorFunction(torch.autograd.Function):
         P = [_f32c(p) for p in params]
         need = any(ctx.needs_input_grad) and _saving()
         f = dict(dtype=torch.float32, device=dev)
+        _require_device(pos if spec.rope else None, phi, rope_inv_freq if spec.rope else None)
         if spec.rope:
             if pos is None:
                 raise ValueError("Node positions `pos` must be provided when use_rope=True.")
             pos = _f32c(pos)
-            if pos.shape[1] < spec.rope_axes:
+            if pos.dim() != 2 or pos.shape[1] < spec.rope_axes:
                 raise ValueError("pos has fewer columns than rope_axes")
+            if pos.shape[0] < N:  # the reference's x[col] / pos[col] indexing would raise here
+                raise IndexError(f"pos has {pos.shape[0]} rows for {N} nodes")
+            if rope_inv_freq is None or rope_inv_freq.numel() != H // (2 * spec.rope_axes):
+                raise ValueError("rope_inv_freq must hold hidden_size // (2 * rope_axes) frequencies")
+            rope_inv_freq = _f32c(rope_inv_freq)
         if phi is not None:
             phi = _f32c(phi).reshape(-1)
+            if phi.numel() != Nn:  # the reference's broadcast of phi [N, 1] against the gate [N, H] would raise
+                raise ValueError(f"phi holds {phi.numel()} values for {Nn} nodes")
         # packed split-bf16 kernels: H = 128, at most 4 layers per MLP
         x6 = (H == 128) and X6_ENABLED and NL <= 4 and L > 0 and E > 0
         # algebraic split of the first edge layer (W0 = [W_e | W_d | W_s]):
@@ -770,7 +920,8 @@ class ProcessorFunction(torch.autograd.Function):
             raise NotImplementedError("the partitioned path runs on the packed H = 128 kernels (no RoPE)")
         # (the fused aggregation's second stage walks a node's tile partials serially: hub topologies take the
         # stand-alone, chunked segment sum instead)
-        fuse_agg = x6 and _os.environ.get("MGN_NO_FUSED_AGG") is None and not topo.has_hubs
+        hubs = topo.begin_use()   # (a fresh lazily-built topology is hub-free for its first pass: Topology docstring)
+        fuse_agg = x6 and _os.environ.get("MGN_NO_FUSED_AGG") is None and not hubs
         relu_bits = x6 and act == 0
         # ---- packed units of all rounds, one launch.  Per round:
         #   edge  [We0|e (, We0|x_dst, We0|x_src with RoPE), We1 .. We_{NL-1}]
@@ -950,6 +1101,8 @@ class ProcessorFunction(torch.autograd.Function):
         P = list(ctx.saved_tensors)
         NL, act, PB = spec.nb_layers, spec.act_id, spec.per_block
         N, E = topo.N, topo.E
+        if not topo.resolved:  # lazily built topology: the forward pass is queued, the flags have long arrived
+            topo.resolve()
         if L == 0:
             return (dx, de, None, None, None, None, None, None, None)
         dev = P[0].device
@@ -970,7 +1123,9 @@ class ProcessorFunction(torch.autograd.Function):
         # tail of the persistent chain kernels, the one-tile node launches).  Its operands (dZ, Sd, Ss) are then
         # double-buffered across rounds and the streams are joined by events.
         side = None
-        if _os.environ.get("MGN_WGRAD_STREAM") is not None and halo is None and not empty and not spec.gate:
+        # (not under activation recompute: a round's recomputed activations are dropped when the loop rebinds S,
+        # while its weight-gradient launch may still read them on the side stream)
+        if _os.environ.get("MGN_WGRAD_STREAM") is not None and halo is None and not empty and not spec.gate and ctx.rerun is None:
             side = _side_stream(dev)
             wsets = [(dZn, dZe, Sd, Ss), ([mk(Nn, H, **f) for _ in range(NL)], [mk(E, H, **f) for _ in range(NL)], mk(N, H, **f), mk(N, H, **f))]
             wdone = [None, None]

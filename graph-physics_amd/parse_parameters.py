@@ -86,3 +86,16 @@ def cylinder_config(message_passing_num: int = 15, hidden_size: int = 128) -> Di
                   "output_index_end": 2, "node_type_index": 2},
         "training": {"use_spatial_mtp": False, "use_temporal_block": False, "enable_vram_optimizations": False},
     }
+
+
+def plate_config(message_passing_num: int = 15, hidden_size: int = 128) -> Dict[str, Any]:
+    """training_config/plate.json run through the message-passing engine (SURVEY.md TL;DR item 2: ``type: "epd"``,
+    ``edge_input_size: 4`` = 3-D Cartesian + distance) under Lightning bf16-mixed (``enable_vram_optimizations``,
+    train.py:74-78) -- BASELINE.json configs[2]."""
+    return {
+        "model": {"type": "epd", "message_passing_num": message_passing_num, "hidden_size": hidden_size,
+                  "node_input_size": 6, "output_size": 3, "edge_input_size": 4},
+        "index": {"feature_index_start": 0, "feature_index_end": 6, "output_index_start": 0, "output_index_end": 3,
+                  "node_type_index": 6},
+        "training": {"use_spatial_mtp": False, "use_temporal_block": False, "enable_vram_optimizations": True},
+    }

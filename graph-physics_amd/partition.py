@@ -315,7 +315,23 @@ class RankPlan:
         return int(self.ghost.numel())
 
 
-def build_rank_plan(edge_index: torch.Tensor, part: np.ndarray, rank: int, world: int) -> RankPlan:
+def morton_keys(pos: np.ndarray) -> np.ndarray:
+    """Morton (Z-order) key of 2-D / 3-D positions on their bounding box (21 bits per axis)"""
+    pos = np.asarray(pos, dtype=np.float64)[:, :3]
+    lo, hi = pos.min(axis=0), pos.max(axis=0)
+    q = ((pos - lo) / np.maximum(hi - lo, 1e-300) * float((1 << 21) - 1)).astype(np.uint64)
+    key = np.zeros(pos.shape[0], dtype=np.uint64)
+    d = pos.shape[1]
+    for b in range(21):
+        for a in range(d):
+            key |= ((q[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(b * d + a)
+    return key
+
+
+def build_rank_plan(edge_index: torch.Tensor, part: np.ndarray, rank: int, world: int, pos: Optional[np.ndarray] = None) -> RankPlan:
+    """``pos`` (optional, [n, 2|3]): the rank's interior and boundary nodes are each numbered along a Morton curve
+    instead of by global id, so that the rows its edge kernels gather are close in memory whatever the global
+    numbering of the mesh is (a mesh generator's ids carry no locality)."""
     ei = edge_index.cpu().numpy()
     part = np.asarray(part)
     n = part.shape[0]
@@ -333,6 +349,12 @@ def build_rank_plan(edge_index: torch.Tensor, part: np.ndarray, rank: int, world
     is_bnd[gdst[remote]] = True
     owned_all = np.nonzero(owned_mask)[0]
     interior, boundary = owned_all[~is_bnd[owned_all]], owned_all[is_bnd[owned_all]]
+    if pos is not None and owned_all.size > 0:
+        mk = morton_keys(np.asarray(pos)[owned_all])
+        mkey = np.zeros(n, dtype=np.uint64)
+        mkey[owned_all] = mk
+        interior = interior[np.argsort(mkey[interior], kind="stable")]
+        boundary = boundary[np.argsort(mkey[boundary], kind="stable")]
     owned = np.concatenate([interior, boundary])
     loc = np.full(n, -1, dtype=np.int64)
     loc[owned] = np.arange(owned.size)

@@ -149,8 +149,8 @@ def add_world_pos_features(graph, world_pos_index_start: int, world_pos_index_en
 def build_preprocessing(noise_parameters=None, world_pos_parameters=None, add_edges_features: bool = True,
                         extra_node_features=None, extra_edge_features=None, seed: int = 0):
     """Device-side ``build_preprocessing`` (preprocessing.py:380-444): the same transform ORDER as the
-    reference -- extra node features, [obstacle next pos,] faces -> edges, [world edges,] edge features
-    [+ world-position edge features], noise inserted at position 1, extra edge features -- as one callable
+    reference -- extra node features, [obstacle next pos,] faces -> edges, [world edges,] edge features,
+    noise inserted at position 1, extra edge features -- as one callable
     ``f(graph, step=0) -> graph`` over device tensors (``graph.face`` [K,F], ``graph.pos``, ``graph.x``,
     ``graph.y``).  Topology-only results (edge_index) can be cached by the caller across a trajectory."""
     steps = []
@@ -176,8 +176,7 @@ def build_preprocessing(noise_parameters=None, world_pos_parameters=None, add_ed
                                            radius=w.get("radius", 0.03))
             return g
         steps.append(world)
-        steps.append(feats)
-        steps.append(lambda g, step: add_world_pos_features(g, w["world_pos_index_start"], w["world_pos_index_end"]))
+        steps.append(feats)   # (the reference's pipeline stops here: add_world_pos_features stays a stand-alone transform, :401-420)
     else:
         steps.append(face_to_edge)
         if add_edges_features:

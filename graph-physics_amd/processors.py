@@ -50,17 +50,24 @@ class EncodeProcessDecode(nn.Module):
         n = graph.x.shape[0]
         topo = getattr(graph, "mgn_topology", None)
         if topo is None:
-            topo = ops.get_topology(edge_index, n)
+            # cached per edge_index; built without a host synchronisation; large meshes are renumbered for locality
+            # (ops.set_node_renumbering) -- node rows are permuted here on entry and back on exit
+            topo = ops.get_topology(edge_index, n, pos=getattr(graph, "pos", None), renumber=True)
         perm = topo.perm_dst.long()
+        order, rank = topo.node_order, topo.node_rank
+        x_in = graph.x if order is None else graph.x.index_select(0, order)
         if self.only_processor:
-            x, e = graph.x, graph.edge_attr[perm]
+            x, e = x_in, graph.edge_attr[perm]
         else:
-            x = self.nodes_encoder(graph.x)
+            x = self.nodes_encoder(x_in)
             # encode edges directly in the engine's dst-sorted order (F_e floats per edge to permute)
             e = self.edges_encoder(graph.edge_attr[perm])
         blocks = list(self.processor_list)
         pos = getattr(graph, "pos", None) if self.use_rope else None
         phi = getattr(graph, "phi", None) if self.use_gate else None
+        if order is not None:
+            pos = pos.index_select(0, order) if pos is not None else None
+            phi = phi.reshape(n, -1).index_select(0, order) if phi is not None else None
         # the temporal block (processors.py:193-209) needs the node latents BEFORE the last round too
         groups = [blocks] if not (self.use_temporal_block and len(blocks) > 1) else [blocks[:-1], blocks[-1:]]
         prev_x = x
@@ -80,7 +87,14 @@ class EncodeProcessDecode(nn.Module):
                                            rope_inv_freq=b0._rope_inv_freq if self.use_rope else None)
         if self.use_temporal_block and self.temporal_block is not None:
             from .transformer import get_attn_topology
+            if rank is not None:  # the attention topology is in the caller's numbering
+                x, prev_x, rank = x.index_select(0, rank), prev_x.index_select(0, rank), None
             x = self.temporal_block(prev_x, x, get_attn_topology(edge_index, n))
-        if self.only_processor:
-            return x
-        return self.decode_module(x)
+        out = x if self.only_processor else self.decode_module(x)
+        if rank is not None:  # back to the caller's numbering (the decoder is row-wise: permute its narrow output)
+            out = out.index_select(0, rank)
+        # every launch of this pass is queued: the wait for a lazily built topology's flags (stray index -> IndexError,
+        # hub tables for later passes) cannot starve the GPU now
+        if not topo.resolved:
+            topo.resolve()
+        return out

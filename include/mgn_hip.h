@@ -65,6 +65,15 @@ size_t mgn_topology_workspace_bytes(int64_t E, int64_t N);
 int mgn_topology_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* perm_dst,
                        int32_t* src_s, int32_t* dst_s, int32_t* rowptr_src, int32_t* perm_src, int32_t* max_degree_host,
                        void* ws, size_t ws_bytes, void* stream);
+/* The same build WITHOUT the host synchronisation (a shuffled loader hands the engine a new edge_index every step,
+ * graphphysics/train.py:160-198: a per-step stream synchronisation costs ~1 ms of a 13 ms step).  flags_dev[4]
+ * (device, int32) receives [0] 1 if an index was outside [0,N), [1] max in-degree, [2] max out-degree; the caller
+ * copies it to the host asynchronously and reads it at its next natural wait.  Every array handed out is safe to
+ * compute on even when [0] is set (edges with a stray index are dropped from both CSRs, rows past the valid count
+ * repeat edge 0, stray node ids read node 0), so launches may be queued before the flag has been looked at. */
+int mgn_topology_build_async(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* perm_dst,
+                             int32_t* src_s, int32_t* dst_s, int32_t* rowptr_src, int32_t* perm_src, int32_t* flags_dev,
+                             void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- segment sum
  * out[i,:] = sum_{k=rowptr[i]}^{rowptr[i+1]-1} src[perm ? perm[k] : k, :]
@@ -321,6 +330,17 @@ int mgn_add_world_edges(const float* x, int x_w, int pos_start, int D, int type_
  * edge_attr[e] = [pos[src]-pos[dst] (D values), ||pos[dst]-pos[src]||_2],  D = 2 or 3. */
 int mgn_edge_features(const float* pos, int D, const int64_t* src, const int64_t* dst, int64_t E,
                       float* edge_attr, void* stream);
+
+/* ------------------------------------------------------------ locality renumbering of the nodes
+ * No reference counterpart (PyTorch gathers x[col], x[row] in whatever numbering the dataset has,
+ * graphphysics/models/layers.py:1017-1018): the engine may renumber the nodes of a mesh along a Morton curve of
+ * their positions so that the 512-byte rows the edge kernels gather sit close together, and un-does it on exit
+ * (ops.Topology(renumber=...), processors.EncodeProcessDecode.forward).  pos: [N, ld] floats, the first D (2 or 3)
+ * columns are coordinates.  order[i] = old id at new position i (ties by old id), rank[old] = new.  Everything on
+ * the device, no host synchronisation. */
+size_t mgn_morton_order_workspace_bytes(int64_t N);
+int mgn_morton_order(const float* pos, int ld, int D, int64_t N, int32_t* order, int32_t* rank, void* ws, size_t ws_bytes,
+                     void* stream);
 
 /* ------------------------------------------------------------ noise injection (N2)
  * add_noise (graphphysics/dataset/preprocessing.py:177-238, wired by build_preprocessing :421-435):

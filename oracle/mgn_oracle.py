@@ -506,7 +506,7 @@ def add_noise_oracle(x, noise_index_start, noise_index_end, noise_scale, node_ty
         raise ValueError("noise_scale must have the same length as noise_index_start and noise_index_end.")
     x = np.array(x, dtype=np.float32, copy=True)
     N = x.shape[0]
-    normal = x[:, node_type_index].astype(np.int64) == NODE_NORMAL
+    normal = x[:, node_type_index] == np.float32(NODE_NORMAL)   # the float is compared (preprocessing.py:219-222)
     rows = np.arange(N, dtype=np.uint64)
     draws = []
     for r, (s0, s1, sc) in enumerate(zip(noise_index_start, noise_index_end, noise_scale)):

@@ -85,9 +85,10 @@ def main():
     for name, c in R.TRANSFORMER_CASES.items():
         H, nh, L, N, seed = c["hidden"], c["heads"], c["L"], c["N"], c["seed"]
         pos, ei, _ = R.delaunay_graph(N, seed, dim=c.get("pos_dim", 3))
-        x_in, cot = R.randn((N, 11), seed + 1), R.randn((N, 2), seed + 3)
+        fin, fout = c.get("f_in", 11), c.get("out", 2)
+        x_in, cot = R.randn((N, fin), seed + 1), R.randn((N, fout), seed + 3)
         if c["model"] == "etd":
-            net = RP.EncodeTransformDecode(message_passing_num=L, node_input_size=11, output_size=2, hidden_size=H, num_heads=nh,
+            net = RP.EncodeTransformDecode(message_passing_num=L, node_input_size=fin, output_size=fout, hidden_size=H, num_heads=nh,
                                            use_rope_embeddings=c.get("rope", False), use_gated_attention=c.get("gate", False),
                                            rope_pos_dimension=c.get("pos_dim", 3), use_temporal_block=c.get("temporal", False))
             params = R.variant_params(net.state_dict(), seed)

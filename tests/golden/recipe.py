@@ -175,4 +175,7 @@ TRANSFORMER_CASES = {
     "etd_h32_heads8_temporal": dict(model="etd", hidden=32, heads=8, L=3, N=100, seed=503, temporal=True),
     "etd_h64_heads2_rope2d": dict(model="etd", hidden=64, heads=2, L=2, N=100, seed=504, rope=True, pos_dim=2),
     "epd_temporal": dict(model="epd", hidden=128, heads=4, L=3, N=120, seed=505),
+    # BASELINE.json configs[4] with training_config/coarse-aneurysm.json:11-22's exact model keys: 10 blocks, hidden 64, 4 heads,
+    # node_input_size 14 (+ 9 one-hot = 23 inputs), output_size 3, on a 3-D tetrahedral mesh
+    "etd_aneurysm": dict(model="etd", hidden=64, heads=4, L=10, N=500, seed=506, f_in=23, out=3, pos_dim=3),
 }

@@ -160,7 +160,8 @@ def test_add_noise_vs_oracle_stream(dev):
 def test_build_preprocessing_widths_like_the_reference_tests(dev):
     """the device-side build_preprocessing: the widths the reference's own tests assert
     (tests/graphphysics/dataset/test_preprocessing.py:52-56,76-90,156-195,182-195): 3-D mesh -> edge_attr
-    width 4; with world positions x gains 3 columns and edge_attr 4 more; noise at position 1 changes
+    width 4; with world positions x gains 3 columns and edge_attr stays 4 wide (the pipeline never calls
+    add_world_pos_features: preprocessing.py:401-420); noise at position 1 changes
     only NORMAL rows."""
     import numpy as np
     from graph_physics_amd import preprocess as PP
@@ -185,9 +186,12 @@ def test_build_preprocessing_widths_like_the_reference_tests(dev):
     # (preprocessing.py:78-80): both transforms read x[:, 6] from then on
     world = {"world_pos_index_start": 0, "world_pos_index_end": 3, "node_type_index": 6, "radius": 0.1}
     g2 = PP.build_preprocessing(dict(noise, node_type_index=6), world, seed=3)(graph(), step=2)
-    assert g2.x.shape[1] == 4 + 3 and g2.edge_attr.shape[1] == 8 and g2.edge_index.shape[1] >= g.edge_index.shape[1]
+    assert g2.x.shape[1] == 4 + 3 and g2.edge_attr.shape[1] == 4 and g2.edge_index.shape[1] >= g.edge_index.shape[1]
     # noise (inserted after add_obstacles_next_pos) touched the first 3 columns of the NORMAL rows only
     moved = (g2.x[:, :3].cpu() - torch.from_numpy(pts)).abs().amax(dim=1) > 0
     assert bool(moved[torch.from_numpy(types == 0)].all()) and not bool(moved[torch.from_numpy(types != 0)].any())
+    # the stand-alone transform (preprocessing.py:143-176) appends the 4 world-position edge features
+    g2b = PP.add_world_pos_features(g2, 0, 3)
+    assert g2b.edge_attr.shape[1] == 8
     g3 = PP.build_preprocessing(noise_parameters=noise)(graph())
     assert g3.edge_attr.shape[1] == 4 and g3.x.shape[1] == 4

@@ -165,3 +165,64 @@ def test_bench_refuses_a_gpus_flag_that_contradicts_the_launch():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(REPO_ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+# ---------------------------------------------------------------- round 3: host logic of the new options
+def test_partitioned_model_refuses_what_it_would_silently_drop():
+    """PartitionedEPD applies neither the temporal block nor RoPE: a model that has them must not construct
+    (the un-partitioned forward would compute another function)."""
+    from graph_physics_amd import distributed as D
+    from graph_physics_amd import partition as P
+
+    pos, ei, _ = R.delaunay_graph(60, 3)
+    plan = P.build_rank_plan(ei, P.partition_nodes(pos.numpy(), ei, 2), 0, 2)
+    with pytest.raises(NotImplementedError, match="temporal"):
+        D.PartitionedEPD(gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_temporal_block=True), plan)
+    with pytest.raises(NotImplementedError, match="rope"):
+        D.PartitionedEPD(gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_rope_embeddings=True, rope_pos_dimension=2), plan)
+    pm = D.PartitionedEPD(gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_gated_attention=True), plan)
+    with pytest.raises(ValueError, match="phi_own"):
+        pm(torch.zeros(plan.n_own, 11), torch.zeros(plan.edge_ids.numel(), 3), phi_own=torch.zeros(plan.n_own + 1))
+
+
+def test_node_renumbering_switch():
+    from graph_physics_amd import ops
+
+    old = ops.get_node_renumbering()
+    try:
+        with pytest.raises(ValueError):
+            ops.set_node_renumbering("maybe")
+        ops.set_node_renumbering("auto")
+        assert not ops.want_renumbering(30160) and ops.want_renumbering(1_000_000)
+        ops.set_node_renumbering("off")
+        assert not ops.want_renumbering(1_000_000)
+        ops.set_node_renumbering("on")
+        assert ops.want_renumbering(10)
+    finally:
+        ops.set_node_renumbering(old)
+
+
+def test_rank_plan_with_positions_keeps_the_contract():
+    """build_rank_plan(pos=...) only changes the ORDER inside the interior / boundary groups (Morton curve instead of
+    global id): same owned set, interior first, same ghosts, same exchange lists up to that order."""
+    import numpy as np
+    from graph_physics_amd import partition as P
+
+    pos, ei, _ = R.delaunay_graph(400, 8)
+    part = P.partition_nodes(pos.numpy(), ei, 4)
+    k = P.morton_keys(pos.numpy())
+    assert k.shape == (400,) and len(np.unique(k)) == 400
+    for r in range(4):
+        a = P.build_rank_plan(ei, part, r, 4)
+        b = P.build_rank_plan(ei, part, r, 4, pos=pos.numpy())
+        assert (a.n_own, a.n_ghost, a.n_interior, a.n_interior_edges) == (b.n_own, b.n_ghost, b.n_interior, b.n_interior_edges)
+        assert sorted(a.owned[:a.n_interior].tolist()) == sorted(b.owned[:b.n_interior].tolist())
+        assert sorted(a.owned[a.n_interior:].tolist()) == sorted(b.owned[b.n_interior:].tolist())
+        assert torch.equal(a.ghost, b.ghost) and a.send_counts == b.send_counts and a.recv_counts == b.recv_counts
+        assert torch.equal(a.edge_ids, b.edge_ids)
+        # the owned rows a peer asks for are the same GLOBAL nodes in the same order
+        assert torch.equal(a.owned[a.send_idx], b.owned[b.send_idx])
+        own_sorted = np.sort(b.owned.numpy())                      # keys are taken on the rank's own bounding box
+        kown = dict(zip(own_sorted.tolist(), P.morton_keys(pos.numpy()[own_sorted]).tolist()))
+        kb = np.array([kown[i] for i in b.owned[:b.n_interior].tolist()], dtype=np.uint64)
+        assert bool((kb[1:] >= kb[:-1]).all())

@@ -1,9 +1,16 @@
-"""GPU, world_size 2: the node-partitioned mesh on the HIP backend -- real kernels AND a real halo
-exchange.  A 1-GPU box cannot run RCCL with two ranks on one device, so both ranks share cuda:0
-and the collectives go over gloo (the all_to_all_single of the halo exchange falls back to
-point-to-point copies through the host there; the partition / halo / gradient-sum logic and the
-kernels are the product's).  Forward, loss and every weight gradient must equal the
-un-partitioned oracle."""
+"""GPU, world_size 2 / 4 / 8: the node-partitioned mesh on the HIP backend -- the PRODUCT halo path
+(``distributed.HaloState`` driven by ``ops.ProcessorFunction(halo=...)``), real kernels and a real
+exchange.  A 1-GPU box cannot run RCCL with several ranks on one device, so all ranks share cuda:0
+(``MGN_SHARE_GPU``-style rehearsal) and the collectives go over gloo (the all_to_all_single of the halo
+exchange falls back to point-to-point copies through the host there; the partition / halo / gradient-sum
+logic and the kernels are the product's).  Forward, loss and every weight gradient must equal the
+un-partitioned oracle, and the gradients must be bit-identical run to run.
+
+The world-4 / world-8 plans are built to hold the shapes an 8-GPU run meets and world 2 cannot:
+  * a rank whose nodes are a mesh component of their own: NO boundary nodes, no ghosts, nothing to send --
+    it still has to enter every collective (empty splits);
+  * peer pairs that exchange nothing (most pairs of a 7-way split of a planar mesh);
+  * ranks with three or more peers."""
 import os
 import socket
 
@@ -18,13 +25,40 @@ from oracle import mgn_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-L, H, N, SEED = 3, 128, 900, 5
+L, H, SEED = 3, 128, 5
 
 
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def _case(world):
+    """(pos, edge_index, part): world 2 -- one Delaunay mesh, coordinate bisection; world >= 4 -- a mesh split
+    world-1 ways plus a SEPARATE small mesh (no edge to the first) that the last rank owns alone."""
+    from graph_physics_amd import partition as P
+
+    n_main = 900 if world == 2 else 260 * (world - 1)
+    pos, ei, _ = R.delaunay_graph(n_main, SEED)
+    if world == 2:
+        return pos, ei, P.partition_nodes(pos.numpy(), ei, 2)
+    pos2, ei2, _ = R.delaunay_graph(150, SEED + 1)
+    part = np.concatenate([P.partition_nodes(pos.numpy(), ei, world - 1), np.full(150, world - 1)])
+    pos_all = torch.cat([pos, pos2 + 10.0])
+    ei_all = torch.cat([ei, ei2 + n_main], dim=1)
+    # shuffle the global numbering: generator ids carry no locality (the plan orders its nodes by position)
+    perm = torch.from_numpy(np.random.default_rng(SEED).permutation(pos_all.shape[0]))
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel())
+    return pos_all[perm], inv[ei_all], part[perm.numpy()]
+
+
+def _inputs(n, e):
+    x_in, e_in = R.randn((n, 11), 1), R.randn((e, 3), 2)
+    tgt = R.randn((n, 2), 3)
+    nt = torch.from_numpy((np.arange(n) % 3 == 0).astype(np.float32) * 5)
+    return x_in, e_in, tgt, nt
 
 
 def _worker(rank, world, port, q):
@@ -35,14 +69,16 @@ def _worker(rank, world, port, q):
     from graph_physics_amd import partition as P
 
     dev = torch.device("cuda:0")
-    pos, ei, ea = R.delaunay_graph(N, SEED)
+    pos, ei, part = _case(world)
+    N = pos.shape[0]
     params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), SEED)
-    x_in, e_in = R.randn((N, 11), 1), R.randn((ei.shape[1], 3), 2)
-    tgt = R.randn((N, 2), 3)
-    nt = torch.from_numpy((np.arange(N) % 3 == 0).astype(np.float32) * 5)
-    part = P.partition_nodes(pos.numpy(), ei, world)
-    plan = P.build_rank_plan(ei, part, rank, world)
-    assert plan.n_ghost > 0 and 0 < plan.n_interior < plan.n_own and 0 < plan.n_interior_edges < plan.edge_ids.numel()
+    x_in, e_in, tgt, nt = _inputs(N, ei.shape[1])
+    plan = P.build_rank_plan(ei, part, rank, world, pos=pos.numpy())
+    n_peers = sum(1 for a, b in zip(plan.send_counts, plan.recv_counts) if a > 0 or b > 0)
+    if world == 2:
+        assert plan.n_ghost > 0 and 0 < plan.n_interior < plan.n_own and 0 < plan.n_interior_edges < plan.edge_ids.numel()
+    elif rank == world - 1:  # the lone component: nothing to exchange at all
+        assert plan.n_ghost == 0 and plan.n_interior == plan.n_own and sum(plan.send_counts) == 0
     net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H).to(dev)
     net.load_state_dict(params)
     pm = D.PartitionedEPD(net, plan)  # default backend: the HIP engine, halo exchange inside the processor node
@@ -58,33 +94,35 @@ def _worker(rank, world, port, q):
         assert torch.equal(runs[0][k], runs[1][k]), k
     D.GradAllReduce(average=False)(net.parameters())
     grads = {k: v.grad.cpu().numpy().copy() for k, v in net.named_parameters()}
-    q.put((rank, plan.owned.numpy().copy(), out.detach().cpu().numpy().copy(), float(loss.detach()), grads))
+    q.put((rank, plan.owned.numpy().copy(), out.detach().cpu().numpy().copy(), float(loss.detach()), grads, n_peers))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_partitioned_hip_two_ranks_equal_unpartitioned_oracle():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_partitioned_hip_ranks_equal_unpartitioned_oracle(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in range(world)]
+    res = [q.get(timeout=900) for _ in range(world)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    pos, ei, ea = R.delaunay_graph(N, SEED)
+    pos, ei, part = _case(world)
+    N = pos.shape[0]
     params = {k: v.clone().requires_grad_(True) for k, v in R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), SEED).items()}
-    x_in, e_in = R.randn((N, 11), 1), R.randn((ei.shape[1], 3), 2)
-    tgt = R.randn((N, 2), 3)
-    nt = torch.from_numpy((np.arange(N) % 3 == 0).astype(np.float32) * 5)
+    x_in, e_in, tgt, nt = _inputs(N, ei.shape[1])
     ref = O.epd_forward(x_in, e_in, ei, params, L)
     ref_loss = O.l2_loss(ref, tgt, nt)
     ref_loss.backward()
     full = torch.zeros_like(ref)
     total = 0.0
-    for rank, owned, out, loss, grads in res:
+    peers = {}
+    for rank, owned, out, loss, grads, n_peers in res:
+        peers[rank] = n_peers
         full[torch.from_numpy(owned)] = torch.from_numpy(out)
         total += loss
         for k, g in grads.items():
@@ -93,3 +131,8 @@ def test_partitioned_hip_two_ranks_equal_unpartitioned_oracle():
             assert err < 3e-4, (rank, k, err)  # the suite's 1e-4-per-round gradient criterion
     assert abs(total - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
     assert float((full - ref.detach()).abs().max() / ref.detach().abs().max()) < 1e-5
+    if world >= 4:
+        assert peers[world - 1] == 0                      # the lone component took part with empty splits (no pair with it exchanges)
+    if world == 8:
+        assert min(peers[r] for r in range(world - 1)) < world - 2   # pairs inside the main mesh that exchange nothing
+        assert max(peers.values()) >= 3                   # a rank with three or more peers

@@ -26,10 +26,11 @@ def _case(name):
 
     c = R.TRANSFORMER_CASES[name]
     H, nh, L, N, seed = c["hidden"], c["heads"], c["L"], c["N"], c["seed"]
-    x_in, cot = R.randn((N, 11), seed + 1), R.randn((N, 2), seed + 3)
+    fin, fout = c.get("f_in", 11), c.get("out", 2)
+    x_in, cot = R.randn((N, fin), seed + 1), R.randn((N, fout), seed + 3)
     if c["model"] == "etd":
         pos, ei, _ = R.delaunay_graph(N, seed, dim=c.get("pos_dim", 3))
-        cfg = {"model": {"type": "transformer", "message_passing_num": L, "hidden_size": H, "node_input_size": 2, "output_size": 2,
+        cfg = {"model": {"type": "transformer", "message_passing_num": L, "hidden_size": H, "node_input_size": fin - 9, "output_size": fout,
                          "edge_input_size": 0, "num_heads": nh, "use_rope_embeddings": c.get("rope", False),
                          "use_gated_attention": c.get("gate", False), "rope_pos_dimension": c.get("pos_dim", 3)},
                "training": {"use_temporal_block": c.get("temporal", False)}}
