@@ -186,10 +186,12 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
 
     ops.mlp_fwd = tm.wrap("edge_fwd", orig[0], lambda a, k: is_edge_fwd(a, k) and len(a) > 10 and a[10] is not None)
     ops.mlp_bwd = tm.wrap("edge_bwd", orig[1], lambda a, k: a[0] == E and a[1] == H and a[4] is not None)
-    ops.wgrad = tm.wrap("wgrad", orig[2], lambda a, k: len(a[0]) >= 8)
+    ops.wgrad = tm.wrap("wgrad", orig[2], lambda a, k: len(a[0]) >= 6)
     ops.segsum2 = tm.wrap("segsum", orig[3], lambda a, k: a[0].shape[0] == E)
     orig_segsum = ops.segsum
     ops.segsum = tm.wrap("segsum_src", orig_segsum, lambda a, k: a[0].shape[0] == E and a[2] is not None)
+    orig_fused = ops.edge_bwd_fused
+    ops.edge_bwd_fused = tm.wrap("edge_bwd_fused", orig_fused, lambda a, k: a[0] == E)
     sync, eng.grad_sync = eng.grad_sync, None  # rank 0 steps alone here: no collective (the timed region is over)
     try:
         for _ in range(steps):
@@ -202,6 +204,7 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
     finally:
         ops.mlp_fwd, ops.mlp_bwd, ops.wgrad, ops.segsum2 = orig
         ops.segsum = orig_segsum
+        ops.edge_bwd_fused = orig_fused
         eng.grad_sync = sync
     traffic, tnote = load_traffic(capi)
     x6 = ops.X6_ENABLED and H == 128
@@ -227,12 +230,26 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
     roof = hbm_obj(f"k_mlp_fwd_{t} (edge update, training mode: W_e.e + gathered node projections, 3 Linear, RMSNorm, "
                    "residual, saves, fused aggregation)", tm.ms("edge_fwd"), b_fwd, traffic.get("edge_fwd_bytes"),
                    dict(mfma(tm.ms("edge_fwd"), nterm if x6 else 1), launches_per_step=per_step("edge_fwd"), traffic_source=tnote))
-    others = [
-        hbm_obj(f"k_mlp_bwd_{t} (edge backward chain: RMSNorm bwd, 3 masked dgrad GEMMs, input grad)", tm.ms("edge_bwd"), b_bwd,
-                traffic.get("edge_bwd_bytes"), dict(mfma(tm.ms("edge_bwd"), nterm if x6 else 1), launches_per_step=per_step("edge_bwd"))),
-        hbm_obj(f"k_wgrad_{'x6' if x6 else 'lds'} + k_wgrad_red (weight gradients of one round: 4 edge + 6..7 node jobs)",
-                tm.ms("wgrad"), b_wg, traffic.get("wgrad_bytes"), {"launches_per_step": per_step("wgrad")}),
-    ]
+    others = []
+    if tm.ms("edge_bwd_fused"):
+        # fused edge backward: reads dE', U, e, H1-3 (6 E-row tensors) + gathered dAgg; writes dE, dZ0; masks, rms, idx;
+        # the per-workgroup partials of dW / db / dscale (256 x 265 KB) written and read once by the reduction
+        b_fz = row * (8 * E + N) + 52.0 * E + 4.0 * E + 2.0 * 256 * 4 * (4 * (H * H + H) + H)
+        tf = tm.ms("edge_bwd_fused")
+        mf = mfma(tf, nterm if x6 else 1)
+        for k_ in ("mfma_achieved_tflops", "mfma_frac", "fp32_equiv_tflops"):   # 8 GEMM units per row: 4 chain + 4 weight-gradient
+            mf[k_] = round(2 * mf[k_], 4 if k_ == "mfma_frac" else 1)
+        others.append(hbm_obj("k_edge_bwd_fused + k_fused_red (edge backward chain AND the four E-row weight gradients of a round in one kernel: "
+                              "dZ1..dZ3 never reach memory; one workgroup per CU, dW accumulators in AGPRs)", tf, b_fz,
+                              traffic.get("edge_bwd_fused_bytes"), dict(mf, launches_per_step=per_step("edge_bwd_fused"))))
+        b_wg = row * (12 * N)                            # the node-row jobs that remain in the weight-gradient launch
+    if tm.ms("edge_bwd"):
+        others.append(hbm_obj(f"k_mlp_bwd_{t} (edge backward chain: RMSNorm bwd, 3 masked dgrad GEMMs, input grad)", tm.ms("edge_bwd"), b_bwd,
+                              traffic.get("edge_bwd_bytes"), dict(mfma(tm.ms("edge_bwd"), nterm if x6 else 1), launches_per_step=per_step("edge_bwd"))))
+    if tm.ms("wgrad"):
+        others.append(hbm_obj(f"k_wgrad_{'x6' if x6 else 'lds'} + k_wgrad_red (weight gradients of one round: "
+                              + ("6..7 node jobs; the E-row jobs run inside the fused edge backward)" if tm.ms("edge_bwd_fused") else "4 edge + 6..7 node jobs)"),
+                              tm.ms("wgrad"), b_wg, traffic.get("wgrad_bytes"), {"launches_per_step": per_step("wgrad")}))
     if tm.ms("edge_inf"):
         others.append(hbm_obj(f"k_mlp_fwd_{t} (edge update, inference mode = the rollout's dominant kernel: nothing saved, "
                               "aggregation fused)", tm.ms("edge_inf"), b_inf, None,

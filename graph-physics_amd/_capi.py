@@ -14,8 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _REPO = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("MGN_LIB") or os.path.join(_CSRC, "libmgn_hip.so")
-SOURCES = [os.path.join(_CSRC, "mgn_kernels.hip"), os.path.join(_CSRC, "mgn_prep.hip"), os.path.join(_CSRC, "mgn_attn.hip")]
-DEPS = [os.path.join(_CSRC, "mgn_x6.inc")]  # included by the source
+SOURCES = [os.path.join(_CSRC, "mgn_kernels.hip"), os.path.join(_CSRC, "mgn_prep.hip"), os.path.join(_CSRC, "mgn_attn.hip"),
+           os.path.join(_CSRC, "mgn_dense.hip")]
+DEPS = [os.path.join(_CSRC, "mgn_x6.inc"), os.path.join(_CSRC, "mgn_fused.inc")]  # included by the source
 HEADER = os.path.join(_REPO, "include", "mgn_hip.h")
 
 MAX_LAYERS = 8
@@ -130,6 +131,26 @@ class SimDesc(C.Structure):
     ]
 
 
+class EdgeBwdFusedArgs(C.Structure):
+    """mgn_edge_bwd_fused_args (include/mgn_hip.h)"""
+    _fields_ = [
+        ("M", C.c_int64), ("dOut", _f32p), ("dAgg", _f32p), ("idx", C.c_void_p), ("U", _f32p), ("R", _f32p), ("scale", _f32p),
+        ("eps", C.c_float), ("X", _f32p * 4), ("Ms", C.c_void_p * 3), ("wpk", C.c_void_p * 4), ("dIn", _f32p), ("dZ0", _f32p),
+        ("dW", _f32p * 4), ("ldw", C.c_int * 4), ("db", _f32p * 4), ("dscale", _f32p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("precision", C.c_int),
+    ]
+
+
+class LinearArgs(C.Structure):
+    """mgn_linear_args (include/mgn_hip.h)"""
+    _fields_ = [
+        ("M", C.c_int64), ("x", _f32p), ("ldx", C.c_int), ("K1", C.c_int), ("x2", _f32p), ("ldx2", C.c_int), ("K2", C.c_int),
+        ("norm_scale", _f32p), ("eps", C.c_float), ("inv_out", _f32p), ("n_out", _f32p), ("W", _f32p), ("ldw", C.c_int), ("b", _f32p),
+        ("W2", _f32p), ("b2", _f32p), ("act", C.c_int), ("N", C.c_int), ("resid", _f32p), ("ldr", C.c_int), ("out", _f32p),
+        ("ldo", C.c_int), ("saveZ1", _f32p), ("saveZ2", _f32p), ("precision", C.c_int),
+    ]
+
+
 class OptTensor(C.Structure):
     _fields_ = [("p", _f32p), ("g", _f32p), ("m", _f32p), ("v", _f32p), ("n", C.c_int64)]
 
@@ -159,6 +180,8 @@ SYMBOLS = {
     "mgn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(WgradJob)]),
     "mgn_wgrad": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_wgrad_p": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "mgn_edge_bwd_fused_workspace_bytes": (C.c_size_t, []),
+    "mgn_edge_bwd_fused": (C.c_int, [C.POINTER(EdgeBwdFusedArgs), C.c_void_p]),
     "mgn_debug_occupancy": (C.c_int, [C.POINTER(C.c_int)]),
     "mgn_transpose_blocks": (C.c_int, [C.c_int, C.POINTER(TBlock), C.c_int, C.c_void_p]),
     "mgn_wpack": (C.c_int, [C.c_int, C.POINTER(WpackBlock), C.c_void_p]),
@@ -191,7 +214,15 @@ SYMBOLS = {
     "mgn_prep_last_error": (C.c_char_p, []),
     "mgn_sparse_attn_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgn_sparse_attn_bwd": (C.c_int, [C.c_void_p] * 11 + [C.c_int64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]),
+    "mgn_sparse_attn_weights": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mgn_attn_last_error": (C.c_char_p, []),
+    "mgn_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    "mgn_act_gate_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgn_rownorm_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgn_rownorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "mgn_rownorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                  C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_dense_last_error": (C.c_char_p, []),
 }
 
 _lib = None
@@ -303,8 +334,8 @@ def lib():
     return _lib
 
 
-def check(rc: int, what: str, prep: bool = False, attn: bool = False):
+def check(rc: int, what: str, prep: bool = False, attn: bool = False, dense: bool = False):
     if rc != 0:
-        fn = lib().mgn_attn_last_error if attn else (lib().mgn_prep_last_error if prep else lib().mgn_last_error)
+        fn = lib().mgn_dense_last_error if dense else (lib().mgn_attn_last_error if attn else (lib().mgn_prep_last_error if prep else lib().mgn_last_error))
         msg = fn().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")

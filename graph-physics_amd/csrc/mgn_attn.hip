@@ -169,6 +169,33 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
   *(float4*)(dv + (size_t)j * H + 4 * l) = make_float4(av[0], av[1], av[2], av[3]);
 }
 
+// attention weights per edge and head (return_attention=True, layers.py:543-559): a[e,h] = exp(score[e,h] - lse[i_e,h]),
+// written at out_pos[e] (the edge's position in the caller's edge_index; NULL: the row-sorted position itself)
+template <int LPR>
+__global__ void __launch_bounds__(256) k_attn_weights(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ lse,
+                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                     const int32_t* __restrict__ out_pos, long N, int NH, float scale, float* __restrict__ a_out) {
+  constexpr int H = 4 * LPR;
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const int l = threadIdx.x % LPR;
+  if (i >= N) return;
+  const size_t ro = (size_t)i * H + 4 * l;
+  const float4 qv = *(const float4*)(q + ro), lv = *(const float4*)(lse + ro);
+  const float qq[4] = {qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale}, ls[4] = {lv.x, lv.y, lv.z, lv.w};
+  const int gs = (NH >= 4) ? (NH >> 2) : 1;
+  const int nr = (NH >= 4) ? 4 : NH;
+  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    const size_t j = (size_t)col[e];
+    const float4 kv = *(const float4*)(k + j * H + 4 * l);
+    float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
+    head_reduce<LPR>(p, NH);
+    const size_t o = (size_t)(out_pos != nullptr ? out_pos[e] : e) * NH;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (l < gs && r < nr) a_out[o + 4 * l + r] = expf(p[r] - ls[r]);
+  }
+}
+
 static int attn_args_ok(int64_t N, int H, int NH) {
   if (N < 0) return 0;
   if (!(H == 16 || H == 32 || H == 64 || H == 128)) return 0;
@@ -211,4 +238,14 @@ extern "C" int mgn_sparse_attn_bwd(const float* q, const float* k, const float* 
   ATTN_DISPATCH(k_attn_bwd_row, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, dq, a_e, ds_e);
   ATTN_DISPATCH(k_attn_bwd_col, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, row_of_edge, (long)N, num_heads, scale, dk, dv);
   return acheck("mgn_sparse_attn_bwd");
+}
+
+extern "C" int mgn_sparse_attn_weights(const float* q, const float* k, const float* lse, const int32_t* rowptr, const int32_t* col,
+                                       const int32_t* out_pos, int64_t N, int H, int num_heads, float* attn, void* stream) {
+  if (!attn_args_ok(N, H, num_heads) || lse == nullptr || attn == nullptr) return afail(1, "mgn_sparse_attn_weights: bad arguments");
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const float scale = 1.0f / sqrtf((float)(H / num_heads));
+  ATTN_DISPATCH(k_attn_weights, q, k, lse, rowptr, col, out_pos, (long)N, num_heads, scale, attn);
+  return acheck("mgn_sparse_attn_weights");
 }

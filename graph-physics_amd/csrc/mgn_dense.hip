@@ -1,0 +1,328 @@
+// MI355X (gfx950) dense row kernels of the sparse-attention Transformer processor (BASELINE.json
+// configs[4]): everything of a Transformer block that is not the sparse attention itself --
+//     x + proj(attn(q, k, v)),  q/k/v = Linear(norm1(x));     x + W3 (act(W1 n + b1) * (W2 n + b2)) + b3,  n = norm2(x)
+// (graphphysics/models/layers.py:564-697 Attention, :700-819 Transformer, :213-278 GatedMLP / build_gated_mlp,
+// :73-129 RMSNorm) -- as fused launches: the RMSNorm is a PROLOGUE of the product that consumes it (the row is in
+// registers anyway), the activation / gated product / bias / residual its EPILOGUE; a concatenated input
+// (TemporalAttention's cat([h_pred, h_prev]), layers.py:858-887) is two input phases and is never materialised.
+//
+// Arithmetic: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) in the T-layout of the generic MLP kernels: a wave owns 16
+// rows, lane (c,g) holds features 16 kb + 4g + {0..3} of row c -- the B operand of four K = 4 steps -- and the weight
+// fragment W[16 ob + c][16 kb + 4g + r] (one 16-byte load per lane, L2-resident: a block's matrices are 16-150 KB) is the A
+// operand; the accumulator comes out as output features 16 ob + 4g + {0..3} of row c = one 16-byte store.  Node-row
+// work at hidden 64 (configs[4]): 6 products of 2 x 64 x 64..192 flop per row against ~1.5 KB of row traffic --
+// HBM-bound, so the exact-fp32 rate (157 TF/s) is not what limits it.  precision = 1 rounds the operands and each
+// result to bf16 (the reference under Lightning bf16-mixed: autocast runs nn.Linear in bf16, train.py:74-78; the
+// sparse attention itself stays fp32, layers.py:49-70).
+// Fourth translation unit of libmgn_hip.so.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "mgn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+static thread_local char g_derr[256] = "";
+extern "C" const char* mgn_dense_last_error(void) { return g_derr; }
+static int dfail(int code, const char* msg) {
+  snprintf(g_derr, sizeof(g_derr), "%s", msg);
+  return code;
+}
+static int dcheck(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_derr, sizeof(g_derr), "%s: %s", what, hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
+__device__ __forceinline__ float bf16r(float v) {  // round to nearest even bf16, returned as fp32
+  unsigned u = __float_as_uint(v);
+  if ((u & 0x7f800000u) == 0x7f800000u) return v;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xffff0000u);
+}
+__device__ __forceinline__ f32x4 bf16r4(f32x4 v) { return f32x4{bf16r(v[0]), bf16r(v[1]), bf16r(v[2]), bf16r(v[3])}; }
+__device__ __forceinline__ float d_silu(float z) { return z / (1.0f + expf(-z)); }
+__device__ __forceinline__ float d_dsilu(float z) {
+  const float sg = 1.0f / (1.0f + expf(-z));
+  return sg * (1.0f + z * (1.0f - sg));
+}
+__device__ __forceinline__ float d_gelu(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float d_dgelu(float z) {
+  return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * expf(-0.5f * z * z);
+}
+__device__ __forceinline__ float d_act(float z, int act) {
+  return act == MGN_ACT_RELU ? fmaxf(z, 0.f) : act == MGN_ACT_SILU ? d_silu(z) : act == MGN_ACT_GELU ? d_gelu(z) : z;
+}
+__device__ __forceinline__ float d_dact(float z, int act) {
+  return act == MGN_ACT_RELU ? (z > 0.f ? 1.f : 0.f) : act == MGN_ACT_SILU ? d_dsilu(z) : act == MGN_ACT_GELU ? d_dgelu(z) : 1.f;
+}
+__device__ __forceinline__ float rowsum4d(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// ------------------------------------------------------------------ fused linear layer
+// KB = input blocks of 16 features (both phases together); 64 rows per workgroup, 16 per wave.
+template <int KB>
+__global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const long m = ((long)blockIdx.x * 4 + wv) * 16 + c;
+  const bool valid = m < a.M;
+  const long mm = valid ? m : a.M - 1;
+  const int K = 16 * KB, kb1 = a.K1 >> 4;
+  f32x4 in[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+    in[kb] = (kb < kb1) ? *(const f32x4*)(a.x + mm * a.ldx + 16 * kb + 4 * g) : *(const f32x4*)(a.x2 + mm * a.ldx2 + 16 * (kb - kb1) + 4 * g);
+  if (a.norm_scale != nullptr) {  // RMSNorm prologue, reference epsilon placement: scale * x / (||x|| / sqrt(K) + eps)
+    float ss = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ss = fmaf(in[kb][r], in[kb][r], ss);
+    ss = rowsum4d(ss);
+    const float inv = 1.0f / (sqrtf(ss) / sqrtf((float)K) + a.eps);
+    if (a.inv_out != nullptr && valid && g == 0) a.inv_out[mm] = inv;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) in[kb] = *(const f32x4*)(a.norm_scale + 16 * kb + 4 * g) * (in[kb] * inv);
+    if (a.n_out != nullptr && valid) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) *(f32x4*)(a.n_out + mm * K + 16 * kb + 4 * g) = in[kb];
+    }
+  }
+  const bool bf = a.precision == 1;
+  if (bf) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) in[kb] = bf16r4(in[kb]);
+  }
+  const int NB = a.N >> 4;
+  const bool gate = a.W2 != nullptr;
+  for (int ob = 0; ob < NB; ++ob) {
+    const int n0 = 16 * ob + 4 * g;
+    f32x4 acc = (a.b != nullptr) ? *(const f32x4*)(a.b + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc2 = (gate && a.b2 != nullptr) ? *(const f32x4*)(a.b2 + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bf) acc = bf16r4(acc), acc2 = bf16r4(acc2);
+    const float* w1 = a.W + (size_t)(16 * ob + c) * a.ldw + 4 * g;
+    const float* w2 = gate ? a.W2 + (size_t)(16 * ob + c) * a.ldw + 4 * g : nullptr;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      f32x4 wa = *(const f32x4*)(w1 + 16 * kb);
+      if (bf) wa = bf16r4(wa);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = MFMA16(wa[r], in[kb][r], acc);
+      if (gate) {
+        f32x4 wb = *(const f32x4*)(w2 + 16 * kb);
+        if (bf) wb = bf16r4(wb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc2 = MFMA16(wb[r], in[kb][r], acc2);
+      }
+    }
+    if (bf) acc = bf16r4(acc), acc2 = bf16r4(acc2);   // a bf16 nn.Linear returns bf16
+    if (valid) {
+      if (a.saveZ1 != nullptr) *(f32x4*)(a.saveZ1 + mm * a.N + n0) = acc;
+      if (gate && a.saveZ2 != nullptr) *(f32x4*)(a.saveZ2 + mm * a.N + n0) = acc2;
+    }
+    f32x4 y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = d_act(acc[r], a.act);
+    if (bf && a.act >= 0) y = bf16r4(y);
+    if (gate) {
+      y = y * acc2;
+      if (bf) y = bf16r4(y);
+    }
+    if (a.resid != nullptr) y = *(const f32x4*)(a.resid + mm * a.ldr + n0) + y;   // the residual stream stays fp32
+    if (valid) *(f32x4*)(a.out + mm * a.ldo + n0) = y;
+  }
+}
+
+extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
+  const mgn_linear_args& a = *args;
+  if (a.M < 0 || a.x == nullptr || a.W == nullptr || a.out == nullptr) return dfail(1, "mgn_linear_fwd: missing operand");
+  const int K = a.K1 + a.K2;
+  if (a.K1 < 16 || (a.K1 & 15) || a.K2 < 0 || (a.K2 & 15) || K > 384 || (a.K2 > 0 && a.x2 == nullptr))
+    return dfail(1, "mgn_linear_fwd: input widths must be multiples of 16, at most 384 together");
+  if (a.N < 16 || (a.N & 15) || a.N > 1024) return dfail(1, "mgn_linear_fwd: output width must be a multiple of 16");
+  if (a.ldx < a.K1 || (a.ldx & 3) || (a.K2 > 0 && (a.ldx2 < a.K2 || (a.ldx2 & 3))) || a.ldw < K || (a.ldw & 3) || a.ldo < a.N || (a.ldo & 3) ||
+      (a.resid != nullptr && (a.ldr < a.N || (a.ldr & 3))))
+    return dfail(1, "mgn_linear_fwd: leading dimensions must cover the widths and keep rows 16-byte aligned");
+  if (a.act < -1 || a.act > MGN_ACT_GELU) return dfail(1, "mgn_linear_fwd: act must be MGN_ACT_NONE, _RELU, _SILU or _GELU");
+  if (a.precision != 0 && a.precision != 1) return dfail(1, "mgn_linear_fwd: precision must be 0 or 1");
+  if (a.M == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((a.M + 63) / 64);
+  switch (K >> 4) {
+#define LIN_CASE(KB_) case KB_: hipLaunchKernelGGL(k_linear<KB_>, dim3(grid), dim3(256), 0, s, a); break;
+    LIN_CASE(1) LIN_CASE(2) LIN_CASE(3) LIN_CASE(4) LIN_CASE(6) LIN_CASE(8) LIN_CASE(12) LIN_CASE(16) LIN_CASE(24)
+#undef LIN_CASE
+    default: return dfail(1, "mgn_linear_fwd: total input width must be 16, 32, 48, 64, 96, 128, 192, 256 or 384");
+  }
+  return dcheck("mgn_linear_fwd");
+}
+
+// ------------------------------------------------------------------ activation / gated-product backward
+// dZ1 = dP * (Z2 or 1) * act'(Z1);  dZ2 = dP * act(Z1)      (elementwise over [M, N], 16-byte lanes)
+__global__ void __launch_bounds__(256) k_act_gate_bwd(const float* __restrict__ dP, const float* __restrict__ Z1, const float* __restrict__ Z2,
+                                                     long n4, int act, int bf, float* __restrict__ dZ1, float* __restrict__ dZ2) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 d = ((const f32x4*)dP)[i], z1 = ((const f32x4*)Z1)[i];
+  f32x4 z2 = f32x4{1.f, 1.f, 1.f, 1.f};
+  if (Z2 != nullptr) z2 = ((const f32x4*)Z2)[i];
+  f32x4 a1, a2;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float h = d_act(z1[r], act);
+    if (bf) h = bf16r(h);
+    a1[r] = d[r] * z2[r] * d_dact(z1[r], act);
+    a2[r] = d[r] * h;
+  }
+  if (bf) a1 = bf16r4(a1), a2 = bf16r4(a2);
+  ((f32x4*)dZ1)[i] = a1;
+  if (dZ2 != nullptr) ((f32x4*)dZ2)[i] = a2;
+}
+
+extern "C" int mgn_act_gate_bwd(const float* dP, const float* Z1, const float* Z2, int64_t M, int N, int act, int precision, float* dZ1,
+                                float* dZ2, void* stream) {
+  if (M < 0 || N < 4 || (N & 3) || dP == nullptr || Z1 == nullptr || dZ1 == nullptr || (Z2 != nullptr && dZ2 == nullptr) || act < -1 ||
+      act > MGN_ACT_GELU)
+    return dfail(1, "mgn_act_gate_bwd: bad arguments");
+  const long n4 = (long)M * N / 4;
+  if (n4 == 0) return 0;
+  hipLaunchKernelGGL(k_act_gate_bwd, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dP, Z1, Z2, n4, act, precision, dZ1, dZ2);
+  return dcheck("mgn_act_gate_bwd");
+}
+
+// ------------------------------------------------------------------ stand-alone RMSNorm (layers.py:73-129)
+// y = scale * x / (||x|| / sqrt(K) + eps) per row; one wave per row pass (the Transformer's norm2 feeds a gated MLP that
+// starts with a norm of its own, layers.py:256-278: the outer one cannot be a prologue)
+template <int KPL>
+__global__ void __launch_bounds__(256) k_rownorm_fwd(const float* __restrict__ x, int ldx, int K, const float* __restrict__ scale, float eps, long M,
+                                                    float* __restrict__ y, float* __restrict__ inv_out) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (long m = (long)blockIdx.x * 4 + wv; m < M; m += (long)gridDim.x * 4) {
+    float xv[KPL];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const int k = lane + 64 * j;
+      xv[j] = (k < K) ? x[m * ldx + k] : 0.f;
+      ss = fmaf(xv[j], xv[j], ss);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float inv = 1.0f / (sqrtf(ss) / sqrtf((float)K) + eps);
+    if (inv_out != nullptr && lane == 0) inv_out[m] = inv;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const int k = lane + 64 * j;
+      if (k < K) y[m * K + k] = scale[k] * (xv[j] * inv);
+    }
+  }
+}
+extern "C" int mgn_rownorm_fwd(const float* x, int ldx, int K, const float* scale, float eps, int64_t M, float* y, float* inv_out, void* stream) {
+  if (M < 0 || x == nullptr || scale == nullptr || y == nullptr || K < 1 || K > 384 || ldx < K) return dfail(1, "mgn_rownorm_fwd: bad arguments (at most 384 columns)");
+  if (M == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned grid = (unsigned)((M + 3) / 4);
+  if (grid > 2048) grid = 2048;
+  switch ((K + 63) / 64) {
+#define RF_CASE(P_) case P_: hipLaunchKernelGGL(k_rownorm_fwd<P_>, dim3(grid), dim3(256), 0, s, x, ldx, K, scale, eps, (long)M, y, inv_out); break;
+    RF_CASE(1) RF_CASE(2) RF_CASE(3) RF_CASE(4) RF_CASE(5) RF_CASE(6)
+#undef RF_CASE
+    default: return dfail(1, "mgn_rownorm_fwd: width out of range");
+  }
+  return dcheck("mgn_rownorm_fwd");
+}
+
+// ------------------------------------------------------------------ RMSNorm-prologue backward
+// n = s * x c, c = 1 / (||x|| / sqrt(K) + eps):   dx = c g - x c^2 <g, x> / (K r),  g = s dn,  r = ||x|| / sqrt(K);
+// dscale partial of the workgroup's rows: sum_rows dn * x c.   One wave per row pass, lane l owns columns l, l + 64, ...
+template <int KPL>  // columns per lane (K / 64 rounded up)
+__global__ void __launch_bounds__(256) k_rownorm_bwd(const float* __restrict__ dn, const float* __restrict__ x, int ldx, const float* __restrict__ x2,
+                                                    int ldx2, int K1, int K, const float* __restrict__ inv, const float* __restrict__ scale,
+                                                    float eps, long M, float* __restrict__ dx, int lddx, float* __restrict__ dx2, int lddx2,
+                                                    float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float ds[KPL];
+  float sc[KPL];
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) {
+    ds[j] = 0.f;
+    const int k = lane + 64 * j;
+    sc[j] = (k < K) ? scale[k] : 0.f;
+  }
+  for (long m = (long)blockIdx.x * 4 + wv; m < M; m += (long)gridDim.x * 4) {
+    float xv[KPL], gv[KPL];
+    float dot = 0.f;
+    const float c = inv[m];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const int k = lane + 64 * j;
+      xv[j] = 0.f, gv[j] = 0.f;
+      if (k < K) {
+        xv[j] = (k < K1) ? x[m * ldx + k] : x2[m * ldx2 + (k - K1)];
+        const float d = dn[m * K + k];
+        ds[j] += d * xv[j] * c;
+        gv[j] = sc[j] * d;
+        dot = fmaf(gv[j], xv[j], dot);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    const float r = 1.0f / c - eps;                       // ||x|| / sqrt(K)
+    const float k2 = (r > 0.f) ? c * c * dot / ((float)K * r) : 0.f;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const int k = lane + 64 * j;
+      if (k < K) {
+        const float v = c * gv[j] - xv[j] * k2;
+        if (k < K1) dx[m * lddx + k] = v;
+        else dx2[m * lddx2 + (k - K1)] = v;
+      }
+    }
+  }
+  __shared__ float red[4][64 * KPL];
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) red[wv][lane + 64 * j] = ds[j];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256) part[(size_t)blockIdx.x * K + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+}
+__global__ void __launch_bounds__(256) k_colsum_parts(const float* __restrict__ part, int nparts, int K, float* __restrict__ out) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * K + k];   // fixed order: deterministic
+  out[k] = s;
+}
+
+#define RN_GRID 512
+extern "C" size_t mgn_rownorm_bwd_workspace_bytes(int K) { return (size_t)RN_GRID * (K > 0 ? K : 0) * sizeof(float); }
+extern "C" int mgn_rownorm_bwd(const float* dn, const float* x, int ldx, const float* x2, int ldx2, int K1, int K2, const float* inv,
+                               const float* scale, float eps, int64_t M, float* dx, int lddx, float* dx2, int lddx2, float* dscale, void* ws,
+                               size_t ws_bytes, void* stream) {
+  const int K = K1 + K2;
+  if (M < 0 || dn == nullptr || x == nullptr || inv == nullptr || scale == nullptr || dx == nullptr || dscale == nullptr || K1 < 1 || K2 < 0 ||
+      K > 384 || (K2 > 0 && (x2 == nullptr || dx2 == nullptr)))
+    return dfail(1, "mgn_rownorm_bwd: bad arguments (at most 384 columns)");
+  if (ws == nullptr || ws_bytes < mgn_rownorm_bwd_workspace_bytes(K)) return dfail(1, "mgn_rownorm_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned grid = (unsigned)((M + 3) / 4);
+  if (grid > RN_GRID) grid = RN_GRID;
+  if (grid == 0) grid = 1;
+  float* part = (float*)ws;
+  const int kpl = (K + 63) / 64;
+  switch (kpl) {
+#define RN_CASE(P_) case P_: hipLaunchKernelGGL(k_rownorm_bwd<P_>, dim3(grid), dim3(256), 0, s, dn, x, ldx, x2, ldx2, K1, K, inv, scale, eps, (long)M, dx, lddx, dx2, lddx2, part); break;
+    RN_CASE(1) RN_CASE(2) RN_CASE(3) RN_CASE(4) RN_CASE(5) RN_CASE(6)
+#undef RN_CASE
+    default: return dfail(1, "mgn_rownorm_bwd: width out of range");
+  }
+  hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, (const float*)part, (int)grid, K, dscale);
+  return dcheck("mgn_rownorm_bwd");
+}

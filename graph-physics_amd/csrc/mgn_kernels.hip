@@ -248,7 +248,16 @@ __device__ __forceinline__ float dsilu_f(float z) {
   const float sg = 1.0f / (1.0f + expf(-z));
   return sg * (1.0f + z * (1.0f - sg));
 }
-__device__ __forceinline__ float act_f(float z, int act) { return act == MGN_ACT_SILU ? silu_f(z) : fmaxf(z, 0.f); }
+// GELU (nn.GELU(), exact erf form; build_mlp(act="gelu"), layers.py:150-160): z Phi(z); derivative Phi(z) + z phi(z).
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float z) {
+  return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * expf(-0.5f * z * z);
+}
+__device__ __forceinline__ bool act_smooth(int act) { return act != MGN_ACT_RELU; }  // needs the saved PRE-activations
+__device__ __forceinline__ float act_f(float z, int act) {
+  return act == MGN_ACT_SILU ? silu_f(z) : (act == MGN_ACT_GELU ? gelu_f(z) : fmaxf(z, 0.f));
+}
+__device__ __forceinline__ float dact_f(float z, int act) { return act == MGN_ACT_GELU ? dgelu_f(z) : dsilu_f(z); }
 
 // ========================================================================= forward
 template <int HB, int MT, bool RAGGED>
@@ -309,7 +318,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_ml
         for (int t = 0; t < MT; ++t) nx[t] = sp + (ip ? (long)ip[mm[t]] : mm[t]) * H + 4 * g;
       }
     } else {  // layer l >= 1: the accumulator IS the next B operand
-      if (a.act == MGN_ACT_SILU && a.saveZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.saveZ[l - 1], acc, H, mm, valid, g);
+      if (act_smooth(a.act) && a.saveZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.saveZ[l - 1], acc, H, mm, valid, g);
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -496,14 +505,14 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
 #pragma unroll
         for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
       gemm_tl<HB, MT>(acc, dz, a.WT[l], 16 * nkb_last, HB, nkb_last, c, g);
-      load_tl<HB, MT, RAGGED>(dz, (a.act == MGN_ACT_SILU) ? a.Zs[l - 1] : a.Hs[l - 1], nullptr, H, mm, g, nkb);
+      load_tl<HB, MT, RAGGED>(dz, act_smooth(a.act) ? a.Zs[l - 1] : a.Hs[l - 1], nullptr, H, mm, g, nkb);
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int ib = 0; ib < HB; ++ib)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            dz[t][ib][r] = !valid[t] ? 0.f : (a.act == MGN_ACT_SILU) ? acc[t][ib][r] * dsilu_f(dz[t][ib][r])
+            dz[t][ib][r] = !valid[t] ? 0.f : act_smooth(a.act) ? acc[t][ib][r] * dact_f(dz[t][ib][r], a.act)
                                                                        : (dz[t][ib][r] > 0.f ? acc[t][ib][r] : 0.f);
       if (a.dZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.dZ[l - 1], dz, H, mm, valid, g);
       if (a.db[l - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
@@ -522,7 +531,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
 #pragma unroll
           for (int ib = 0; ib < HB; ++ib) acc[t][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
         Wp = a.WT[l];
-        const float* hz = (a.act == MGN_ACT_SILU) ? a.Zs[l - 1] : a.Hs[l - 1];
+        const float* hz = act_smooth(a.act) ? a.Zs[l - 1] : a.Hs[l - 1];
 #pragma unroll
         for (int t = 0; t < MT; ++t) nx[t] = hz + mm[t] * H + 4 * g;  // dz <- h_l (ReLU) / z_l (SiLU) on the way out
       } else {
@@ -554,7 +563,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
           for (int ib = 0; ib < HB; ++ib)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              dz[t][ib][r] = !valid[t] ? 0.f : (a.act == MGN_ACT_SILU) ? acc[t][ib][r] * dsilu_f(dz[t][ib][r])
+              dz[t][ib][r] = !valid[t] ? 0.f : act_smooth(a.act) ? acc[t][ib][r] * dact_f(dz[t][ib][r], a.act)
                                                                          : (dz[t][ib][r] > 0.f ? acc[t][ib][r] : 0.f);
         if (a.dZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.dZ[l - 1], dz, H, mm, valid, g);
         if (a.db[l - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
@@ -1542,6 +1551,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
 }
 
 #include "mgn_x6.inc"
+#include "mgn_fused.inc"
 
 // dW[r,k] = sum over the job's workgroup partials.  64 outputs x 4 partial-lanes per block:
 // consecutive threads read consecutive addresses of one partial (coalesced), four lanes walk
@@ -1828,10 +1838,11 @@ static bool fwd_ragged(const mgn_mlp_fwd_args& a) {
   return r;
 }
 
-static MlpPlan plan_mlp(int64_t M, int H, int NL, bool ragged, bool bwd) {
+static MlpPlan plan_mlp(int64_t M, int H, int NL, bool ragged, bool bwd, int act = MGN_ACT_RELU) {
   MlpPlan p;
   p.lds = (H == 128) && !ragged && NL >= (bwd ? 2 : 1) && NL <= LDS_MAX_NL;
   if (getenv("MGN_NO_LDS") != nullptr) p.lds = false;
+  if (act == MGN_ACT_GELU) p.lds = false;  // GELU lives on the generic kernels only (a stand-alone build_mlp option)
   p.mt = (M >= (int64_t)64 * 2048) ? 2 : 1;
   // measured on MI355X (tools/kbench.py, E = 180k): with LDS-shared weights the forward is
   // faster at 16 rows per wave (172 VGPRs, no spills: 352 vs 368 us), the backward chain at 32
@@ -1894,7 +1905,7 @@ static int fwd_static_shape(const mgn_mlp_fwd_args& a) {
 template <int HB>
 static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
   const bool ragged = fwd_ragged(a);
-  const MlpPlan p = plan_mlp(a.M, a.H, a.NL, ragged, false);
+  const MlpPlan p = plan_mlp(a.M, a.H, a.NL, ragged, false, a.act);
   if (p.lds && fwd_x6(a)) {
     // 8-wave workgroups (one per CU) when every CU still gets a tile; MGN_NW=4/8 overrides
     int nw = (a.M >= 128 * 256) ? X6_FWD_NW_LARGE : 4;
@@ -1999,7 +2010,7 @@ static bool bwd_x6(const mgn_mlp_bwd_args& a) {
 
 template <int HB>
 static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
-  MlpPlan p = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true);
+  MlpPlan p = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true, a.act);
   if (p.lds && bwd_x6(a)) {
     static thread_local bool attr_done = false;
     if (!attr_done) {
@@ -2210,6 +2221,39 @@ int mgn_topology_build_async(const int64_t* src, const int64_t* dst, int64_t E, 
   return topology_enqueue(src, dst, E, N, rowptr_dst, perm_dst, src_s, dst_s, rowptr_src, perm_src, flags_dev, ws, ws_bytes, (hipStream_t)stream);
 }
 
+#define FZ_GRID 256  /* one workgroup per CU (the accumulators take the whole register file) */
+size_t mgn_edge_bwd_fused_workspace_bytes(void) { return (size_t)FZ_GRID * FZ_PART_FLOATS * sizeof(float); }
+
+int mgn_edge_bwd_fused(const mgn_edge_bwd_fused_args* args, void* stream) {
+  const mgn_edge_bwd_fused_args& a = *args;
+  hipStream_t s = (hipStream_t)stream;
+  if (a.M < 0 || a.dOut == nullptr || a.dAgg == nullptr || a.idx == nullptr || a.U == nullptr || a.R == nullptr || a.scale == nullptr ||
+      a.dIn == nullptr)
+    return fail(1, "mgn_edge_bwd_fused: missing operand");
+  for (int l = 0; l < 4; ++l)
+    if (a.X[l] == nullptr || a.wpk[l] == nullptr || (a.dW[l] != nullptr && a.ldw[l] < 128)) return fail(1, "mgn_edge_bwd_fused: missing layer operand");
+  for (int l = 0; l < 3; ++l)
+    if (a.Ms[l] == nullptr) return fail(1, "mgn_edge_bwd_fused: missing ReLU mask words");
+  if (a.precision != 0 && a.precision != 1) return fail(1, "mgn_edge_bwd_fused: precision must be 0 or 1");
+  if (a.ws == nullptr || a.ws_bytes < mgn_edge_bwd_fused_workspace_bytes()) return fail(1, "mgn_edge_bwd_fused: workspace too small");
+  static thread_local bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)k_edge_bwd_fused<6>, hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_edge_bwd_fused<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS_BYTES) != hipSuccess)
+      return fail(2, "mgn_edge_bwd_fused: cannot reserve LDS");
+    attr_done = true;
+  }
+  const long ntiles = (a.M + 63) / 64;
+  unsigned grid = (unsigned)(ntiles < FZ_GRID ? ntiles : FZ_GRID);
+  if (grid == 0) grid = 1;  // M == 0: one workgroup writes zero partials
+  if (a.precision == 1)
+    hipLaunchKernelGGL((k_edge_bwd_fused<1>), dim3(grid), dim3(256), FZ_LDS_BYTES, s, a);
+  else
+    hipLaunchKernelGGL((k_edge_bwd_fused<6>), dim3(grid), dim3(256), FZ_LDS_BYTES, s, a);
+  hipLaunchKernelGGL(k_fused_red, dim3((FZ_PART_FLOATS + 63) / 64), dim3(256), 0, s, a, (int)grid);
+  return check_launch("mgn_edge_bwd_fused");
+}
+
 int mgn_segsum(const float* src, const int32_t* rowptr, const int32_t* perm, float* out, int64_t N, int H, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (N == 0) return 0;
@@ -2259,7 +2303,9 @@ int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream) {
   if (a.out_relu && (a.scale != nullptr || a.resid != nullptr || a.wpk[0] != nullptr ||
                      plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds))
     return fail(1, "mgn_mlp_fwd: out_relu is for a plain ragged-input launch (no norm / residual / packed path)");
-  if (a.act != MGN_ACT_RELU && a.act != MGN_ACT_SILU) return fail(1, "mgn_mlp_fwd: act must be MGN_ACT_RELU or MGN_ACT_SILU");
+  if (a.act != MGN_ACT_RELU && a.act != MGN_ACT_SILU && a.act != MGN_ACT_GELU) return fail(1, "mgn_mlp_fwd: act must be MGN_ACT_RELU, _SILU or _GELU");
+  if (a.act == MGN_ACT_GELU && (a.wpk[0] != nullptr || a.precision != 0 || a.seg_out != nullptr || a.n_add > 0 || a.n_post > 0 || a.ldw0 > 0))
+    return fail(1, "mgn_mlp_fwd: GELU runs on the generic kernels only (no packed weights / gathers / post-products)");
   if (a.act == MGN_ACT_SILU && plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && !fwd_x6(a) && a.NL > 1)
     return fail(1, "mgn_mlp_fwd: SiLU is not available on the exact-fp32 LDS generation (pass packed weights)");
   if (a.precision == 1 && !(plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && fwd_x6(a)))
@@ -2297,10 +2343,14 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   if (a.n_din < 0 || a.n_din > MGN_MAX_PHASES) return fail(1, "mgn_mlp_bwd: n_din out of range");
   if (a.n_din > 1 && a.dZ[0] == nullptr) return fail(1, "mgn_mlp_bwd: n_din > 1 needs dZ[0]");
   if (a.precision != 0 && a.precision != 1) return fail(1, "mgn_mlp_bwd: precision must be 0 (fp32-grade) or 1 (bf16)");
-  if (a.act != MGN_ACT_RELU && a.act != MGN_ACT_SILU) return fail(1, "mgn_mlp_bwd: act must be MGN_ACT_RELU or MGN_ACT_SILU");
-  if (a.act == MGN_ACT_SILU) {
+  if (a.act != MGN_ACT_RELU && a.act != MGN_ACT_SILU && a.act != MGN_ACT_GELU) return fail(1, "mgn_mlp_bwd: act must be MGN_ACT_RELU, _SILU or _GELU");
+  if (a.act == MGN_ACT_GELU && (a.wpk[0] != nullptr || a.precision != 0 || a.seg_out != nullptr || a.n_front != 0))
+    return fail(1, "mgn_mlp_bwd: GELU runs on the generic kernels only");
+  if (a.act != MGN_ACT_RELU) {
     for (int l = 1; l < a.NL; ++l)
-      if (a.Zs[l - 1] == nullptr) return fail(1, "mgn_mlp_bwd: SiLU needs the saved pre-activations Zs[]");
+      if (a.Zs[l - 1] == nullptr) return fail(1, "mgn_mlp_bwd: SiLU / GELU need the saved pre-activations Zs[]");
+  }
+  if (a.act == MGN_ACT_SILU) {
     if (plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && !bwd_x6(a))
       return fail(1, "mgn_mlp_bwd: SiLU is not available on the exact-fp32 LDS generation (pass packed weights)");
   }
@@ -2323,7 +2373,7 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   if (lrc) return fail(2, "mgn_mlp_bwd: cannot reserve LDS");
   if (int rc = check_launch("mgn_mlp_bwd")) return rc;
   // column reductions: db[l], dscale
-  const unsigned grid = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).grid;
+  const unsigned grid = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true, a.act).grid;
   const int nslot = a.NL + 1;
   ColredOuts outs;
   bool any = false;

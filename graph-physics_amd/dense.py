@@ -1,0 +1,235 @@
+"""Dense row work of the sparse-attention Transformer processor on the engine (csrc/mgn_dense.hip): every ``nn.Linear`` of a
+Transformer block (graphphysics/models/layers.py:564-697,700-819), of its gated MLP (:213-278) and of ``TemporalAttention``
+(:822-887) is ONE fused launch -- RMSNorm as a prologue, activation / gated product / bias / residual as the epilogue, a
+concatenated input as two phases -- wrapped in a ``torch.autograd.Function`` whose backward is built from the same launch
+(dX = dZ W), ``mgn_act_gate_bwd``, ``mgn_rownorm_bwd`` and the engine's weight-gradient kernel.  No ``F.linear``, no
+``torch.cat``; CUDA tensors only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _capi, ops
+
+ACT_NONE = -1
+ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "relu": 0, "silu": 1, "gelu": 2}
+
+
+def _prec() -> int:
+    return 1 if ops.get_matrix_precision() == "bf16" else 0
+
+
+def linear_launch(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act: int = ACT_NONE, resid=None, out=None, inv_out=None,
+                  n_out=None, saveZ1=None, saveZ2=None, precision: int = 0):
+    """one ``mgn_linear_fwd`` launch (include/mgn_hip.h); x / x2 / resid may be row-strided views (stride(1) == 1)"""
+    M, K1 = int(x.shape[0]), int(x.shape[1])
+    K2 = int(x2.shape[1]) if x2 is not None else 0
+    N = int(W.shape[0])
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    a = _capi.LinearArgs()
+    a.M, a.x, a.ldx, a.K1 = M, x.data_ptr(), int(x.stride(0)), K1
+    a.x2, a.ldx2, a.K2 = (x2.data_ptr() if x2 is not None else None), (int(x2.stride(0)) if x2 is not None else 0), K2
+    a.norm_scale, a.eps = ops._ptr(norm_scale), ops.EPS
+    a.inv_out, a.n_out = ops._ptr(inv_out), ops._ptr(n_out)
+    a.W, a.ldw, a.b = W.data_ptr(), int(W.stride(0)), ops._ptr(b)
+    a.W2, a.b2 = ops._ptr(W2), ops._ptr(b2)
+    a.act, a.N = act, N
+    a.resid, a.ldr = ops._ptr(resid), (int(resid.stride(0)) if resid is not None else 0)
+    a.out, a.ldo = out.data_ptr(), int(out.stride(0))
+    a.saveZ1, a.saveZ2, a.precision = ops._ptr(saveZ1), ops._ptr(saveZ2), precision
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().mgn_linear_fwd(C.byref(a), ops._stream(x.device))
+    _capi.check(rc, "mgn_linear_fwd", dense=True)
+    return out
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """fp32 rows with unit column stride and 16-byte aligned row starts (a column slab of a wider matrix is fine)"""
+    t = t.float() if t.dtype != torch.float32 else t
+    if t.dim() != 2 or t.stride(1) != 1 or (t.stride(0) & 3) or (t.data_ptr() & 15):
+        t = t.contiguous()
+    return t
+
+
+class DenseFn(torch.autograd.Function):
+    """out = [resid +] epi(n W^T + b),  n = RMSNorm(cat[x, x2]; norm_scale) or cat[x, x2];
+    epi(z) = act(z) [* (n W2^T + b2)]                       (see include/mgn_hip.h, mgn_linear_fwd)"""
+
+    @staticmethod
+    def forward(ctx, x, x2, W, b, W2, b2, norm_scale, resid, act: int, precision: int):
+        ops._require_device(x, x2, W, b, W2, b2, norm_scale, resid)
+        x = _rows(x)
+        x2 = _rows(x2) if x2 is not None else None
+        resid = _rows(resid) if resid is not None else None
+        W = ops._f32c(W)
+        W2 = ops._f32c(W2) if W2 is not None else None
+        M, K = x.shape[0], x.shape[1] + (x2.shape[1] if x2 is not None else 0)
+        N = W.shape[0]
+        dev = x.device
+        need = any(ctx.needs_input_grad) and ops._saving()
+        f = dict(dtype=torch.float32, device=dev)
+        smooth = act != ACT_NONE
+        Z1 = torch.empty(M, N, **f) if (need and (smooth or W2 is not None)) else None
+        Z2 = torch.empty(M, N, **f) if (need and W2 is not None) else None
+        inv = torch.empty(M, **f) if (need and norm_scale is not None) else None
+        n_out = torch.empty(M, K, **f) if (need and norm_scale is not None) else None
+        out = linear_launch(x, W, b, x2, W2, b2, norm_scale, act, resid, None, inv, n_out, Z1, Z2, precision)
+        ctx.save_for_backward(x, x2, W, W2, norm_scale)
+        ctx.aux = (act, precision, Z1, Z2, inv, n_out, b is not None, b2 is not None, resid is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, W, W2, norm_scale = ctx.saved_tensors
+        act, prec, Z1, Z2, inv, n_out, has_b, has_b2, has_res = ctx.aux
+        if ctx.aux is None or (Z1 is None and (act != ACT_NONE or W2 is not None)):
+            raise RuntimeError("DenseFn: no saved activations (the forward ran under no_grad, or backward ran twice)")
+        dy = ops._f32c(dy)
+        M, N = dy.shape
+        K1 = x.shape[1]
+        K2 = x2.shape[1] if x2 is not None else 0
+        K = K1 + K2
+        dev = dy.device
+        f = dict(dtype=torch.float32, device=dev)
+        L = _capi.lib()
+        # ---- through the epilogue
+        if act != ACT_NONE or W2 is not None:
+            dZ1 = torch.empty(M, N, **f)
+            dZ2 = torch.empty(M, N, **f) if W2 is not None else None
+            with torch.cuda.device(dev):
+                rc = L.mgn_act_gate_bwd(dy.data_ptr(), Z1.data_ptr(), ops._ptr(Z2), M, N, act, prec, dZ1.data_ptr(), ops._ptr(dZ2), ops._stream(dev))
+            _capi.check(rc, "mgn_act_gate_bwd", dense=True)
+        else:
+            dZ1, dZ2 = dy, None
+        # ---- input gradient: dn = dZ1 W (+ dZ2 W2) -- the same launch with the transposed weight
+        want_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+        dx = dx2 = dscale = None
+        if (want_dx or norm_scale is not None) and M > 0:
+            if N > 384:
+                raise NotImplementedError("input gradient of a Linear wider than 384 outputs")
+            dn = linear_launch(dZ1, W.t().contiguous(), precision=prec)
+            if W2 is not None:
+                dn = linear_launch(dZ2, W2.t().contiguous(), resid=dn, precision=prec)
+            if norm_scale is not None:
+                dx = torch.empty(M, K1, **f)
+                dx2 = torch.empty(M, K2, **f) if x2 is not None else None
+                dscale = torch.empty(K, **f)
+                ws = torch.empty(max(L.mgn_rownorm_bwd_workspace_bytes(K), 16), dtype=torch.uint8, device=dev)
+                with torch.cuda.device(dev):
+                    rc = L.mgn_rownorm_bwd(dn.data_ptr(), x.data_ptr(), int(x.stride(0)), ops._ptr(x2), int(x2.stride(0)) if x2 is not None else 0,
+                                           K1, K2, inv.data_ptr(), norm_scale.data_ptr(), ops.EPS, M, dx.data_ptr(), K1, ops._ptr(dx2), K2,
+                                           dscale.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream(dev))
+                _capi.check(rc, "mgn_rownorm_bwd", dense=True)
+            elif x2 is not None:
+                dx, dx2 = dn[:, :K1], dn[:, K1:]
+            else:
+                dx = dn
+        elif M == 0:
+            dx = torch.zeros(0, K1, **f)
+            dx2 = torch.zeros(0, K2, **f) if x2 is not None else None
+            dscale = torch.zeros(K, **f) if norm_scale is not None else None
+        # ---- weight / bias gradients: dW = dZ^T n on the engine's weight-gradient kernel, 128-column slabs
+        nsrc = n_out if norm_scale is not None else None
+
+        def wgrad_of(dZ, want_b):
+            dW = torch.empty(N, K, **f) if M > 0 else torch.zeros(N, K, **f)
+            db = (torch.empty(N, **f) if M > 0 else torch.zeros(N, **f)) if want_b else None
+            jobs = []
+            for j0 in range(0, N, 128):
+                nj = min(128, N - j0)
+                A = dZ[:, j0:j0 + nj]
+                first = True
+                srcs = [(nsrc, 0, K)] if nsrc is not None else ([(x, 0, K1)] + ([(x2, K1, K2)] if x2 is not None else []))
+                for src, koff, kw_all in srcs:
+                    for k0 in range(0, kw_all, 128):
+                        nk = min(128, kw_all - k0)
+                        B = src[:, k0:k0 + nk]
+                        job = (A, int(dZ.stride(0)), nj // 16, B, int(src.stride(0)), nk // 16, nk, dW, j0 * K + koff + k0, K)
+                        if first and db is not None:
+                            job = job + (db[j0:j0 + nj],)
+                        first = False
+                        jobs.append(job)
+            if M > 0:
+                ops.wgrad(jobs, dev, prec)
+            return dW, db
+
+        dW, db = wgrad_of(dZ1, has_b)
+        dW2 = db2 = None
+        if W2 is not None:
+            dW2, db2 = wgrad_of(dZ2, has_b2)
+        ctx.aux = None
+        return (dx if ctx.needs_input_grad[0] else None, dx2 if (x2 is not None and ctx.needs_input_grad[1]) else None, dW, db, dW2, db2,
+                dscale, dy if has_res else None, None, None)
+
+
+def dense(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act: Optional[str] = None, resid=None):
+    """fused Linear on the engine (module docstring); ``act``: None / "relu" / "silu" / "gelu"."""
+    ops._call.grad = torch.is_grad_enabled()
+    try:
+        return DenseFn.apply(x, x2, W, b, W2, b2, norm_scale, resid, ACT_IDS[act], _prec())
+    finally:
+        ops._call.grad = True
+
+
+class SigmoidGateFn(torch.autograd.Function):
+    """y * sigmoid(G) on ``mgn_gate_fwd`` / ``mgn_gate_bwd`` (the gated attention of layers.py:688-693)"""
+
+    @staticmethod
+    def forward(ctx, y, G):
+        y, G = ops._f32c(y), ops._f32c(G)
+        gate, out = torch.empty_like(y), torch.empty_like(y)
+        ops.gate_fwd(G, None, None, y, gate, out)
+        ctx.save_for_backward(y, gate)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        y, gate = ctx.saved_tensors
+        d = ops._f32c(d)
+        dy, dG = torch.empty_like(y), torch.empty_like(y)
+        ops.gate_bwd(d, y, gate, dy, dG)
+        return dy, dG
+
+
+class RMSNormFn(torch.autograd.Function):
+    """stand-alone RMSNorm on ``mgn_rownorm_fwd`` / ``mgn_rownorm_bwd`` (layers.py:73-129; widths up to 384)"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ops._require_device(x, scale)
+        shape = x.shape
+        x2d = _rows(x.reshape(-1, shape[-1]))
+        M, K = x2d.shape
+        y = torch.empty(M, K, dtype=torch.float32, device=x.device)
+        inv = torch.empty(M, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _capi.lib().mgn_rownorm_fwd(x2d.data_ptr(), int(x2d.stride(0)), K, scale.data_ptr(), ops.EPS, M, y.data_ptr(), inv.data_ptr(),
+                                             ops._stream(x.device))
+        _capi.check(rc, "mgn_rownorm_fwd", dense=True)
+        ctx.save_for_backward(x2d, scale, inv)
+        ctx.shape = shape
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, inv = ctx.saved_tensors
+        M, K = x.shape
+        dy = ops._f32c(dy.reshape(M, K))
+        dev = dy.device
+        dx = torch.empty(M, K, dtype=torch.float32, device=dev)
+        dscale = torch.empty(K, dtype=torch.float32, device=dev) if M > 0 else torch.zeros(K, dtype=torch.float32, device=dev)
+        if M > 0:
+            L = _capi.lib()
+            ws = torch.empty(max(L.mgn_rownorm_bwd_workspace_bytes(K), 16), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = L.mgn_rownorm_bwd(dy.data_ptr(), x.data_ptr(), int(x.stride(0)), None, 0, K, 0, inv.data_ptr(), scale.data_ptr(), ops.EPS, M,
+                                       dx.data_ptr(), K, None, 0, dscale.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream(dev))
+            _capi.check(rc, "mgn_rownorm_bwd", dense=True)
+        return dx.reshape(ctx.shape), dscale
+
+
+def rms_norm(x, scale):
+    return RMSNormFn.apply(x, scale)

@@ -42,6 +42,9 @@ class RMSNorm(nn.Module):
 
     def forward(self, x):
         ops._require_device(x)
+        if x.shape[-1] <= 384:   # engine kernel (csrc/mgn_dense.hip), forward and backward
+            from .dense import rms_norm
+            return rms_norm(x, self.scale)
         rms = x.norm(2, dim=-1, keepdim=True) / (self.d ** 0.5)
         return self.scale * (x / (rms + self.eps))
 
@@ -63,7 +66,15 @@ class SiLU(ReLU):
         return torch.nn.functional.silu(x)
 
 
-_ACT_MODULES = {"relu": ReLU, "silu": SiLU}
+class GELU(ReLU):
+    """nn.GELU() (exact erf form) -- ``build_mlp(act="gelu")`` (layers.py:150-160)."""
+
+    def forward(self, x):
+        ops._require_device(x)
+        return torch.nn.functional.gelu(x)
+
+
+_ACT_MODULES = {"relu": ReLU, "silu": SiLU, "gelu": GELU}
 
 
 class MLP(nn.Sequential):
@@ -91,9 +102,6 @@ def build_mlp(in_size: int, hidden_size: int, out_size: int, nb_of_layers: int =
     key = act if act is not None else ("silu" if _USE_SILU_ACTIVATION else "relu")
     if key not in ("relu", "gelu", "silu"):
         raise NotImplementedError(f"Activation '{key}' not supported. Available: ['relu', 'gelu', 'silu'].")
-    if key == "gelu":
-        raise NotImplementedError("GELU in build_mlp is reachable only through an explicit act='gelu' argument, which no "
-                                  "caller of the reference passes; the MI355X engine implements ReLU and SiLU")
     A = _ACT_MODULES[key]
     layers = [nn.Linear(in_size, hidden_size), A()]
     for _ in range(nb_of_layers - 2):

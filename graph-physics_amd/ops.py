@@ -475,6 +475,38 @@ def mlp_bwd(M: int, H: int, NL: int, dOut: torch.Tensor, dOut2, idx2, out_w: int
     _capi.check(rc, "mgn_mlp_bwd")
 
 
+_fused_ws: dict = {}
+
+
+def edge_bwd_fused(E: int, dOut, dAgg, idx, U, R, scale, X: Sequence[torch.Tensor], Ms: Sequence[torch.Tensor], wpk: Sequence[int],
+                   dIn, dZ0, dW: Sequence[Tuple[torch.Tensor, int, int]], db: Sequence[Optional[torch.Tensor]], dscale, precision: int = 0):
+    """mgn_edge_bwd_fused: the edge backward chain of a round AND its four E-row weight gradients in one kernel
+    (include/mgn_hip.h).  ``dW``: (tensor, element offset, leading dimension) per layer."""
+    L = _capi.lib()
+    a = _capi.EdgeBwdFusedArgs()
+    a.M = E
+    a.dOut, a.dAgg, a.idx, a.U, a.R, a.scale, a.eps = _ptr(dOut), _ptr(dAgg), _ptr(idx), _ptr(U), _ptr(R), _ptr(scale), EPS
+    for l in range(4):
+        a.X[l] = _ptr(X[l])
+        a.wpk[l] = wpk[l]
+        t, off, ld = dW[l]
+        a.dW[l], a.ldw[l] = t.data_ptr() + 4 * off, ld
+        a.db[l] = _ptr(db[l])
+    for l in range(3):
+        a.Ms[l] = _ptr(Ms[l])
+    a.dIn, a.dZ0, a.dscale = _ptr(dIn), _ptr(dZ0), _ptr(dscale)
+    dev = dOut.device
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _fused_ws.get(key)   # 68 MB of per-workgroup partials, re-used by every round (launches of one stream are ordered)
+    if ws is None:
+        ws = torch.empty(L.mgn_edge_bwd_fused_workspace_bytes(), dtype=torch.uint8, device=dev)
+        _fused_ws[key] = ws
+    a.ws, a.ws_bytes, a.precision = _ptr(ws), ws.numel(), precision
+    with torch.cuda.device(dev):
+        rc = L.mgn_edge_bwd_fused(C.byref(a), _stream(dev))
+    _capi.check(rc, "mgn_edge_bwd_fused")
+
+
 def colred_batch(deferred: list, dev):
     """finish the column sums (bias / scale gradients) of ``mlp_bwd(..., defer=deferred)`` launches"""
     if not deferred:
@@ -606,7 +638,7 @@ def _saving() -> bool:
     return getattr(_call, "grad", True)
 
 
-ACT_IDS = {"relu": 0, "silu": 1}
+ACT_IDS = {"relu": 0, "silu": 1, "gelu": 2}   # gelu: stand-alone build_mlp(act="gelu") only (generic kernels)
 
 
 def mlp_apply(x, has_norm, *params, act: str = "relu"):
@@ -743,7 +775,7 @@ class MlpFunction(torch.autograd.Function):
         need = any(ctx.needs_input_grad) and _saving()
         f = dict(dtype=torch.float32, device=dev)
         y = torch.empty(M, out_w, **f)
-        x6 = H == 128 and out_w == H and X6_ENABLED and M > 0
+        x6 = H == 128 and out_w == H and X6_ENABLED and M > 0 and act != 2   # GELU: generic kernels
         mode = "generic"
         if x6 and kin < H and 3 <= NL <= 4:
             mode = "enc"    # narrow first layer stand-alone, layers 1.. on the packed kernels
@@ -754,7 +786,7 @@ class MlpFunction(torch.autograd.Function):
         U = torch.empty(M, H, **f) if (need and has_norm) else None
         R = torch.empty(M, **f) if (need and has_norm) else None
         Ms = [torch.empty(M, 4, dtype=torch.int32, device=dev) for _ in range(NL - 1)] if (need and packed and act == 0) else None
-        Zs = [torch.empty(M, H, **f) for _ in range(NL - 1)] if (need and act == 1) else None
+        Zs = [torch.empty(M, H, **f) for _ in range(NL - 1)] if (need and act != 0) else None
         if mode == "enc":
             # h1 = act(W0 x + b0): the activation the backward needs anyway
             h1 = saveH[0] if need else torch.empty(M, H, **f)
@@ -1249,7 +1281,16 @@ class ProcessorFunction(torch.autograd.Function):
             # (measured neutral on the bench workload -- the chain kernel gains the 10 us the stand-alone sum
             # loses -- so it is opt-in: MGN_FUSED_SD=1; tests/test_hip_parity.py covers it)
             fuse_sd = x6 and act == 0 and prec == 0 and E > 0 and _os.environ.get("MGN_FUSED_SD") is not None and not topo.has_hubs
-            if E > 0:
+            # the edge chain AND its four E-row weight gradients in one kernel (mgn_edge_bwd_fused: dZ1..dZ3 never reach
+            # memory; 763 MB per launch instead of 1594 MB).  Built, parity-green -- and measured SLOWER than the split
+            # launches at the bench size (545-560 us against 390-405 us: one wave per SIMD serialises what two waves overlap,
+            # DESIGN.md section 4.6), so it is opt-in: MGN_FUSED_BWD=1
+            fused_bwd = (x6 and act == 0 and NL == 4 and spec.layer_norm and not spec.rope and E > 0 and Nn > 0 and not fuse_sd
+                         and side is None and _os.environ.get("MGN_FUSED_BWD", "0") == "1")
+            if fused_bwd:
+                edge_bwd_fused(E, de, dAgg, topo.dst_s, Ue, Re, se, [e] + list(He), S["Me"], ke, de_new, dZe[0],
+                               [(gWe[0], 0, 3 * H), (gWe[1], 0, H), (gWe[2], 0, H), (gWe[3], 0, H)], gbe, gse, precision=prec)
+            elif E > 0:
                 seg = None
                 if fuse_sd:
                     part_b = torch.empty((E + 15) // 16, 2, H, **f)
@@ -1300,8 +1341,10 @@ class ProcessorFunction(torch.autograd.Function):
             if spec.gate:
                 gWg, gbg, gpos = g[2 * k_], g[2 * k_ + 1], g[2 * k_ + 2]
                 njobs.append((dG, H, nb, x, H, nb, H, gWg, 0, H, gbg))
+            if fused_bwd:
+                ejobs = []
             if halo is not None:
-                if E > 0:
+                if E > 0 and ejobs:
                     wgrad(ejobs, dev, prec)
                 halo.finish_backward(back, Ss)
                 if Nn > 0:
@@ -1312,6 +1355,8 @@ class ProcessorFunction(torch.autograd.Function):
                 n_sc = 1 if spec.rope else 2
                 deep = [j for pair in zip(njobs[2 + n_sc:2 + n_sc + NL - 1], ejobs[len(ejobs) - (NL - 1):]) for j in pair]
                 alljobs = njobs[:2] + ejobs[:len(ejobs) - (NL - 1)] + njobs[2:2 + n_sc] + deep + (njobs[-1:] if spec.gate else [])
+                if fused_bwd:  # the E-row jobs ran inside the fused kernel
+                    alljobs = njobs
                 if side is not None:
                     ready = torch.cuda.Event()
                     ready.record(main)

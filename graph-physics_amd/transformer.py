@@ -8,8 +8,11 @@ half and runs on the HIP kernels of csrc/mgn_attn.hip (CSR by row, online softma
 backward).  It follows the reference's DGL branch (``HAS_DGL_SPARSE``): adjacency
 ``dglsp.spmatrix(indices=edge_index)`` (rows = edge_index[0]), ``bsddmm`` -> ``softmax`` -> ``bspmm`` with
 the head index as the fastest axis of the hidden dimension.  Encoder / decoder are the engine's fused MLP
-kernels; the per-node projections and the gated MLP of a block are plain dense GEMMs (rocBLAS through
-``torch.nn.functional.linear``), as in ``gated.py``.  CUDA tensors only."""
+kernels.  The DENSE half of a block -- q / k / v / gate / output projections, both RMSNorms, the gated MLP, the
+mixers of ``TemporalAttention`` -- runs on the fused Linear launches of csrc/mgn_dense.hip (``dense.py``): norm as
+prologue, activation / gated product / bias / residual as epilogue, concatenated inputs as two phases; no
+``F.linear`` and no ``torch.cat`` on the path.  ``ops.set_matrix_precision("bf16")`` runs those Linears in bf16
+(the reference under Lightning bf16-mixed; the sparse attention stays fp32, layers.py:49-70).  CUDA tensors only."""
 from __future__ import annotations
 
 import math
@@ -19,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _capi, ops
+from .dense import SigmoidGateFn, dense, rms_norm
 from .gated import build_gated_mlp
 from .layers import RMSNorm, build_mlp
 
@@ -31,6 +35,7 @@ class AttnTopology:
         self.N, self.E = t.N, t.E
         self.rowptr, self.col, self.row = t.rowptr_dst, t.src_s, t.dst_s
         self.cptr, self.cperm = t.rowptr_src, t.perm_src
+        self.perm = t.perm_dst   # row-sorted position -> edge id in the caller's edge_index
 
 
 _attn_cache: dict = {}
@@ -65,10 +70,11 @@ class SparseAttentionFn(torch.autograd.Function):
         _capi.check(rc, "mgn_sparse_attn_fwd", attn=True)
         ctx.save_for_backward(q, k, v, y, lse)
         ctx.topo, ctx.num_heads = topo, num_heads
-        return y
+        ctx.mark_non_differentiable(lse)
+        return y, lse
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dlse=None):
         q, k, v, y, lse = ctx.saved_tensors
         topo, nh = ctx.topo, ctx.num_heads
         dy = dy.float().contiguous()
@@ -84,8 +90,20 @@ class SparseAttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None
 
 
-def sparse_attention(q, k, v, topo: AttnTopology, num_heads: int):
-    return SparseAttentionFn.apply(q, k, v, topo, num_heads)
+def sparse_attention(q, k, v, topo: AttnTopology, num_heads: int, return_attention: bool = False):
+    """``return_attention``: also the per-edge attention weights [E, num_heads] in the order of the caller's edge_index
+    (the values of the reference's softmax-ed sparse matrix, layers.py:543-559); no gradient flows through them."""
+    y, lse = SparseAttentionFn.apply(q, k, v, topo, num_heads)
+    if not return_attention:
+        return y
+    qd, kd = q.detach().float().contiguous(), k.detach().float().contiguous()
+    attn = torch.empty(topo.E, num_heads, dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        rc = _capi.lib().mgn_sparse_attn_weights(qd.data_ptr(), kd.data_ptr(), lse.data_ptr(), topo.rowptr.data_ptr(), topo.col.data_ptr(),
+                                                 topo.perm.data_ptr(), qd.shape[0], qd.shape[1], num_heads, attn.data_ptr(),
+                                                 ops._stream(q.device))
+    _capi.check(rc, "mgn_sparse_attn_weights", attn=True)
+    return y, attn
 
 
 def _make_inv_freq(m: int, base: float) -> torch.Tensor:
@@ -145,24 +163,37 @@ class Attention(nn.Module):
                 self.k_proj.weight = self.q_proj.weight
                 self.v_proj.weight = self.q_proj.weight
 
-    def forward(self, x: torch.Tensor, adj, pos: Optional[torch.Tensor] = None, return_attention: bool = False):
-        """``adj``: an :class:`AttnTopology` (or an edge_index tensor, converted and cached)."""
-        if return_attention:
-            raise NotImplementedError("return_attention is not provided by the fused sparse-attention kernel")
+    def forward(self, x: torch.Tensor, adj, pos: Optional[torch.Tensor] = None, return_attention: bool = False,
+                _norm_scale: Optional[torch.Tensor] = None, _resid: Optional[torch.Tensor] = None):
+        """``adj``: an :class:`AttnTopology` (or an edge_index tensor, converted and cached).
+        ``_norm_scale`` / ``_resid`` (used by :class:`Transformer`): RMSNorm fused as the prologue of the q / k / v / gate
+        projections, the block's residual as the epilogue of the output projection."""
         if self.use_rope_embeddings and pos is None:
             raise ValueError("RoPE embeddings require positional information when enabled.")
         ops._require_device(x)
         N = x.size(0)
         topo = adj if isinstance(adj, AttnTopology) else get_attn_topology(adj, N)
-        q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        lin = lambda m: dense(x, m.weight, m.bias, norm_scale=_norm_scale)  # noqa: E731
+        q, k, v = lin(self.q_proj), lin(self.k_proj), lin(self.v_proj)
         if self.use_rope_embeddings and self.rope_inv_freq.numel() > 0:
             q3, k3 = _apply_rope_with_inv(q.reshape(N, self.head_dim, self.num_heads), k.reshape(N, self.head_dim, self.num_heads),
                                           pos, self.rope_inv_freq)
             q, k = q3.reshape(N, -1), k3.reshape(N, -1)
-        y = sparse_attention(q, k, v, topo, self.num_heads)
+        bf16 = ops.get_matrix_precision() == "bf16"
+        if bf16:  # the scaled query is a bf16 tensor in the reference (q / sqrt(d) on the bf16 projection, layers.py:509-510)
+            s_ = math.sqrt(self.head_dim)
+            q = (q / s_).bfloat16().float() * s_
+        attn = None
+        if return_attention:   # (out, attn): attn [E, num_heads] lines up with edge_index (layers.py:688-697)
+            y, attn = sparse_attention(q, k, v, topo, self.num_heads, return_attention=True)
+        else:
+            y = sparse_attention(q, k, v, topo, self.num_heads)
+        if bf16:  # scores / softmax / AV ran in fp32 (the reference's shims, layers.py:49-70); y returns in v's dtype
+            y = y.bfloat16().float()
         if self.use_gated_attention and self.gate_proj is not None:
-            y = y * torch.sigmoid(self.gate_proj(x))   # same flat layout as reshape(N, head_dim, num_heads)
-        return self.proj(y)
+            y = SigmoidGateFn.apply(y, lin(self.gate_proj))   # same flat layout as reshape(N, head_dim, num_heads)
+        out = dense(y, self.proj.weight, self.proj.bias, resid=_resid)
+        return (out, attn) if return_attention else out
 
 
 class Transformer(nn.Module):
@@ -184,8 +215,17 @@ class Transformer(nn.Module):
     def forward(self, x: torch.Tensor, adj, pos: Optional[torch.Tensor] = None, return_attention: bool = False) -> torch.Tensor:
         if self.use_rope_embeddings and pos is None:
             raise ValueError("Transformer blocks require node positions when use_rope_embeddings=True.")
-        x = x + self.attention(self.norm1(x), adj, pos=pos, return_attention=return_attention)
-        return x + self.gated_mlp(self.norm2(x))
+        # x + Attention(norm1(x)): norm1 is the prologue of the projections, the residual the epilogue of the output projection
+        a = self.attention(x, adj, pos=pos, return_attention=return_attention, _norm_scale=self.norm1.scale, _resid=x)
+        x, attn = a if return_attention else (a, None)
+        # x + gated_mlp(norm2(x)); build_gated_mlp starts with a norm of its own (layers.py:256-278), so norm2 is a launch of
+        # its own and the inner one the prologue of the two gate Linears
+        gm = self.gated_mlp
+        h = rms_norm(x, self.norm2.scale)
+        p_ = dense(h, gm[1].linear1.weight, gm[1].linear1.bias, W2=gm[1].linear2.weight, b2=gm[1].linear2.bias, norm_scale=gm[0].scale,
+                   act=("silu" if isinstance(gm[1].activation, nn.SiLU) else "gelu"))
+        x = dense(p_, gm[2].weight, gm[2].bias, resid=x)
+        return (x, attn) if return_attention else x
 
 
 class TemporalAttention(nn.Module):
@@ -209,12 +249,17 @@ class TemporalAttention(nn.Module):
         if adj is None:
             raise NotImplementedError("TemporalAttention runs over the mesh adjacency (the reference's DGL branch)")
         topo = adj if isinstance(adj, AttnTopology) else get_attn_topology(adj, h_prev.size(0))
-        y = sparse_attention(self.q_proj(h_pred), self.k_proj(h_prev), self.v_proj(h_pred), topo, self.H)
-        out = self.out_proj(y)
-        if self.use_gate:
-            out = self.gate(torch.cat([h_pred, h_prev], dim=-1)) * out
+        q = dense(h_pred, self.q_proj.weight, self.q_proj.bias)
+        k = dense(h_prev, self.k_proj.weight, self.k_proj.bias)
+        v = dense(h_pred, self.v_proj.weight, self.v_proj.bias)
+        y = sparse_attention(q, k, v, topo, self.H)
+        out = dense(y, self.out_proj.weight, self.out_proj.bias)
+        if self.use_gate:   # sigmoid(Linear(SiLU(Linear(cat[h_pred, h_prev])))) * out: the concatenation is two input phases
+            g1 = dense(h_pred, self.gate[0].weight, self.gate[0].bias, x2=h_prev, act="silu")
+            out = SigmoidGateFn.apply(out, dense(g1, self.gate[2].weight, self.gate[2].bias))
         h_corr = h_prev + out
-        return h_corr + self.mixer(torch.cat([h_corr, h_prev], dim=-1))
+        m1 = dense(h_corr, self.mixer[0].weight, self.mixer[0].bias, x2=h_prev, act="silu")
+        return dense(m1, self.mixer[2].weight, self.mixer[2].bias, resid=h_corr)
 
 
 class EncodeTransformDecode(nn.Module):

@@ -173,6 +173,9 @@ typedef struct {
 } mgn_mlp_fwd_args;
 #define MGN_ACT_RELU 0
 #define MGN_ACT_SILU 1
+/* GELU (exact erf form, nn.GELU()): the reference's build_mlp(act="gelu") option (layers.py:150-160).  Generic kernels only
+ * (any H, ragged widths; no packed weights, gathers or post-products); saveZ / Zs as for SiLU. */
+#define MGN_ACT_GELU 2
 int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream);
 
 /* ----------------------------------------------------- fused MLP backward chain
@@ -268,6 +271,44 @@ size_t mgn_wgrad_workspace_bytes(int njobs, const mgn_wgrad_job* jobs);
 int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, void* stream);
 /* same with an explicit matrix precision for the full 128x128 jobs (0 / 1 as in mgn_mlp_fwd_args) */
 int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, int precision, void* stream);
+
+/* ------------------------------------------------ fused edge backward of a round (chain + weight gradients)
+ * The backward of GraphNetBlock's edge update (graphphysics/models/layers.py:1044-1060 under autograd: edge_block =
+ * build_mlp :163-210, 4 Linear / ReLU / RMSNorm :104-129, residual :1039) for the dst-sorted edge rows, as ONE kernel:
+ *   dY   = dOut + dAgg[idx]                     (gradient of e' = e + m and of agg = sum m, layers.py:1031-1040)
+ *   dZ3  = RMSNorm backward of dY (U, R, scale);   dZ_{l-1} = (W_l^T dZ_l) masked by Ms[l-1]   (l = 3, 2, 1)
+ *   dIn  = dOut + We0^T dZ0                       (the input gradient wrt e)
+ *   dW_l = dZ_l^T X_l,  db_l = column sums of dZ_l   (X_0 = the round's input e, X_l = saved activation H_l),
+ *   dscale = sum_rows dY * U;   dZ0 is also stored (the node-side scatters of the split first layer read it).
+ * It replaces mgn_mlp_bwd (edge chain) + the four E-row jobs of mgn_wgrad of a round; dZ1..dZ3 never reach memory.
+ * wpk[0..3]: packed W3^T, W2^T, W1^T, We0^T (mgn_wpack).  dW[l]: [128, ldw[l]] destinations (dW[0] is the first slab
+ * of the [128, 384] first-layer gradient: ldw[0] = 384).  ws: mgn_edge_bwd_fused_workspace_bytes() bytes of device
+ * scratch (per-workgroup partials, summed in a fixed order: deterministic).  H = 128, 4 layers, ReLU only.
+ * precision as in mgn_mlp_fwd_args. */
+typedef struct {
+  int64_t M;
+  const float* dOut;
+  const float* dAgg;
+  const int32_t* idx;
+  const float* U;
+  const float* R;
+  const float* scale;
+  float eps;
+  const float* X[4];
+  const uint32_t* Ms[3];
+  const void* wpk[4];
+  float* dIn;
+  float* dZ0;
+  float* dW[4];
+  int ldw[4];
+  float* db[4];
+  float* dscale;
+  void* ws;
+  size_t ws_bytes;
+  int precision;
+} mgn_edge_bwd_fused_args;
+size_t mgn_edge_bwd_fused_workspace_bytes(void);
+int mgn_edge_bwd_fused(const mgn_edge_bwd_fused_args* args, void* stream);
 
 /* Diagnostic: resident workgroups per CU (HIP occupancy query) of the persistent kernels at their launch
  * configuration -- out[0..5] = forward chain (fp32-grade, 4 waves), forward chain (bf16), backward chain
@@ -469,7 +510,63 @@ int mgn_sparse_attn_bwd(const float* q, const float* k, const float* v, const fl
                         const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
                         const int32_t* row_of_edge, int64_t N, int64_t E, int H, int num_heads,
                         float* dq, float* dk, float* dv, float* ws, size_t ws_bytes, void* stream);
+/* The attention weights themselves (Attention.forward(..., return_attention=True), layers.py:543-559,688-697: the values of
+ * the softmax-ed sparse matrix): attn[out_pos[e], h] = exp(score[e,h] - lse[i_e,h]) for the row-sorted edge e; out_pos
+ * (optional) = the position of that edge in the caller's edge_index (the CSR build's perm), so attn [E, num_heads] lines up
+ * with edge_index.  lse from mgn_sparse_attn_fwd. */
+int mgn_sparse_attn_weights(const float* q, const float* k, const float* lse, const int32_t* rowptr, const int32_t* col,
+                            const int32_t* out_pos, int64_t N, int H, int num_heads, float* attn, void* stream);
 const char* mgn_attn_last_error(void);
+
+/* ================================================================================
+ * Dense row work of the Transformer processor -- csrc/mgn_dense.hip
+ * ================================================================================
+ * One fused launch per Linear of a Transformer block (graphphysics/models/layers.py:564-697 Attention, :700-819
+ * Transformer, :213-278 GatedMLP / build_gated_mlp) and of TemporalAttention (:822-887):
+ *   out = [resid +] epi( n W^T + b ),   n = RMSNorm(cat[x, x2]) if norm_scale else cat[x, x2]      (RMSNorm :73-129)
+ *   epi(z) = act(z)                       (act = MGN_ACT_NONE / _RELU / _SILU / _GELU)
+ *          = act(z) * (n W2^T + b2)       when W2 is given  (the gated product of GatedMLP, :249-253)
+ * x [M, ldx] (first K1 columns), x2 [M, ldx2] (first K2 columns, optional: a concatenation that is never materialised);
+ * K1, K2 multiples of 16, K1 + K2 in {16,32,48,64,96,128,192,256,384}; W, W2 [N, ldw] row-major (nn.Linear layout),
+ * N a multiple of 16.  Optional outputs for the backward pass: inv_out [M] = 1 / (rms + eps), n_out [M, K1 + K2] = the
+ * normalised input (the B operand of the weight gradient), saveZ1 / saveZ2 [M, N] = the pre-activations.
+ * precision 1 = the reference under Lightning bf16-mixed (autocast runs nn.Linear in bf16, train.py:74-78): operands and
+ * every result rounded to bf16, fp32 accumulation; the residual add stays fp32.
+ * The backward pass is built from the same launch (dX = dZ W: pass W^T as the weight), mgn_act_gate_bwd, mgn_rownorm_bwd
+ * and mgn_wgrad jobs. */
+#define MGN_ACT_NONE (-1)
+typedef struct {
+  int64_t M;
+  const float* x; int ldx; int K1;
+  const float* x2; int ldx2; int K2;
+  const float* norm_scale; float eps;
+  float* inv_out;
+  float* n_out;
+  const float* W; int ldw;
+  const float* b;
+  const float* W2;
+  const float* b2;
+  int act;
+  int N;
+  const float* resid; int ldr;
+  float* out; int ldo;
+  float* saveZ1;
+  float* saveZ2;
+  int precision;
+} mgn_linear_args;
+int mgn_linear_fwd(const mgn_linear_args* args, void* stream);
+/* dZ1 = dP * (Z2 or 1) * act'(Z1);  dZ2 = dP * act(Z1)   over [M, N] (Z2 / dZ2 NULL: a plain activation) */
+int mgn_act_gate_bwd(const float* dP, const float* Z1, const float* Z2, int64_t M, int N, int act, int precision, float* dZ1,
+                     float* dZ2, void* stream);
+/* stand-alone RMSNorm (layers.py:73-129): y [M, K] = scale * x / (||x|| / sqrt(K) + eps), inv_out [M] optional */
+int mgn_rownorm_fwd(const float* x, int ldx, int K, const float* scale, float eps, int64_t M, float* y, float* inv_out, void* stream);
+/* backward of the RMSNorm prologue: from dn [M, K1 + K2] (gradient of the normalised input), the raw rows, inv and scale:
+ * dx [M, lddx] (K1 columns), dx2 [M, lddx2] (K2 columns), dscale [K1 + K2] (fixed summation order). */
+size_t mgn_rownorm_bwd_workspace_bytes(int K);
+int mgn_rownorm_bwd(const float* dn, const float* x, int ldx, const float* x2, int ldx2, int K1, int K2, const float* inv,
+                    const float* scale, float eps, int64_t M, float* dx, int lddx, float* dx2, int lddx2, float* dscale, void* ws,
+                    size_t ws_bytes, void* stream);
+const char* mgn_dense_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -81,7 +81,7 @@ def mlp(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str, act: str = "re
     layers.py:150-160); entry 7 is RMSNorm when present (``layer_norm=True``).
     ``p`` is a state_dict; ``prefix`` e.g. "processor_list.0.edge_block.".
     """
-    f = torch.relu if act == "relu" else torch.nn.functional.silu
+    f = {"relu": torch.relu, "silu": torch.nn.functional.silu, "gelu": torch.nn.functional.gelu}[act]  # layers.py:150-160
     h = x
     idx = []  # Linear entries 0, 2, 4, ... (nb_of_layers of them; 4 unless the block was built otherwise)
     while f"{prefix}{2 * len(idx)}.weight" in p:
@@ -104,15 +104,24 @@ def mlp(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str, act: str = "re
     return h
 
 
+def _linear(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """nn.Linear; under :class:`bf16_mixed` as CUDA autocast runs it: inputs, weight and bias cast to bf16, bf16 result
+    (fp32 accumulation inside the GEMM)."""
+    if _BF16_MIXED:
+        return torch.nn.functional.linear(x.to(torch.bfloat16), W.to(torch.bfloat16), None if b is None else b.to(torch.bfloat16))
+    return torch.nn.functional.linear(x, W, b)
+
+
 def gated_mlp(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str, act: str = "relu") -> torch.Tensor:
     """build_gated_mlp, graphphysics/models/layers.py:256-278: Sequential(RMSNorm(in) [entry 0],
     GatedMLP [entry 1: act(linear1 x) * linear2 x, layers.py:249-253; activation SiLU when the global
-    switch is set, else GELU, :235-236], Linear [entry 2])."""
-    h = rms_norm(x, p[prefix + "0.scale"])
+    switch is set, else GELU, :235-236], Linear [entry 2]).  Under bf16_mixed: the norm in fp32, the three Linears, the
+    activation and the product in bf16 (autocast op lists; the product of two bf16 tensors is bf16)."""
+    h = rms_norm(x.float(), p[prefix + "0.scale"])
     a = torch.nn.functional.silu if act == "silu" else torch.nn.functional.gelu
-    left = a(torch.nn.functional.linear(h, p[prefix + "1.linear1.weight"], p[prefix + "1.linear1.bias"]))
-    right = torch.nn.functional.linear(h, p[prefix + "1.linear2.weight"], p[prefix + "1.linear2.bias"])
-    return torch.nn.functional.linear(left * right, p[prefix + "2.weight"], p[prefix + "2.bias"])
+    left = a(_linear(h, p[prefix + "1.linear1.weight"], p[prefix + "1.linear1.bias"]))
+    right = _linear(h, p[prefix + "1.linear2.weight"], p[prefix + "1.linear2.bias"])
+    return _linear(left * right, p[prefix + "2.weight"], p[prefix + "2.bias"])
 
 
 def rope_inv_freq(hidden_size: int, rope_axes: int, rope_base: float) -> torch.Tensor:
@@ -581,12 +590,20 @@ def apply_rope_with_inv(q, k, pos, inv_freq):
 def attention(x, p, prefix, edge_index, num_heads, pos=None, use_rope=False, use_gate=False, pos_dimension=3, rope_base=10000.0):
     """Attention.forward, layers.py:641-697."""
     N = x.size(0)
-    lin = lambda name, t: torch.nn.functional.linear(t, p[f"{prefix}{name}.weight"], p.get(f"{prefix}{name}.bias"))  # noqa: E731
+    lin = lambda name, t: _linear(t, p[f"{prefix}{name}.weight"], p.get(f"{prefix}{name}.bias"))  # noqa: E731
     hd = p[prefix + "q_proj.weight"].shape[0] // num_heads
     q, k, v = (lin(n, x).reshape(N, hd, num_heads) for n in ("q_proj", "k_proj", "v_proj"))
     if use_rope:
         q, k = apply_rope_with_inv(q, k, pos, attn_inv_freq(hd, pos_dimension, rope_base))
-    y = sparse_attention(q, k, v, edge_index)
+    if _BF16_MIXED:
+        # training.enable_vram_optimizations sets Lightning bf16-mixed AND the memory-optimised switch (parse_parameters.py:
+        # 111-112): the scaled query is a bf16 tensor (q / sqrt(d) on bf16, layers.py:509-510), bsddmm / softmax / bspmm run in
+        # fp32 through the _bsddmm_fp32 / _bspmm_fp32 shims (layers.py:49-70,513-517,549-553) and y returns in v's dtype
+        scale = math.sqrt(k.size(1))
+        qs = (q / scale).float() * scale          # the bf16-rounded scaled query, re-expressed for sparse_attention's own division
+        y = sparse_attention(qs, k.float(), v.float(), edge_index).to(torch.bfloat16)
+    else:
+        y = sparse_attention(q, k, v, edge_index)
     if use_gate:
         y = y * torch.sigmoid(lin("gate_proj", x)).reshape(N, hd, num_heads)
     return lin("proj", y.reshape(N, -1))
@@ -594,7 +611,7 @@ def attention(x, p, prefix, edge_index, num_heads, pos=None, use_rope=False, use
 
 def transformer_block(x, p, prefix, edge_index, num_heads, act="relu", **kw):
     """Transformer.forward, layers.py:813-816: x + attention(norm1(x)); x + gated_mlp(norm2(x))."""
-    x = x + attention(rms_norm(x, p[prefix + "norm1.scale"]), p, prefix + "attention.", edge_index, num_heads, **kw)
+    x = x + attention(rms_norm(x, p[prefix + "norm1.scale"]), p, prefix + "attention.", edge_index, num_heads, **kw)   # fp32 + bf16 -> fp32
     return x + gated_mlp(rms_norm(x, p[prefix + "norm2.scale"]), p, prefix + "gated_mlp.", act)
 
 

@@ -195,3 +195,28 @@ def test_build_preprocessing_widths_like_the_reference_tests(dev):
     assert g2b.edge_attr.shape[1] == 8
     g3 = PP.build_preprocessing(noise_parameters=noise)(graph())
     assert g3.edge_attr.shape[1] == 4 and g3.x.shape[1] == 4
+
+
+def test_build_mlp_gelu_vs_oracle(dev):
+    """build_mlp(act="gelu") (layers.py:150-160: nn.GELU(), exact erf form) on the generic kernels: forward and every
+    gradient against the oracle, at hidden 128 (full width: off the packed path by design), 64 and a ragged shape."""
+    from oracle import mgn_oracle as O
+
+    for (fin, hid, fout, norm, M) in ((128, 128, 128, True, 700), (11, 64, 64, True, 300), (128, 128, 3, False, 257)):
+        mlp = gp.build_mlp(fin, hid, fout, layer_norm=norm, act="gelu").to(dev)
+        sd = R.variant_params(mlp.state_dict(), 90 + fin)
+        mlp.load_state_dict(sd)
+        x, cot = R.randn((M, fin), 5), R.randn((M, fout), 6)
+        xd = x.to(dev).requires_grad_(fin == hid)
+        y = mlp(xd)
+        (y * cot.to(dev)).sum().backward()
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xo = x.clone().requires_grad_(True)
+        yo = O.mlp(xo, p, "", act="gelu")
+        (yo * cot).sum().backward()
+        assert_close3(y, yo.detach(), 1e-5, f"gelu forward {fin}-{hid}-{fout}")
+        for k, t in mlp.named_parameters():
+            assert rel_err(t.grad, p[k].grad) < 1e-4, (k, fin, hid, fout)
+        if fin == hid:
+            assert rel_err(xd.grad, xo.grad) < 1e-4
+    assert isinstance(mlp[1], torch.nn.Module) and float((mlp[1](torch.tensor([1.0], device=dev)) - 0.8413447).abs()) < 1e-6
