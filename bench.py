@@ -21,6 +21,8 @@ The JSON line also carries
   roofline_other_kernels   backward chain, weight gradients, inference-mode edge kernel (rollout),
   topology            CSR build time per batch + steps/s when the topology is rebuilt every step,
   plate_bf16          BASELINE configs[2]: plate meshes with world edges in the bf16 matrix mode (batch 1 and 16),
+  c5                  BASELINE configs[4]: the coarse-aneurysm Transformer (10 blocks, hidden 64, 4 heads) on a 3-D mesh, fp32 and
+                      bf16, with the sparse-attention kernels' HBM rooflines,
   c4                  BASELINE configs[3]: the 1M-node / 6M-edge mesh -- at N = 1 whole-mesh inference,
                       one rank's share of the 8-way partitioned training step, and the scatter-add
                       roofline past the 256 MiB Infinity Cache; at N > 1 the N-way partitioned
@@ -66,6 +68,7 @@ def parse():
     ap.add_argument("--no-c4", action="store_true", help="skip the 1M-node record (BASELINE configs[3])")
     ap.add_argument("--c4-nodes", type=int, default=1_000_000)
     ap.add_argument("--c4-steps", type=int, default=3)
+    ap.add_argument("--c5-nodes", type=int, default=150_000, help="nodes of the 3-D mesh of the configs[4] (Transformer) record")
     return ap.parse_args()
 
 
@@ -425,6 +428,97 @@ def PP_mesh_edges(g):
     return PP.faces_to_edges(g.face, g.x.shape[0]).shape[1]
 
 
+def c5_record(args, gp, ops, harness, dev):
+    """BASELINE configs[4]: training_config/coarse-aneurysm.json's model keys (Transformer processor: 10 blocks, hidden 64, 4 heads,
+    node_input_size 14 + 9 one-hot, output_size 3) on a synthetic 3-D tetrahedral mesh large enough to leave the Infinity Cache.
+    Inference forward and training step (forward + MSE + backward + clip + AdamW) in fp32 and in the bf16 matrix mode, and the
+    sparse-attention kernel on its own against the HBM roofline (it gathers two 4*hidden-byte rows per edge)."""
+    import numpy as np
+    from scipy.spatial import Delaunay
+
+    from graph_physics_amd import preprocess as PP
+    from graph_physics_amd import transformer as T
+
+    n = args.c5_nodes
+    rng = np.random.default_rng(0)
+    pts = rng.random((n, 3)).astype(np.float32)
+    cells = torch.from_numpy(Delaunay(pts).simplices.T.astype(np.int64)).to(dev)
+    ei = PP.faces_to_edges(cells, n)
+    E = int(ei.shape[1])
+    H, nh, L = 64, 4, 10
+    cfg = {"model": {"type": "transformer", "message_passing_num": L, "hidden_size": H, "node_input_size": 14, "output_size": 3,
+                     "edge_input_size": 0, "num_heads": nh, "use_rope_embeddings": False, "use_gated_attention": False},
+           "training": {"use_temporal_block": False}}
+    torch.manual_seed(0)
+    net = gp.get_model(cfg).to(dev)
+    graph = gp.Graph(x=torch.randn(n, 23, device=dev), edge_index=ei, pos=torch.from_numpy(pts).to(dev))
+    graph.mgn_attn_topology = T.get_attn_topology(ei, n)
+    tgt = torch.randn(n, 3, device=dev)
+    opt = harness.FusedClipAdamW(net.parameters(), 1e-4, max_norm=1.0)
+
+    def timed(fn, k=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k
+
+    def fwd():
+        with torch.no_grad():
+            net(graph)
+
+    def train():
+        loss = ((net(graph) - tgt) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    rec = {"workload": f"3-D Delaunay tetrahedral mesh N={n} E={E} (directed), EncodeTransformDecode {L} blocks, hidden {H}, {nh} heads, "
+                       "23 inputs, 3 outputs (training_config/coarse-aneurysm.json:11-22); BASELINE.json configs[4]"}
+    prev = ops.get_matrix_precision()
+    try:
+        for mode in ("fp32", "bf16"):
+            ops.set_matrix_precision(mode)
+            tf, tt = timed(fwd), timed(train)
+            rec[mode] = {"forward_ms": round(1e3 * tf, 2), "forward_node_steps_per_s": round(n / tf, 1), "train_ms_per_step": round(1e3 * tt, 2),
+                         "train_steps_per_s": round(1.0 / tt, 2)}
+    finally:
+        ops.set_matrix_precision(prev)
+    # the sparse-attention kernels on their own
+    topo = graph.mgn_attn_topology
+    q, k, v = (torch.randn(n, H, device=dev) for _ in range(3))
+    dy = torch.randn(n, H, device=dev)
+
+    def ev(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    t_f = ev(lambda: T.SparseAttentionFn.apply(q, k, v, topo, nh))
+    b_f = 2 * 4.0 * H * E + 3 * 4.0 * H * n + 4.0 * E + 4.0 * (n + 1)      # k, v rows per edge | q read, y + lse written per node | col, rowptr
+    rec["roofline_attention"] = hbm_obj("k_attn_fwd<16> (edge-masked QK^T -> online softmax -> AV over the CSR of the mesh adjacency: two gathered "
+                                        "256-byte rows per edge; no matrix cores)", t_f, b_f)
+    qg, kg, vg = (t.clone().requires_grad_(True) for t in (q, k, v))
+
+    def bwd():
+        y, _ = T.SparseAttentionFn.apply(qg, kg, vg, topo, nh)
+        y.backward(dy)
+
+    t_b = ev(bwd) - t_f
+    b_b = 4.0 * H * (5 * E) + 4.0 * H * 7 * n + 4.0 * nh * 4 * E       # rows of k, v (pass A), q, dy (pass B) + a / ds per edge and head written + read
+    rec["roofline_attention_backward"] = hbm_obj("k_attn_bwd_row + k_attn_bwd_col (two passes: by row dq + per-edge attn / dscore, by column dk, dv)",
+                                                 t_b, b_b)
+    return rec
+
+
 def c4_record(args, gp, D, ops, harness, rank, world, dev):
     """BASELINE configs[3]: synthetic Delaunay mesh (1M nodes / 6M directed edges), latent 128, 15 rounds."""
     from graph_physics_amd import partition as P
@@ -584,6 +678,11 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
     rec["train_ms_per_step"] = round(1e3 * t_tr, 2)
     rec["node_train_steps_per_s"] = round(n / t_tr, 1)
     rec["train_peak_mem_gib"] = round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)
+    ops.set_node_renumbering("off")
+    try:
+        rec["train_ms_per_step_raw_numbering"] = round(1e3 * timed(whole_train_step, 2), 2)
+    finally:
+        ops.set_node_renumbering("auto")
     rec["train_activation_recompute"] = ops.get_activation_recompute() + (
         " (on: saved activations would be %.0f GB)" % (ops.saved_activation_bytes(E, n, H, 4, args.rounds, 0) / 1e9))
     # What the same step costs WITHOUT the recompute (the N > 1 runs keep their saves): measured on a 5-round
@@ -754,6 +853,13 @@ def main():
             out["plate_bf16"] = plate_bf16_record(args, gp, ops, harness, dev)
         except Exception as ex:  # noqa: BLE001
             out["plate_bf16"] = {"error": f"{type(ex).__name__}: {ex}"}
+            ops.set_matrix_precision("fp32")
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_kernel_timing and not args.no_c4 and args.precision == "fp32":
+        try:
+            out["c5"] = c5_record(args, gp, ops, harness, dev)
+        except Exception as ex:  # noqa: BLE001
+            out["c5"] = {"error": f"{type(ex).__name__}: {ex}"}
             ops.set_matrix_precision("fp32")
         torch.cuda.empty_cache()
     if not args.no_c4:

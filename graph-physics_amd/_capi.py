@@ -145,10 +145,16 @@ class LinearArgs(C.Structure):
     """mgn_linear_args (include/mgn_hip.h)"""
     _fields_ = [
         ("M", C.c_int64), ("x", _f32p), ("ldx", C.c_int), ("K1", C.c_int), ("x2", _f32p), ("ldx2", C.c_int), ("K2", C.c_int),
+        ("x3", _f32p), ("ldx3", C.c_int), ("K3", C.c_int), ("idx", C.c_void_p), ("idx2", C.c_void_p), ("idx3", C.c_void_p),
         ("norm_scale", _f32p), ("eps", C.c_float), ("inv_out", _f32p), ("n_out", _f32p), ("W", _f32p), ("ldw", C.c_int), ("b", _f32p),
         ("W2", _f32p), ("b2", _f32p), ("act", C.c_int), ("N", C.c_int), ("resid", _f32p), ("ldr", C.c_int), ("out", _f32p),
         ("ldo", C.c_int), ("saveZ1", _f32p), ("saveZ2", _f32p), ("precision", C.c_int),
     ]
+
+
+class RownormPhase(C.Structure):
+    """mgn_rownorm_phase (include/mgn_hip.h)"""
+    _fields_ = [("x", _f32p), ("ldx", C.c_int), ("K", C.c_int), ("idx", C.c_void_p), ("dx", _f32p), ("lddx", C.c_int)]
 
 
 class OptTensor(C.Structure):
@@ -220,8 +226,8 @@ SYMBOLS = {
     "mgn_act_gate_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgn_rownorm_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgn_rownorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int]),
-    "mgn_rownorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
-                                  C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_rownorm_bwd": (C.c_int, [C.c_void_p, C.POINTER(RownormPhase), C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_dense_last_error": (C.c_char_p, []),
 }
 

@@ -38,13 +38,29 @@ static int dcheck(const char* what) {
   return 0;
 }
 
-__device__ __forceinline__ float bf16r(float v) {  // round to nearest even bf16, returned as fp32
-  unsigned u = __float_as_uint(v);
-  if ((u & 0x7f800000u) == 0x7f800000u) return v;
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return __uint_as_float(u & 0xffff0000u);
+// round to nearest-even bf16, returned as fp32 (v_cvt_pk_bf16_f32: the hardware conversion)
+typedef float f32x2_d __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bf16r2(float a, float b, float& ra, float& rb) {
+  const f32x2_d v = {a, b};
+  const unsigned q = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_d));
+  ra = __uint_as_float(q << 16);
+  rb = __uint_as_float(q & 0xffff0000u);
 }
-__device__ __forceinline__ f32x4 bf16r4(f32x4 v) { return f32x4{bf16r(v[0]), bf16r(v[1]), bf16r(v[2]), bf16r(v[3])}; }
+__device__ __forceinline__ float bf16r(float v) {
+  float a, b;
+  bf16r2(v, v, a, b);
+  return a;
+}
+__device__ __forceinline__ f32x4 bf16r4(f32x4 v) {
+  f32x4 o;
+  float a, b;
+  bf16r2(v[0], v[1], a, b);
+  o[0] = a, o[1] = b;
+  bf16r2(v[2], v[3], a, b);
+  o[2] = a, o[3] = b;
+  return o;
+}
 __device__ __forceinline__ float d_silu(float z) { return z / (1.0f + expf(-z)); }
 __device__ __forceinline__ float d_dsilu(float z) {
   const float sg = 1.0f / (1.0f + expf(-z));
@@ -75,11 +91,18 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
   const long m = ((long)blockIdx.x * 4 + wv) * 16 + c;
   const bool valid = m < a.M;
   const long mm = valid ? m : a.M - 1;
-  const int K = 16 * KB, kb1 = a.K1 >> 4;
+  const int K = 16 * KB, kb1 = a.K1 >> 4, kb2 = kb1 + (a.K2 >> 4);
+  // rows of the (up to three) input phases; a phase with an index row is GATHERED (x[dst], x[src] of an edge row: the
+  // concatenation cat[e, x_i, x_j] of GraphNetBlock.edge_update, layers.py:1044-1060, is never materialised)
+  const long r1 = a.idx != nullptr ? (long)a.idx[mm] : mm;
+  const long r2 = a.idx2 != nullptr ? (long)a.idx2[mm] : mm;
+  const long r3 = a.idx3 != nullptr ? (long)a.idx3[mm] : mm;
   f32x4 in[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb)
-    in[kb] = (kb < kb1) ? *(const f32x4*)(a.x + mm * a.ldx + 16 * kb + 4 * g) : *(const f32x4*)(a.x2 + mm * a.ldx2 + 16 * (kb - kb1) + 4 * g);
+    in[kb] = (kb < kb1)   ? *(const f32x4*)(a.x + r1 * a.ldx + 16 * kb + 4 * g)
+             : (kb < kb2) ? *(const f32x4*)(a.x2 + r2 * a.ldx2 + 16 * (kb - kb1) + 4 * g)
+                          : *(const f32x4*)(a.x3 + r3 * a.ldx3 + 16 * (kb - kb2) + 4 * g);
   if (a.norm_scale != nullptr) {  // RMSNorm prologue, reference epsilon placement: scale * x / (||x|| / sqrt(K) + eps)
     float ss = 0.f;
 #pragma unroll
@@ -144,9 +167,11 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
 extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
   const mgn_linear_args& a = *args;
   if (a.M < 0 || a.x == nullptr || a.W == nullptr || a.out == nullptr) return dfail(1, "mgn_linear_fwd: missing operand");
-  const int K = a.K1 + a.K2;
-  if (a.K1 < 16 || (a.K1 & 15) || a.K2 < 0 || (a.K2 & 15) || K > 384 || (a.K2 > 0 && a.x2 == nullptr))
+  const int K = a.K1 + a.K2 + a.K3;
+  if (a.K1 < 16 || (a.K1 & 15) || a.K2 < 0 || (a.K2 & 15) || a.K3 < 0 || (a.K3 & 15) || K > 384 || (a.K2 > 0 && a.x2 == nullptr) ||
+      (a.K3 > 0 && (a.x3 == nullptr || a.K2 == 0)))
     return dfail(1, "mgn_linear_fwd: input widths must be multiples of 16, at most 384 together");
+  if (a.K3 > 0 && (a.ldx3 < a.K3 || (a.ldx3 & 3))) return dfail(1, "mgn_linear_fwd: bad leading dimension of the third phase");
   if (a.N < 16 || (a.N & 15) || a.N > 1024) return dfail(1, "mgn_linear_fwd: output width must be a multiple of 16");
   if (a.ldx < a.K1 || (a.ldx & 3) || (a.K2 > 0 && (a.ldx2 < a.K2 || (a.ldx2 & 3))) || a.ldw < K || (a.ldw & 3) || a.ldo < a.N || (a.ldo & 3) ||
       (a.resid != nullptr && (a.ldr < a.N || (a.ldr & 3))))
@@ -243,30 +268,42 @@ extern "C" int mgn_rownorm_fwd(const float* x, int ldx, int K, const float* scal
 // ------------------------------------------------------------------ RMSNorm-prologue backward
 // n = s * x c, c = 1 / (||x|| / sqrt(K) + eps):   dx = c g - x c^2 <g, x> / (K r),  g = s dn,  r = ||x|| / sqrt(K);
 // dscale partial of the workgroup's rows: sum_rows dn * x c.   One wave per row pass, lane l owns columns l, l + 64, ...
+struct RnPhases {
+  const float* x[3];
+  const int32_t* idx[3];
+  int ld[3];
+  float* dx[3];
+  int lddx[3];
+  int k0[4];   // first column of each phase, k0[3] = K
+};
 template <int KPL>  // columns per lane (K / 64 rounded up)
-__global__ void __launch_bounds__(256) k_rownorm_bwd(const float* __restrict__ dn, const float* __restrict__ x, int ldx, const float* __restrict__ x2,
-                                                    int ldx2, int K1, int K, const float* __restrict__ inv, const float* __restrict__ scale,
-                                                    float eps, long M, float* __restrict__ dx, int lddx, float* __restrict__ dx2, int lddx2,
-                                                    float* __restrict__ part) {
+__global__ void __launch_bounds__(256) k_rownorm_bwd(const float* __restrict__ dn, const RnPhases P, int K, const float* __restrict__ inv,
+                                                    const float* __restrict__ scale, float eps, long M, float* __restrict__ part) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float ds[KPL];
   float sc[KPL];
+  int ph[KPL];
 #pragma unroll
   for (int j = 0; j < KPL; ++j) {
     ds[j] = 0.f;
     const int k = lane + 64 * j;
     sc[j] = (k < K) ? scale[k] : 0.f;
+    ph[j] = (k < P.k0[1]) ? 0 : (k < P.k0[2]) ? 1 : 2;
   }
   for (long m = (long)blockIdx.x * 4 + wv; m < M; m += (long)gridDim.x * 4) {
     float xv[KPL], gv[KPL];
     float dot = 0.f;
     const float c = inv[m];
+    long row[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) row[p] = (P.idx[p] != nullptr) ? (long)P.idx[p][m] : m;
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
       const int k = lane + 64 * j;
       xv[j] = 0.f, gv[j] = 0.f;
       if (k < K) {
-        xv[j] = (k < K1) ? x[m * ldx + k] : x2[m * ldx2 + (k - K1)];
+        const int p = ph[j];
+        xv[j] = P.x[p][row[p] * P.ld[p] + (k - P.k0[p])];
         const float d = dn[m * K + k];
         ds[j] += d * xv[j] * c;
         gv[j] = sc[j] * d;
@@ -281,9 +318,8 @@ __global__ void __launch_bounds__(256) k_rownorm_bwd(const float* __restrict__ d
     for (int j = 0; j < KPL; ++j) {
       const int k = lane + 64 * j;
       if (k < K) {
-        const float v = c * gv[j] - xv[j] * k2;
-        if (k < K1) dx[m * lddx + k] = v;
-        else dx2[m * lddx2 + (k - K1)] = v;
+        const int p = ph[j];
+        P.dx[p][m * P.lddx[p] + (k - P.k0[p])] = c * gv[j] - xv[j] * k2;   // per EDGE row: the caller sums gathered phases over their segments
       }
     }
   }
@@ -303,22 +339,35 @@ __global__ void __launch_bounds__(256) k_colsum_parts(const float* __restrict__ 
 
 #define RN_GRID 512
 extern "C" size_t mgn_rownorm_bwd_workspace_bytes(int K) { return (size_t)RN_GRID * (K > 0 ? K : 0) * sizeof(float); }
-extern "C" int mgn_rownorm_bwd(const float* dn, const float* x, int ldx, const float* x2, int ldx2, int K1, int K2, const float* inv,
-                               const float* scale, float eps, int64_t M, float* dx, int lddx, float* dx2, int lddx2, float* dscale, void* ws,
-                               size_t ws_bytes, void* stream) {
-  const int K = K1 + K2;
-  if (M < 0 || dn == nullptr || x == nullptr || inv == nullptr || scale == nullptr || dx == nullptr || dscale == nullptr || K1 < 1 || K2 < 0 ||
-      K > 384 || (K2 > 0 && (x2 == nullptr || dx2 == nullptr)))
-    return dfail(1, "mgn_rownorm_bwd: bad arguments (at most 384 columns)");
+extern "C" int mgn_rownorm_bwd(const float* dn, const mgn_rownorm_phase* phases, int nphase, const float* inv, const float* scale, float eps,
+                               int64_t M, float* dscale, void* ws, size_t ws_bytes, void* stream) {
+  if (M < 0 || dn == nullptr || phases == nullptr || nphase < 1 || nphase > 3 || inv == nullptr || scale == nullptr || dscale == nullptr)
+    return dfail(1, "mgn_rownorm_bwd: bad arguments");
+  RnPhases P;
+  int K = 0;
+  for (int p = 0; p < 3; ++p) {
+    const bool on = p < nphase;
+    if (on && (phases[p].x == nullptr || phases[p].dx == nullptr || phases[p].K < 1 || phases[p].ldx < phases[p].K || phases[p].lddx < phases[p].K))
+      return dfail(1, "mgn_rownorm_bwd: bad phase");
+    P.x[p] = on ? phases[p].x : phases[0].x;
+    P.idx[p] = on ? phases[p].idx : nullptr;
+    P.ld[p] = on ? phases[p].ldx : 0;
+    P.dx[p] = on ? phases[p].dx : phases[0].dx;
+    P.lddx[p] = on ? phases[p].lddx : 0;
+    P.k0[p] = K;
+    K += on ? phases[p].K : 0;
+  }
+  P.k0[3] = K;
+  for (int p = nphase; p < 3; ++p) P.k0[p] = K;
+  if (K > 384) return dfail(1, "mgn_rownorm_bwd: at most 384 columns");
   if (ws == nullptr || ws_bytes < mgn_rownorm_bwd_workspace_bytes(K)) return dfail(1, "mgn_rownorm_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   unsigned grid = (unsigned)((M + 3) / 4);
   if (grid > RN_GRID) grid = RN_GRID;
   if (grid == 0) grid = 1;
   float* part = (float*)ws;
-  const int kpl = (K + 63) / 64;
-  switch (kpl) {
-#define RN_CASE(P_) case P_: hipLaunchKernelGGL(k_rownorm_bwd<P_>, dim3(grid), dim3(256), 0, s, dn, x, ldx, x2, ldx2, K1, K, inv, scale, eps, (long)M, dx, lddx, dx2, lddx2, part); break;
+  switch ((K + 63) / 64) {
+#define RN_CASE(P_) case P_: hipLaunchKernelGGL(k_rownorm_bwd<P_>, dim3(grid), dim3(256), 0, s, dn, P, K, inv, scale, eps, (long)M, part); break;
     RN_CASE(1) RN_CASE(2) RN_CASE(3) RN_CASE(4) RN_CASE(5) RN_CASE(6)
 #undef RN_CASE
     default: return dfail(1, "mgn_rownorm_bwd: width out of range");

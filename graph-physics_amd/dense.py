@@ -22,16 +22,21 @@ def _prec() -> int:
 
 
 def linear_launch(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act: int = ACT_NONE, resid=None, out=None, inv_out=None,
-                  n_out=None, saveZ1=None, saveZ2=None, precision: int = 0):
-    """one ``mgn_linear_fwd`` launch (include/mgn_hip.h); x / x2 / resid may be row-strided views (stride(1) == 1)"""
-    M, K1 = int(x.shape[0]), int(x.shape[1])
+                  n_out=None, saveZ1=None, saveZ2=None, precision: int = 0, x3=None, idx=(None, None, None), M: Optional[int] = None):
+    """one ``mgn_linear_fwd`` launch (include/mgn_hip.h); x / x2 / x3 / resid may be row-strided views (stride(1) == 1);
+    ``idx[p]`` (int32 [M]) gathers the rows of phase p; ``M`` = output rows (default: rows of x)."""
+    M = int(x.shape[0]) if M is None else int(M)
+    K1 = int(x.shape[1])
     K2 = int(x2.shape[1]) if x2 is not None else 0
+    K3 = int(x3.shape[1]) if x3 is not None else 0
     N = int(W.shape[0])
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     a = _capi.LinearArgs()
     a.M, a.x, a.ldx, a.K1 = M, x.data_ptr(), int(x.stride(0)), K1
     a.x2, a.ldx2, a.K2 = (x2.data_ptr() if x2 is not None else None), (int(x2.stride(0)) if x2 is not None else 0), K2
+    a.x3, a.ldx3, a.K3 = (x3.data_ptr() if x3 is not None else None), (int(x3.stride(0)) if x3 is not None else 0), K3
+    a.idx, a.idx2, a.idx3 = ops._ptr(idx[0]), ops._ptr(idx[1]), ops._ptr(idx[2])
     a.norm_scale, a.eps = ops._ptr(norm_scale), ops.EPS
     a.inv_out, a.n_out = ops._ptr(inv_out), ops._ptr(n_out)
     a.W, a.ldw, a.b = W.data_ptr(), int(W.stride(0)), ops._ptr(b)
@@ -55,43 +60,50 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
 
 
 class DenseFn(torch.autograd.Function):
-    """out = [resid +] epi(n W^T + b),  n = RMSNorm(cat[x, x2]; norm_scale) or cat[x, x2];
-    epi(z) = act(z) [* (n W2^T + b2)]                       (see include/mgn_hip.h, mgn_linear_fwd)"""
+    """out = [resid +] epi(n W^T + b),  n = RMSNorm(cat[x, x2, x3]; norm_scale) or the plain concatenation;
+    epi(z) = act(z) [* (n W2^T + b2)]                       (see include/mgn_hip.h, mgn_linear_fwd)
+    ``gather`` = (topology, ("dst" | "src" | None) per phase): a gathered phase reads x_p[topo.dst_s / src_s] per edge row and
+    its input gradient is the CSR segment sum over the same grouping (atomics-free, hub-safe)."""
 
     @staticmethod
-    def forward(ctx, x, x2, W, b, W2, b2, norm_scale, resid, act: int, precision: int):
-        ops._require_device(x, x2, W, b, W2, b2, norm_scale, resid)
-        x = _rows(x)
-        x2 = _rows(x2) if x2 is not None else None
+    def forward(ctx, x, x2, x3, W, b, W2, b2, norm_scale, resid, act: int, precision: int, gather):
+        ops._require_device(x, x2, x3, W, b, W2, b2, norm_scale, resid)
+        xs = [_rows(t) if t is not None else None for t in (x, x2, x3)]
         resid = _rows(resid) if resid is not None else None
         W = ops._f32c(W)
         W2 = ops._f32c(W2) if W2 is not None else None
-        M, K = x.shape[0], x.shape[1] + (x2.shape[1] if x2 is not None else 0)
+        topo, by = gather if gather is not None else (None, (None, None, None))
+        idx = tuple((topo.dst_s if g_ == "dst" else topo.src_s) if g_ is not None else None for g_ in by)
+        M = topo.E if any(g_ is not None for g_ in by) else xs[0].shape[0]
+        K = sum(t.shape[1] for t in xs if t is not None)
         N = W.shape[0]
-        dev = x.device
+        dev = xs[0].device
         need = any(ctx.needs_input_grad) and ops._saving()
         f = dict(dtype=torch.float32, device=dev)
-        smooth = act != ACT_NONE
-        Z1 = torch.empty(M, N, **f) if (need and (smooth or W2 is not None)) else None
+        if any(g_ is not None for g_ in by) and norm_scale is None and need:
+            raise NotImplementedError("gathered phases without the norm prologue have no weight-gradient operand")
+        Z1 = torch.empty(M, N, **f) if (need and (act != ACT_NONE or W2 is not None)) else None
         Z2 = torch.empty(M, N, **f) if (need and W2 is not None) else None
         inv = torch.empty(M, **f) if (need and norm_scale is not None) else None
         n_out = torch.empty(M, K, **f) if (need and norm_scale is not None) else None
-        out = linear_launch(x, W, b, x2, W2, b2, norm_scale, act, resid, None, inv, n_out, Z1, Z2, precision)
-        ctx.save_for_backward(x, x2, W, W2, norm_scale)
-        ctx.aux = (act, precision, Z1, Z2, inv, n_out, b is not None, b2 is not None, resid is not None)
+        out = linear_launch(xs[0], W, b, xs[1], W2, b2, norm_scale, act, resid, None, inv, n_out, Z1, Z2, precision, xs[2], idx, M)
+        ctx.save_for_backward(xs[0], xs[1], xs[2], W, W2, norm_scale)
+        ctx.aux = (act, precision, Z1, Z2, inv, n_out, b is not None, b2 is not None, resid is not None, topo, by, idx, M)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, x2, W, W2, norm_scale = ctx.saved_tensors
-        act, prec, Z1, Z2, inv, n_out, has_b, has_b2, has_res = ctx.aux
-        if ctx.aux is None or (Z1 is None and (act != ACT_NONE or W2 is not None)):
-            raise RuntimeError("DenseFn: no saved activations (the forward ran under no_grad, or backward ran twice)")
+        if ctx.aux is None:
+            raise RuntimeError("DenseFn: backward ran twice (the saved activations are released eagerly)")
+        x, x2, x3, W, W2, norm_scale = ctx.saved_tensors
+        act, prec, Z1, Z2, inv, n_out, has_b, has_b2, has_res, topo, by, idx, M = ctx.aux
+        if Z1 is None and (act != ACT_NONE or W2 is not None):
+            raise RuntimeError("DenseFn: no saved activations (the forward ran under no_grad)")
+        xs = [x, x2, x3]
         dy = ops._f32c(dy)
-        M, N = dy.shape
-        K1 = x.shape[1]
-        K2 = x2.shape[1] if x2 is not None else 0
-        K = K1 + K2
+        N = dy.shape[1]
+        Ks = [t.shape[1] if t is not None else 0 for t in xs]
+        K = sum(Ks)
         dev = dy.device
         f = dict(dtype=torch.float32, device=dev)
         L = _capi.lib()
@@ -105,34 +117,55 @@ class DenseFn(torch.autograd.Function):
         else:
             dZ1, dZ2 = dy, None
         # ---- input gradient: dn = dZ1 W (+ dZ2 W2) -- the same launch with the transposed weight
-        want_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
-        dx = dx2 = dscale = None
-        if (want_dx or norm_scale is not None) and M > 0:
+        want = [xs[p] is not None and ctx.needs_input_grad[p] for p in range(3)]
+        dxs = [None, None, None]
+        dscale = None
+        if M > 0 and (any(want) or norm_scale is not None):
             if N > 384:
                 raise NotImplementedError("input gradient of a Linear wider than 384 outputs")
             dn = linear_launch(dZ1, W.t().contiguous(), precision=prec)
             if W2 is not None:
                 dn = linear_launch(dZ2, W2.t().contiguous(), resid=dn, precision=prec)
             if norm_scale is not None:
-                dx = torch.empty(M, K1, **f)
-                dx2 = torch.empty(M, K2, **f) if x2 is not None else None
+                nph = sum(1 for t in xs if t is not None)
+                rows = [torch.empty(M, Ks[p], **f) for p in range(nph)]       # per (edge) row
+                arr = (_capi.RownormPhase * nph)()
+                for p in range(nph):
+                    arr[p].x, arr[p].ldx, arr[p].K, arr[p].idx = xs[p].data_ptr(), int(xs[p].stride(0)), Ks[p], ops._ptr(idx[p])
+                    arr[p].dx, arr[p].lddx = rows[p].data_ptr(), Ks[p]
                 dscale = torch.empty(K, **f)
                 ws = torch.empty(max(L.mgn_rownorm_bwd_workspace_bytes(K), 16), dtype=torch.uint8, device=dev)
                 with torch.cuda.device(dev):
-                    rc = L.mgn_rownorm_bwd(dn.data_ptr(), x.data_ptr(), int(x.stride(0)), ops._ptr(x2), int(x2.stride(0)) if x2 is not None else 0,
-                                           K1, K2, inv.data_ptr(), norm_scale.data_ptr(), ops.EPS, M, dx.data_ptr(), K1, ops._ptr(dx2), K2,
-                                           dscale.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream(dev))
+                    rc = L.mgn_rownorm_bwd(dn.data_ptr(), arr, nph, inv.data_ptr(), norm_scale.data_ptr(), ops.EPS, M, dscale.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), ops._stream(dev))
                 _capi.check(rc, "mgn_rownorm_bwd", dense=True)
-            elif x2 is not None:
-                dx, dx2 = dn[:, :K1], dn[:, K1:]
             else:
-                dx = dn
+                rows, k0 = [], 0
+                for p in range(3):
+                    if xs[p] is not None:
+                        rows.append(dn[:, k0:k0 + Ks[p]])
+                        k0 += Ks[p]
+            for p in range(len(rows)):
+                if not want[p]:
+                    continue
+                if by[p] is not None:   # gathered phase: sum the edge rows over their segments (the gather's transpose)
+                    src_rows = rows[p] if rows[p].is_contiguous() else rows[p].contiguous()
+                    out_n = torch.empty(xs[p].shape[0], Ks[p], **f)
+                    dxs[p] = ops.segsum_topo(src_rows, topo, by[p], out_n)
+                else:
+                    dxs[p] = rows[p]
         elif M == 0:
-            dx = torch.zeros(0, K1, **f)
-            dx2 = torch.zeros(0, K2, **f) if x2 is not None else None
+            dxs = [torch.zeros(t.shape[0], t.shape[1], **f) if t is not None else None for t in xs]
             dscale = torch.zeros(K, **f) if norm_scale is not None else None
         # ---- weight / bias gradients: dW = dZ^T n on the engine's weight-gradient kernel, 128-column slabs
-        nsrc = n_out if norm_scale is not None else None
+        if norm_scale is not None:
+            srcs = [(n_out, 0, K)]
+        else:
+            srcs, k0 = [], 0
+            for p in range(3):
+                if xs[p] is not None:
+                    srcs.append((xs[p], k0, Ks[p]))
+                    k0 += Ks[p]
 
         def wgrad_of(dZ, want_b):
             dW = torch.empty(N, K, **f) if M > 0 else torch.zeros(N, K, **f)
@@ -142,12 +175,11 @@ class DenseFn(torch.autograd.Function):
                 nj = min(128, N - j0)
                 A = dZ[:, j0:j0 + nj]
                 first = True
-                srcs = [(nsrc, 0, K)] if nsrc is not None else ([(x, 0, K1)] + ([(x2, K1, K2)] if x2 is not None else []))
                 for src, koff, kw_all in srcs:
-                    for k0 in range(0, kw_all, 128):
-                        nk = min(128, kw_all - k0)
-                        B = src[:, k0:k0 + nk]
-                        job = (A, int(dZ.stride(0)), nj // 16, B, int(src.stride(0)), nk // 16, nk, dW, j0 * K + koff + k0, K)
+                    for k0_ in range(0, kw_all, 128):
+                        nk = min(128, kw_all - k0_)
+                        B = src[:, k0_:k0_ + nk]
+                        job = (A, int(dZ.stride(0)), nj // 16, B, int(src.stride(0)), nk // 16, nk, dW, j0 * K + koff + k0_, K)
                         if first and db is not None:
                             job = job + (db[j0:j0 + nj],)
                         first = False
@@ -161,15 +193,16 @@ class DenseFn(torch.autograd.Function):
         if W2 is not None:
             dW2, db2 = wgrad_of(dZ2, has_b2)
         ctx.aux = None
-        return (dx if ctx.needs_input_grad[0] else None, dx2 if (x2 is not None and ctx.needs_input_grad[1]) else None, dW, db, dW2, db2,
-                dscale, dy if has_res else None, None, None)
+        return (dxs[0] if want[0] else None, dxs[1] if want[1] else None, dxs[2] if want[2] else None, dW, db, dW2, db2,
+                dscale, dy if has_res else None, None, None, None)
 
 
-def dense(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act: Optional[str] = None, resid=None):
-    """fused Linear on the engine (module docstring); ``act``: None / "relu" / "silu" / "gelu"."""
+def dense(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act: Optional[str] = None, resid=None, x3=None, gather=None):
+    """fused Linear on the engine (module docstring); ``act``: None / "relu" / "silu" / "gelu"; ``gather`` = (topology,
+    (by_1, by_2, by_3)) with by_p in ("dst", "src", None)."""
     ops._call.grad = torch.is_grad_enabled()
     try:
-        return DenseFn.apply(x, x2, W, b, W2, b2, norm_scale, resid, ACT_IDS[act], _prec())
+        return DenseFn.apply(x, x2, x3, W, b, W2, b2, norm_scale, resid, ACT_IDS[act], _prec(), gather)
     finally:
         ops._call.grad = True
 
@@ -224,9 +257,11 @@ class RMSNormFn(torch.autograd.Function):
         if M > 0:
             L = _capi.lib()
             ws = torch.empty(max(L.mgn_rownorm_bwd_workspace_bytes(K), 16), dtype=torch.uint8, device=dev)
+            arr = (_capi.RownormPhase * 1)()
+            arr[0].x, arr[0].ldx, arr[0].K, arr[0].idx, arr[0].dx, arr[0].lddx = x.data_ptr(), int(x.stride(0)), K, None, dx.data_ptr(), K
             with torch.cuda.device(dev):
-                rc = L.mgn_rownorm_bwd(dy.data_ptr(), x.data_ptr(), int(x.stride(0)), None, 0, K, 0, inv.data_ptr(), scale.data_ptr(), ops.EPS, M,
-                                       dx.data_ptr(), K, None, 0, dscale.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream(dev))
+                rc = L.mgn_rownorm_bwd(dy.data_ptr(), arr, 1, inv.data_ptr(), scale.data_ptr(), ops.EPS, M, dscale.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), ops._stream(dev))
             _capi.check(rc, "mgn_rownorm_bwd", dense=True)
         return dx.reshape(ctx.shape), dscale
 

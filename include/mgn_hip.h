@@ -526,8 +526,9 @@ const char* mgn_attn_last_error(void);
  *   out = [resid +] epi( n W^T + b ),   n = RMSNorm(cat[x, x2]) if norm_scale else cat[x, x2]      (RMSNorm :73-129)
  *   epi(z) = act(z)                       (act = MGN_ACT_NONE / _RELU / _SILU / _GELU)
  *          = act(z) * (n W2^T + b2)       when W2 is given  (the gated product of GatedMLP, :249-253)
- * x [M, ldx] (first K1 columns), x2 [M, ldx2] (first K2 columns, optional: a concatenation that is never materialised);
- * K1, K2 multiples of 16, K1 + K2 in {16,32,48,64,96,128,192,256,384}; W, W2 [N, ldw] row-major (nn.Linear layout),
+ * x [*, ldx] (first K1 columns), x2 / x3 (optional further phases: a concatenation that is never materialised), each optionally
+ * GATHERED through an int32 index row (the cat[e, x[dst], x[src]] of GraphNetBlock.edge_update, layers.py:1044-1060);
+ * K1, K2, K3 multiples of 16, their sum in {16,32,48,64,96,128,192,256,384}; W, W2 [N, ldw] row-major (nn.Linear layout),
  * N a multiple of 16.  Optional outputs for the backward pass: inv_out [M] = 1 / (rms + eps), n_out [M, K1 + K2] = the
  * normalised input (the B operand of the weight gradient), saveZ1 / saveZ2 [M, N] = the pre-activations.
  * precision 1 = the reference under Lightning bf16-mixed (autocast runs nn.Linear in bf16, train.py:74-78): operands and
@@ -539,6 +540,8 @@ typedef struct {
   int64_t M;
   const float* x; int ldx; int K1;
   const float* x2; int ldx2; int K2;
+  const float* x3; int ldx3; int K3;            /* third phase (optional; needs the second) */
+  const int32_t* idx; const int32_t* idx2; const int32_t* idx3;   /* optional gather rows per phase (int32 [M]): phase p reads x_p[idx_p[m]] */
   const float* norm_scale; float eps;
   float* inv_out;
   float* n_out;
@@ -560,12 +563,17 @@ int mgn_act_gate_bwd(const float* dP, const float* Z1, const float* Z2, int64_t 
                      float* dZ2, void* stream);
 /* stand-alone RMSNorm (layers.py:73-129): y [M, K] = scale * x / (||x|| / sqrt(K) + eps), inv_out [M] optional */
 int mgn_rownorm_fwd(const float* x, int ldx, int K, const float* scale, float eps, int64_t M, float* y, float* inv_out, void* stream);
-/* backward of the RMSNorm prologue: from dn [M, K1 + K2] (gradient of the normalised input), the raw rows, inv and scale:
- * dx [M, lddx] (K1 columns), dx2 [M, lddx2] (K2 columns), dscale [K1 + K2] (fixed summation order). */
+/* backward of the RMSNorm prologue: from dn [M, K] (gradient of the normalised concatenated input), the raw rows of the (up to three,
+ * optionally gathered) phases, inv and scale: per phase dx [M, lddx] IN ROW SPACE (a gathered phase's rows are summed over their
+ * segments by the caller: mgn_segsum), dscale [K] (fixed summation order). */
+typedef struct {
+  const float* x; int ldx; int K;
+  const int32_t* idx;
+  float* dx; int lddx;
+} mgn_rownorm_phase;
 size_t mgn_rownorm_bwd_workspace_bytes(int K);
-int mgn_rownorm_bwd(const float* dn, const float* x, int ldx, const float* x2, int ldx2, int K1, int K2, const float* inv,
-                    const float* scale, float eps, int64_t M, float* dx, int lddx, float* dx2, int lddx2, float* dscale, void* ws,
-                    size_t ws_bytes, void* stream);
+int mgn_rownorm_bwd(const float* dn, const mgn_rownorm_phase* phases, int nphase, const float* inv, const float* scale, float eps,
+                    int64_t M, float* dscale, void* ws, size_t ws_bytes, void* stream);
 const char* mgn_dense_last_error(void);
 
 #ifdef __cplusplus

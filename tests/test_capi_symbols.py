@@ -35,7 +35,7 @@ def test_struct_layout_matches_header(tmp_path):
     from graph_physics_amd import _capi as c
 
     structs = {"mgn_mlp_fwd_args": c.MlpFwdArgs, "mgn_mlp_bwd_args": c.MlpBwdArgs, "mgn_wgrad_job": c.WgradJob,
-               "mgn_tblock": c.TBlock, "mgn_wpack_block": c.WpackBlock, "mgn_edge_bwd_fused_args": c.EdgeBwdFusedArgs, "mgn_linear_args": c.LinearArgs}
+               "mgn_tblock": c.TBlock, "mgn_wpack_block": c.WpackBlock, "mgn_edge_bwd_fused_args": c.EdgeBwdFusedArgs, "mgn_linear_args": c.LinearArgs, "mgn_rownorm_phase": c.RownormPhase}
     cc = shutil.which("gcc") or shutil.which("cc")
     assert cc, "a C compiler is part of the toolchain contract"
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "mgn_hip.h"', "int main(void) {"]

@@ -276,3 +276,33 @@ def test_transformer_block_bf16_mode_vs_mixed_oracle(dev):
     assert 1e-4 < rel_err(outs["bf16"][0], ref[False][0]) < 3e-2    # really the bf16 path
     assert e16 < 0.5 * gap + 1e-3, (e16, gap)                       # tracks the mixed oracle much closer than fp32 does
     assert rms_err(outs["bf16"][1], ref[True][1]) < max(1.5 * rms_err(ref[True][1], ref[False][1]), 2e-2)
+
+
+@pytest.mark.gpu
+def test_no_library_gemm_and_no_concat_on_the_transformer_and_gated_paths(dev, monkeypatch):
+    """the dense half of a Transformer block, TemporalAttention and the use_gated_mlp GraphNetBlock run on the engine's fused
+    Linear launches: torch.nn.functional.linear and torch.cat are never called on their forward / backward paths"""
+    import graph_physics_amd as gp
+
+    N, H = 400, 64
+    pos, ei, ea = R.delaunay_graph(N, 5, dim=3)
+    x = R.randn((N, H), 1).to(dev).requires_grad_(True)
+    blk = gp.Transformer(H, H, 4, use_gated_attention=True).to(dev)
+    tmp = gp.TemporalAttention(H).to(dev)
+    gnb = gp.GraphNetBlock(128, use_gated_mlp=True, use_gate=True).to(dev)
+    x128 = R.randn((N, 128), 2).to(dev).requires_grad_(True)
+    e128 = R.randn((ei.shape[1], 128), 3).to(dev).requires_grad_(True)
+    eid = ei.to(dev)
+
+    def boom(*a, **k):
+        raise AssertionError("library GEMM / concatenation on an engine path")
+
+    monkeypatch.setattr(torch.nn.functional, "linear", boom)
+    monkeypatch.setattr(torch, "cat", boom)
+    y = blk(x, eid)
+    z = tmp(x, y, eid)
+    xn, en = gnb(x128, eid, e128)
+    (y.sum() + z.sum() + xn.sum() + en.sum()).backward()
+    torch.cuda.synchronize()
+    assert x.grad is not None and x128.grad is not None and e128.grad is not None
+    assert all(p.grad is not None for p in list(blk.parameters()) + list(tmp.parameters()))
