@@ -66,6 +66,7 @@ def parse():
                     help="matrix precision of the processor GEMMs: fp32 = BASELINE configs[1] (headline); bf16 = the "
                          "reference's bf16-mixed semantic (configs[2]-style), reported with dtype bf16")
     ap.add_argument("--no-c4", action="store_true", help="skip the 1M-node record (BASELINE configs[3])")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch1 / plate_bf16 / c5 records (a kernel trace of the headline alone)")
     ap.add_argument("--c4-nodes", type=int, default=1_000_000)
     ap.add_argument("--c4-steps", type=int, default=3)
     ap.add_argument("--c5-nodes", type=int, default=150_000, help="nodes of the 3-D mesh of the configs[4] (Transformer) record")
@@ -842,20 +843,20 @@ def main():
     # free the configs[1] state before the 1M-node record
     del eng, batch, frames, rollout, step
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_kernel_timing:
+    if rank == 0 and world == 1 and not args.no_kernel_timing and not args.no_extras:
         try:
             out["batch1"] = batch1_record(args, gp, ops, harness, dev)
         except Exception as ex:  # noqa: BLE001  (an extra record must not cost the headline)
             out["batch1"] = {"error": f"{type(ex).__name__}: {ex}"}
         torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_kernel_timing and args.precision == "fp32":
+    if rank == 0 and world == 1 and not args.no_kernel_timing and not args.no_extras and args.precision == "fp32":
         try:
             out["plate_bf16"] = plate_bf16_record(args, gp, ops, harness, dev)
         except Exception as ex:  # noqa: BLE001
             out["plate_bf16"] = {"error": f"{type(ex).__name__}: {ex}"}
             ops.set_matrix_precision("fp32")
         torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_kernel_timing and not args.no_c4 and args.precision == "fp32":
+    if rank == 0 and world == 1 and not args.no_kernel_timing and not args.no_c4 and not args.no_extras and args.precision == "fp32":
         try:
             out["c5"] = c5_record(args, gp, ops, harness, dev)
         except Exception as ex:  # noqa: BLE001

@@ -306,3 +306,84 @@ def test_no_library_gemm_and_no_concat_on_the_transformer_and_gated_paths(dev, m
     torch.cuda.synchronize()
     assert x.grad is not None and x128.grad is not None and e128.grad is not None
     assert all(p.grad is not None for p in list(blk.parameters()) + list(tmp.parameters()))
+
+
+# ----------------------------------------------------------------------------- configs[4] at scale, fp32 and bf16
+ANEURYSM = {"model": {"type": "transformer", "message_passing_num": 10, "hidden_size": 64, "node_input_size": 14, "output_size": 3,
+                      "edge_input_size": 0, "num_heads": 4, "use_silu_activation": False, "use_rope_embeddings": False,
+                      "use_gated_attention": False},
+            "training": {"use_temporal_block": False}}   # training_config/coarse-aneurysm.json:11-22,41-45
+
+
+@pytest.mark.gpu
+def test_coarse_aneurysm_config_at_12000_nodes_vs_oracle(dev):
+    """BASELINE configs[4] with the JSON's exact model keys on a 12 000-node 3-D tetrahedral mesh (E ~ 180 000): forward at
+    1e-5 in three readings and every parameter gradient against the oracle (oracle-only: the reference-minted fixture of the
+    same keys is `etd_aneurysm`, N = 500)."""
+    import graph_physics_amd as gp
+
+    N, seed = 12000, 606
+    pos, ei, _ = R.delaunay_graph(N, seed, dim=3)
+    net = gp.get_model(ANEURYSM).to(dev)
+    params = R.variant_params(net.state_dict(), seed)
+    net.load_state_dict(params)
+    x_in, cot = R.randn((N, 23), seed + 1), R.randn((N, 3), seed + 3)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.etd_forward(x_in, ei, p, 10, 4)
+    (ref * cot).sum().backward()
+    out = net(gp.Graph(x=x_in.to(dev), edge_index=ei.to(dev), pos=pos.to(dev)))
+    (out * cot.to(dev)).sum().backward()
+    assert_close3(out, ref.detach(), FWD_TOL, "coarse-aneurysm forward, N = 12000")
+    worst = 0.0
+    for k, t in net.named_parameters():
+        gref = p[k].grad
+        if k.endswith("k_proj.bias"):          # softmax-invariant: rounding noise on both sides
+            assert float(t.grad.abs().max()) < 1e-3 * max(1.0, float(p[k.replace("k_proj.bias", "q_proj.bias")].grad.abs().max()))
+            continue
+        e = rel_err(t.grad, gref)
+        worst = max(worst, e)
+        # ReLU encoder / decoder: a pre-activation at rounding distance from zero may take the other branch (test_hip_configs._check_grads)
+        assert e < (2e-3 if ("encoder" in k or "decode" in k) else 2e-4), (k, e)
+    print(f"coarse-aneurysm N=12000: worst parameter-gradient error {worst:.2e}")
+
+
+@pytest.mark.gpu
+def test_coarse_aneurysm_config_bf16_mode_vs_mixed_oracle(dev):
+    """configs[4] in its stated precision: the 10 Transformer blocks in the bf16 matrix mode (encoder / decoder stay on the fp32 MLP
+    kernels: set_matrix_precision covers the processor) against the oracle with the SAME split -- fp32 encoder, bf16-mixed
+    blocks, fp32 decoder -- and not farther from it than half the distance between that semantic and fp32."""
+    import graph_physics_amd as gp
+    from graph_physics_amd import ops
+
+    N, seed = 6000, 707
+    pos, ei, _ = R.delaunay_graph(N, seed, dim=3)
+    net = gp.get_model(ANEURYSM).to(dev)
+    params = R.variant_params(net.state_dict(), seed)
+    net.load_state_dict(params)
+    x_in = R.randn((N, 23), seed + 1)
+
+    def oracle(mixed):
+        x = O.mlp(x_in, params, "nodes_encoder.")
+        for i in range(10):
+            if mixed:
+                with O.bf16_mixed():
+                    x = O.transformer_block(x, params, f"processor_list.{i}.", ei, 4, act="gelu")
+            else:
+                x = O.transformer_block(x, params, f"processor_list.{i}.", ei, 4, act="gelu")
+        return O.mlp(x.float(), params, "decode_module.")
+
+    r32, r16 = oracle(False), oracle(True)
+    g = gp.Graph(x=x_in.to(dev), edge_index=ei.to(dev), pos=pos.to(dev))
+    with torch.no_grad():
+        o32 = net(g).cpu()
+        ops.set_matrix_precision("bf16")
+        try:
+            o16 = net(g).cpu()
+        finally:
+            ops.set_matrix_precision("fp32")
+    assert_close3(o32, r32, FWD_TOL, "fp32 mode")
+    gap = rel_err(r16, r32)
+    e16 = rel_err(o16, r16)
+    assert 1e-4 < rel_err(o16, r32) < 5e-2
+    assert e16 < 0.5 * gap + 1e-3, (e16, gap)
+    print(f"coarse-aneurysm bf16: engine vs mixed oracle {e16:.2e}, mixed oracle vs fp32 {gap:.2e}")

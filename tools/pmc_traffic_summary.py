@@ -33,7 +33,8 @@ for key in ("calibration_copy", "edge_fwd", "edge_bwd", "wgrad", "segsum"):
     rows.append((key, nf, f, nw, w, int(rb), int(wb), int(rb + wb)))
     if key != "calibration_copy":
         out[key + "_bytes"] = int(rb + wb)
-path = os.path.join(REPO, "profiles", f"{tag}_pmc_hbm_traffic.csv")
+PROF = os.environ.get("PROFILES_DIR") or os.path.join(REPO, "profiles")   # on the GPU box: a directory under gpurun_out/ (only that is merged back)
+path = os.path.join(PROF, f"{tag}_pmc_hbm_traffic.csv")
 with open(path, "w") as fh:
     fh.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) of tools/pmc_step.py (real training steps); counters in KB.\n")
     fh.write(f"# FETCH_SIZE correction x{fcorr:.3f} from the 1 GiB calibration copy (gfx950 reports half, MI355X_MICROARCH.md HBM section); WRITE_SIZE exact.\n")
@@ -45,5 +46,5 @@ from graph_physics_amd import _capi  # noqa: E402
 out["csrc_hash"] = _capi.source_hash()   # bench.py refuses this file for any other build of csrc/
 out["source"] = f"profiles/{tag}_pmc_hbm_traffic.csv (rocprofv3 PMC passes over real training steps, FETCH_SIZE x{fcorr:.2f} per the calibration copy)"
 out["workload"] = "N=30160, E=180082 (bench default), per launch, averaged over the launches of 3 training steps"
-json.dump(out, open(os.path.join(REPO, "profiles", "pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
 print(open(path).read())
