@@ -32,6 +32,7 @@ pytestmark = pytest.mark.gpu
 FWD_TOL = 1e-5
 GRAD_TOL = 1e-4
 BF16_TOL = 3e-2  # stated tolerance of the bf16 matrix mode after 15 rounds ("~1e-2 rel")
+BF16_STEP_TOL = ((2e-2, 2e-2), (2e-2, 3e-2))   # (loss, gradient norm) per training step, relative to the bf16-mixed oracle (measured: <= 5.6e-3 / 6.6e-3; round 2 allowed 10 % / 20 %)
 
 
 # ------------------------------------------------------------------ configs[2]: plate
@@ -113,11 +114,11 @@ def test_plate_world_edges_bf16_forward_vs_mixed_oracle(dev):
 def test_plate_bf16_training_step_vs_mixed_oracle(dev):
     """configs[2]: training steps of the plate workload through Simulator + Engine with
     enable_vram_optimizations (the bf16 matrix mode) against O.train_steps(mixed=True): loss and
-    gradient norm per step; on a 2-round net every parameter gradient against the ORACLE's bf16-mixed
-    gradient (Frobenius-relative), bounded by how far that oracle itself is from fp32."""
+    gradient norm per step (2 % / 2-3 %: measured 0.6 %); every parameter gradient of the 15-round and of a 2-round net
+    against the ORACLE's bf16-mixed gradient (Frobenius-relative), bounded by how far that oracle itself is from fp32."""
     x, y, pos, ei, ea, g = plate_graph_on_device(dev)
     ix = PLATE_INDEX
-    for L, check_grads in ((15, False), (2, True)):
+    for L, check_grads in ((15, True), (2, True)):
         cfg = plate_config(L)
         seed = 70 + L
         params = R.make_params(R.epd_param_shapes(L, 128, 15, 4, 3), seed)
@@ -143,9 +144,12 @@ def test_plate_bf16_training_step_vs_mixed_oracle(dev):
         (lg16, g16), (lg32, g32) = ref[True], ref[False]
         # step 0: the same weights on both sides; step 1 follows an AdamW update (|dw| = lr whatever the
         # gradient's size: bf16 rounding noise on small gradients moves the two trajectories apart)
-        for t, (ltol, gtol) in enumerate(((BF16_TOL, 0.1), (0.1, 0.2))):
-            assert abs(logs[t][0] - lg16[t][0]) < ltol * lg16[t][0], (L, t, logs, lg16)
-            assert abs(logs[t][1] - lg16[t][1]) < gtol * lg16[t][1], (L, t, logs, lg16)
+        for t, (ltol, gtol) in enumerate(BF16_STEP_TOL):
+            el, eg = abs(logs[t][0] - lg16[t][0]) / lg16[t][0], abs(logs[t][1] - lg16[t][1]) / lg16[t][1]
+            print(f"plate bf16 L={L} step {t}: loss error {el:.2e}, grad-norm error {eg:.2e} vs the mixed oracle "
+                  f"(mixed vs fp32 oracle: loss {abs(lg16[t][0] - lg32[t][0]) / lg32[t][0]:.2e}, grad norm {abs(lg16[t][1] - lg32[t][1]) / lg32[t][1]:.2e})")
+            assert el < ltol, (L, t, logs, lg16)
+            assert eg < gtol, (L, t, logs, lg16)
         if check_grads:
             for k in g16:
                 a, b, c = grads[0][k].double(), g16[k].double(), g32[k].double()
