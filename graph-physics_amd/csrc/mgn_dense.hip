@@ -295,15 +295,21 @@ __global__ void __launch_bounds__(256) k_rownorm_bwd(const float* __restrict__ d
     float dot = 0.f;
     const float c = inv[m];
     long row[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) row[p] = (P.idx[p] != nullptr) ? (long)P.idx[p][m] : m;
+    row[0] = (P.idx[0] != nullptr) ? (long)P.idx[0][m] : m;
+    row[1] = (P.idx[1] != nullptr) ? (long)P.idx[1][m] : m;
+    row[2] = (P.idx[2] != nullptr) ? (long)P.idx[2][m] : m;
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
       const int k = lane + 64 * j;
       xv[j] = 0.f, gv[j] = 0.f;
       if (k < K) {
         const int p = ph[j];
-        xv[j] = P.x[p][row[p] * P.ld[p] + (k - P.k0[p])];
+        // (constant indices + selects: a kernel-argument array indexed by a register is copied to scratch)
+        const float* xp = (p == 0) ? P.x[0] : (p == 1) ? P.x[1] : P.x[2];
+        const long rw = (p == 0) ? row[0] : (p == 1) ? row[1] : row[2];
+        const int ldp = (p == 0) ? P.ld[0] : (p == 1) ? P.ld[1] : P.ld[2];
+        const int k0p = (p == 0) ? P.k0[0] : (p == 1) ? P.k0[1] : P.k0[2];
+        xv[j] = xp[rw * ldp + (k - k0p)];
         const float d = dn[m * K + k];
         ds[j] += d * xv[j] * c;
         gv[j] = sc[j] * d;
@@ -319,7 +325,10 @@ __global__ void __launch_bounds__(256) k_rownorm_bwd(const float* __restrict__ d
       const int k = lane + 64 * j;
       if (k < K) {
         const int p = ph[j];
-        P.dx[p][m * P.lddx[p] + (k - P.k0[p])] = c * gv[j] - xv[j] * k2;   // per EDGE row: the caller sums gathered phases over their segments
+        float* dp = (p == 0) ? P.dx[0] : (p == 1) ? P.dx[1] : P.dx[2];
+        const int ldd = (p == 0) ? P.lddx[0] : (p == 1) ? P.lddx[1] : P.lddx[2];
+        const int k0p = (p == 0) ? P.k0[0] : (p == 1) ? P.k0[1] : P.k0[2];
+        dp[m * ldd + (k - k0p)] = c * gv[j] - xv[j] * k2;   // per EDGE row: the caller sums gathered phases over their segments
       }
     }
   }
@@ -329,16 +338,32 @@ __global__ void __launch_bounds__(256) k_rownorm_bwd(const float* __restrict__ d
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += 256) part[(size_t)blockIdx.x * K + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
 }
-__global__ void __launch_bounds__(256) k_colsum_parts(const float* __restrict__ part, int nparts, int K, float* __restrict__ out) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= K) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * K + k];   // fixed order: deterministic
-  out[k] = s;
+// column sums of the workgroups' partials: 64 columns per block, 4 slices of the partial list per column, combined in a fixed
+// order (deterministic)
+__global__ void __launch_bounds__(256) k_colsum_parts(const float* __restrict__ part, int nparts, int chunk, int K, float* __restrict__ out) {
+  // block (x, y): columns 64 x .. 64 x + 63 of the partials [y chunk, (y + 1) chunk) -> out[y][k]; a long partial list is summed in
+  // two launches (chunks, then the chunk sums) so that no thread walks more than a few dozen dependent loads
+  __shared__ float red[4][64];
+  const int k = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  const int lo = blockIdx.y * chunk;
+  const int hi = (lo + chunk < nparts) ? lo + chunk : nparts;
+  float s0 = 0.f, s1 = 0.f;
+  if (k < K) {
+    int p = lo + sl;
+    for (; p + 4 < hi; p += 8) {
+      s0 += part[(size_t)p * K + k];
+      s1 += part[(size_t)(p + 4) * K + k];
+    }
+    if (p < hi) s0 += part[(size_t)p * K + k];
+  }
+  red[sl][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && k < K) out[(size_t)blockIdx.y * K + k] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-#define RN_GRID 512
-extern "C" size_t mgn_rownorm_bwd_workspace_bytes(int K) { return (size_t)RN_GRID * (K > 0 ? K : 0) * sizeof(float); }
+#define RN_GRID 2048
+#define RN_CHUNK 64
+extern "C" size_t mgn_rownorm_bwd_workspace_bytes(int K) { return (size_t)(RN_GRID + RN_GRID / RN_CHUNK + 1) * (K > 0 ? K : 0) * sizeof(float); }
 extern "C" int mgn_rownorm_bwd(const float* dn, const mgn_rownorm_phase* phases, int nphase, const float* inv, const float* scale, float eps,
                                int64_t M, float* dscale, void* ws, size_t ws_bytes, void* stream) {
   if (M < 0 || dn == nullptr || phases == nullptr || nphase < 1 || nphase > 3 || inv == nullptr || scale == nullptr || dscale == nullptr)
@@ -362,7 +387,7 @@ extern "C" int mgn_rownorm_bwd(const float* dn, const mgn_rownorm_phase* phases,
   if (K > 384) return dfail(1, "mgn_rownorm_bwd: at most 384 columns");
   if (ws == nullptr || ws_bytes < mgn_rownorm_bwd_workspace_bytes(K)) return dfail(1, "mgn_rownorm_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  unsigned grid = (unsigned)((M + 3) / 4);
+  unsigned grid = (unsigned)((M + 15) / 16);   // >= 4 rows per wave: enough loads in flight per wave, enough waves per CU
   if (grid > RN_GRID) grid = RN_GRID;
   if (grid == 0) grid = 1;
   float* part = (float*)ws;
@@ -372,6 +397,14 @@ extern "C" int mgn_rownorm_bwd(const float* dn, const mgn_rownorm_phase* phases,
 #undef RN_CASE
     default: return dfail(1, "mgn_rownorm_bwd: width out of range");
   }
-  hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, (const float*)part, (int)grid, K, dscale);
+  const unsigned kb_ = (unsigned)((K + 63) / 64);
+  if (grid > RN_CHUNK) {
+    const unsigned nch = (grid + RN_CHUNK - 1) / RN_CHUNK;
+    float* part2 = part + (size_t)RN_GRID * K;
+    hipLaunchKernelGGL(k_colsum_parts, dim3(kb_, nch), dim3(256), 0, s, (const float*)part, (int)grid, RN_CHUNK, K, part2);
+    hipLaunchKernelGGL(k_colsum_parts, dim3(kb_, 1), dim3(256), 0, s, (const float*)part2, (int)nch, (int)nch, K, dscale);
+  } else {
+    hipLaunchKernelGGL(k_colsum_parts, dim3(kb_, 1), dim3(256), 0, s, (const float*)part, (int)grid, (int)grid, K, dscale);
+  }
   return dcheck("mgn_rownorm_bwd");
 }

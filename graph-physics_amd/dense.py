@@ -171,8 +171,11 @@ class DenseFn(torch.autograd.Function):
             dW = torch.empty(N, K, **f) if M > 0 else torch.zeros(N, K, **f)
             db = (torch.empty(N, **f) if M > 0 else torch.zeros(N, **f)) if want_b else None
             jobs = []
-            for j0 in range(0, N, 128):
-                nj = min(128, N - j0)
+            # the generic weight-gradient kernel is instantiated for the widest block count of a launch: with 64-wide inputs
+            # 64-row slabs keep it on the 4-block instance (measured 94 us against 183 us for dW[192, 64] at 150 000 rows)
+            nslab = 64 if all(kw_ <= 64 for _, _, kw_ in srcs) else 128
+            for j0 in range(0, N, nslab):
+                nj = min(nslab, N - j0)
                 A = dZ[:, j0:j0 + nj]
                 first = True
                 for src, koff, kw_all in srcs:
