@@ -83,8 +83,12 @@ __device__ __forceinline__ float rowsum4d(float v) {
 }
 
 // ------------------------------------------------------------------ fused linear layer
-// KB = input blocks of 16 features (both phases together); 64 rows per workgroup, 16 per wave.
-template <int KB>
+// KB = input blocks of 16 features (all phases together); 64 rows per workgroup, 16 per wave.  BF (bf16 operand / result
+// rounding) and GATE (second product) are template parameters: as run-time tests they put a branch behind every weight fragment
+// load and the compiler answered with one `s_waitcnt vmcnt(0)` per fragment -- 16 serialised L2 round trips per row tile (seen
+// in the ISA; 64 -> 64 at 150 000 rows: 35 us).  Straight-line now: all fragments of an output block are requested together,
+// and (up to 8 input blocks) those of the NEXT output block before this block's MFMAs.
+template <int KB, bool BF, bool GATE>
 __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -119,49 +123,98 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
       for (int kb = 0; kb < KB; ++kb) *(f32x4*)(a.n_out + mm * K + 16 * kb + 4 * g) = in[kb];
     }
   }
-  const bool bf = a.precision == 1;
-  if (bf) {
+  if (BF) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) in[kb] = bf16r4(in[kb]);
   }
   const int NB = a.N >> 4;
-  const bool gate = a.W2 != nullptr;
+  constexpr bool PF = KB <= 8;   // prefetch the next output block's fragments (registers allow it)
+  const float* w1 = a.W + (size_t)c * a.ldw + 4 * g;
+  const float* w2 = GATE ? a.W2 + (size_t)c * a.ldw + 4 * g : nullptr;
+  f32x4 wa[KB], wb[GATE ? KB : 1];
+  if (PF) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      wa[kb] = *(const f32x4*)(w1 + 16 * kb);
+      if (GATE) wb[kb] = *(const f32x4*)(w2 + 16 * kb);
+    }
+  }
   for (int ob = 0; ob < NB; ++ob) {
     const int n0 = 16 * ob + 4 * g;
     f32x4 acc = (a.b != nullptr) ? *(const f32x4*)(a.b + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 acc2 = (gate && a.b2 != nullptr) ? *(const f32x4*)(a.b2 + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
-    if (bf) acc = bf16r4(acc), acc2 = bf16r4(acc2);
-    const float* w1 = a.W + (size_t)(16 * ob + c) * a.ldw + 4 * g;
-    const float* w2 = gate ? a.W2 + (size_t)(16 * ob + c) * a.ldw + 4 * g : nullptr;
+    f32x4 acc2 = (GATE && a.b2 != nullptr) ? *(const f32x4*)(a.b2 + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (BF) acc = bf16r4(acc), acc2 = bf16r4(acc2);
+    f32x4 ca[KB], cb[GATE ? KB : 1];
+    if (PF) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      f32x4 wa = *(const f32x4*)(w1 + 16 * kb);
-      if (bf) wa = bf16r4(wa);
+      for (int kb = 0; kb < KB; ++kb) {
+        ca[kb] = wa[kb];
+        if (GATE) cb[kb] = wb[kb];
+      }
+      const size_t nxt = (size_t)16 * ((ob + 1 < NB) ? ob + 1 : ob) * a.ldw;   // (the last block re-requests its own: an unconditional load)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc = MFMA16(wa[r], in[kb][r], acc);
-      if (gate) {
-        f32x4 wb = *(const f32x4*)(w2 + 16 * kb);
-        if (bf) wb = bf16r4(wb);
+      for (int kb = 0; kb < KB; ++kb) {
+#ifndef LIN_EXP_NOW
+        wa[kb] = *(const f32x4*)(w1 + nxt + 16 * kb);
+        if (GATE) wb[kb] = *(const f32x4*)(w2 + nxt + 16 * kb);
+#endif
+      }
+    } else {
+      const size_t cur = (size_t)16 * ob * a.ldw;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc2 = MFMA16(wb[r], in[kb][r], acc2);
+      for (int kb = 0; kb < KB; ++kb) {
+        ca[kb] = *(const f32x4*)(w1 + cur + 16 * kb);
+        if (GATE) cb[kb] = *(const f32x4*)(w2 + cur + 16 * kb);
       }
     }
-    if (bf) acc = bf16r4(acc), acc2 = bf16r4(acc2);   // a bf16 nn.Linear returns bf16
+    if (BF) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        ca[kb] = bf16r4(ca[kb]);
+        if (GATE) cb[kb] = bf16r4(cb[kb]);
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#ifdef LIN_EXP_NOMFMA   // timing experiment only
+        acc[r] += ca[kb][r] * in[kb][r];
+#else
+        acc = MFMA16(ca[kb][r], in[kb][r], acc);
+#endif
+        if (GATE) acc2 = MFMA16(cb[kb][r], in[kb][r], acc2);
+      }
+    }
+    if (BF) acc = bf16r4(acc), acc2 = bf16r4(acc2);   // a bf16 nn.Linear returns bf16
     if (valid) {
       if (a.saveZ1 != nullptr) *(f32x4*)(a.saveZ1 + mm * a.N + n0) = acc;
-      if (gate && a.saveZ2 != nullptr) *(f32x4*)(a.saveZ2 + mm * a.N + n0) = acc2;
+      if (GATE && a.saveZ2 != nullptr) *(f32x4*)(a.saveZ2 + mm * a.N + n0) = acc2;
     }
     f32x4 y;
 #pragma unroll
     for (int r = 0; r < 4; ++r) y[r] = d_act(acc[r], a.act);
-    if (bf && a.act >= 0) y = bf16r4(y);
-    if (gate) {
+    if (BF && a.act >= 0) y = bf16r4(y);
+    if (GATE) {
       y = y * acc2;
-      if (bf) y = bf16r4(y);
+      if (BF) y = bf16r4(y);
     }
     if (a.resid != nullptr) y = *(const f32x4*)(a.resid + mm * a.ldr + n0) + y;   // the residual stream stays fp32
+#ifdef LIN_EXP_NOSTORE
+    if (valid && y[0] == 12345.678f) *(f32x4*)(a.out + mm * a.ldo + n0) = y;
+#else
     if (valid) *(f32x4*)(a.out + mm * a.ldo + n0) = y;
+#endif
   }
+}
+
+template <int KB>
+static void launch_linear(const mgn_linear_args& a, unsigned grid, hipStream_t s) {
+  const bool bf = a.precision == 1, gate = a.W2 != nullptr;
+  if (bf && gate) hipLaunchKernelGGL((k_linear<KB, true, true>), dim3(grid), dim3(256), 0, s, a);
+  else if (bf) hipLaunchKernelGGL((k_linear<KB, true, false>), dim3(grid), dim3(256), 0, s, a);
+  else if (gate) hipLaunchKernelGGL((k_linear<KB, false, true>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_linear<KB, false, false>), dim3(grid), dim3(256), 0, s, a);
 }
 
 extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
@@ -182,7 +235,7 @@ extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)((a.M + 63) / 64);
   switch (K >> 4) {
-#define LIN_CASE(KB_) case KB_: hipLaunchKernelGGL(k_linear<KB_>, dim3(grid), dim3(256), 0, s, a); break;
+#define LIN_CASE(KB_) case KB_: launch_linear<KB_>(a, grid, s); break;
     LIN_CASE(1) LIN_CASE(2) LIN_CASE(3) LIN_CASE(4) LIN_CASE(6) LIN_CASE(8) LIN_CASE(12) LIN_CASE(16) LIN_CASE(24)
 #undef LIN_CASE
     default: return dfail(1, "mgn_linear_fwd: total input width must be 16, 32, 48, 64, 96, 128, 192, 256 or 384");
