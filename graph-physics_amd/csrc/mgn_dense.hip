@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "mgn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -88,11 +89,28 @@ __device__ __forceinline__ float rowsum4d(float v) {
 // load and the compiler answered with one `s_waitcnt vmcnt(0)` per fragment -- 16 serialised L2 round trips per row tile (seen
 // in the ISA; 64 -> 64 at 150 000 rows: 35 us).  Straight-line now: all fragments of an output block are requested together,
 // and (up to 8 input blocks) those of the NEXT output block before this block's MFMAs.
-template <int KB, bool BF, bool GATE>
+// LDSW: the weight matrix (both of a gated product) is staged ONCE per workgroup into LDS (rows padded by 16 bytes: the 16 rows a
+// fragment read touches then start 17 chunks apart, 4-5 LDS cycles per ds_read_b128) and persistent workgroups walk the row
+// tiles -- without it every wave re-reads the matrix from L1 / L2 next to its row traffic (64 -> 64 at 600 000 rows: 124 us, of
+// which 40 us are those loads; timing-only builds).  Used when the image fits 64 KB (3+ workgroups per CU).
+template <int KB, bool BF, bool GATE, bool LDSW>
 __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const long m = ((long)blockIdx.x * 4 + wv) * 16 + c;
+  constexpr int SP = 16 * KB + 4;   // padded row stride of the LDS image (floats)
+  extern __shared__ __attribute__((aligned(16))) float lw_[];
+  if (LDSW) {
+    const int nvec = a.N * (KB * 4);   // f32x4 elements of one matrix
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+      const int n = i / (KB * 4), j = i % (KB * 4);
+      *(f32x4*)(lw_ + n * SP + 4 * j) = *(const f32x4*)(a.W + (size_t)n * a.ldw + 4 * j);
+      if (GATE) *(f32x4*)(lw_ + (a.N + n) * SP + 4 * j) = *(const f32x4*)(a.W2 + (size_t)n * a.ldw + 4 * j);
+    }
+    __syncthreads();
+  }
+  const long ntiles = (a.M + 63) / 64;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const long m = (tile * 4 + wv) * 16 + c;
   const bool valid = m < a.M;
   const long mm = valid ? m : a.M - 1;
   const int K = 16 * KB, kb1 = a.K1 >> 4, kb2 = kb1 + (a.K2 >> 4);
@@ -128,9 +146,11 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
     for (int kb = 0; kb < KB; ++kb) in[kb] = bf16r4(in[kb]);
   }
   const int NB = a.N >> 4;
-  constexpr bool PF = KB <= 8;   // prefetch the next output block's fragments (registers allow it)
+  constexpr bool PF = KB <= 8 && !LDSW;   // prefetch the next output block's fragments from L2 (registers allow it)
   const float* w1 = a.W + (size_t)c * a.ldw + 4 * g;
   const float* w2 = GATE ? a.W2 + (size_t)c * a.ldw + 4 * g : nullptr;
+  const float* l1 = lw_ + c * SP + 4 * g;
+  const float* l2 = lw_ + (a.N + c) * SP + 4 * g;
   f32x4 wa[KB], wb[GATE ? KB : 1];
   if (PF) {
 #pragma unroll
@@ -158,6 +178,12 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
         wa[kb] = *(const f32x4*)(w1 + nxt + 16 * kb);
         if (GATE) wb[kb] = *(const f32x4*)(w2 + nxt + 16 * kb);
 #endif
+      }
+    } else if (LDSW) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        ca[kb] = *(const f32x4*)(l1 + 16 * ob * SP + 16 * kb);
+        if (GATE) cb[kb] = *(const f32x4*)(l2 + 16 * ob * SP + 16 * kb);
       }
     } else {
       const size_t cur = (size_t)16 * ob * a.ldw;
@@ -206,15 +232,40 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
     if (valid) *(f32x4*)(a.out + mm * a.ldo + n0) = y;
 #endif
   }
+  }  // tiles
 }
 
-template <int KB>
-static void launch_linear(const mgn_linear_args& a, unsigned grid, hipStream_t s) {
+template <int KB, bool LDSW>
+static int launch_linear_v(const mgn_linear_args& a, unsigned grid, size_t lds, hipStream_t s) {
   const bool bf = a.precision == 1, gate = a.W2 != nullptr;
-  if (bf && gate) hipLaunchKernelGGL((k_linear<KB, true, true>), dim3(grid), dim3(256), 0, s, a);
-  else if (bf) hipLaunchKernelGGL((k_linear<KB, true, false>), dim3(grid), dim3(256), 0, s, a);
-  else if (gate) hipLaunchKernelGGL((k_linear<KB, false, true>), dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_linear<KB, false, false>), dim3(grid), dim3(256), 0, s, a);
+#define LIN_GO(BF_, GATE_)                                                                                                            \
+  do {                                                                                                                                \
+    if (LDSW && lds > 48 * 1024) {                                                                                                    \
+      if (hipFuncSetAttribute((const void*)k_linear<KB, BF_, GATE_, LDSW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return 2;                                                                                                                     \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((k_linear<KB, BF_, GATE_, LDSW>), dim3(grid), dim3(256), lds, s, a);                                           \
+  } while (0)
+  if (bf && gate) LIN_GO(true, true);
+  else if (bf) LIN_GO(true, false);
+  else if (gate) LIN_GO(false, true);
+  else LIN_GO(false, false);
+#undef LIN_GO
+  return 0;
+}
+template <int KB>
+static int launch_linear(const mgn_linear_args& a, hipStream_t s) {
+  const long ntiles = (a.M + 63) / 64;
+  const size_t img = (size_t)(a.W2 != nullptr ? 2 : 1) * a.N * (16 * KB + 4) * sizeof(float);
+  // the LDS-resident weight image pays once every workgroup walks several tiles and three or more workgroups fit a CU
+  if (img <= 64 * 1024 && ntiles >= 1024 && getenv("MGN_LINEAR_NO_LDS") == nullptr) {
+    int per_cu = (int)((160 * 1024) / img);
+    if (per_cu > 8) per_cu = 8;
+    unsigned grid = 256u * (unsigned)per_cu;
+    if ((long)grid > ntiles) grid = (unsigned)ntiles;
+    return launch_linear_v<KB, true>(a, grid, img, s);
+  }
+  return launch_linear_v<KB, false>(a, (unsigned)ntiles, 0, s);
 }
 
 extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
@@ -233,9 +284,8 @@ extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
   if (a.precision != 0 && a.precision != 1) return dfail(1, "mgn_linear_fwd: precision must be 0 or 1");
   if (a.M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const unsigned grid = (unsigned)((a.M + 63) / 64);
   switch (K >> 4) {
-#define LIN_CASE(KB_) case KB_: launch_linear<KB_>(a, grid, s); break;
+#define LIN_CASE(KB_) case KB_: if (launch_linear<KB_>(a, s)) return dfail(2, "mgn_linear_fwd: cannot reserve LDS"); break;
     LIN_CASE(1) LIN_CASE(2) LIN_CASE(3) LIN_CASE(4) LIN_CASE(6) LIN_CASE(8) LIN_CASE(12) LIN_CASE(16) LIN_CASE(24)
 #undef LIN_CASE
     default: return dfail(1, "mgn_linear_fwd: total input width must be 16, 32, 48, 64, 96, 128, 192, 256 or 384");
