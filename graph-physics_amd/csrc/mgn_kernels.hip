@@ -2416,13 +2416,21 @@ int mgn_colred_batch(int n, const mgn_colred_job* jobs, void* stream) {
 }
 
 static int wgrad_plan(int njobs, const mgn_wgrad_job* jobs, int* wg0, bool lds) {
-  // A fixed budget of workgroups -- exactly what is co-resident (512 = 2 per CU for the LDS
-  // kernel, 1024 for the generic one) -- shared out in proportion to the rows of each job.
+  // A fixed budget of workgroups -- at most what is co-resident (512 = 2 per CU for the LDS
+  // kernel; the generic one could hold 1024) -- shared out in proportion to the rows of each job.
   // The total must NEVER exceed the budget: four workgroups too many start a second
   // scheduling round and the kernel takes 1.4x as long (measured).  Floor shares first, the
   // remainder goes to the jobs with the most tiles per workgroup.
   const int rows = lds ? WG_TILE_ROWS : 16;
-  const int budget = lds ? 512 : 1024;
+  // (generic kernel: 1024 workgroups are co-resident, but half as many leave half the partials to k_wgrad_red -- neutral on the
+  //  headline, -3.5 % on the Transformer step whose weight gradients are all small matrices; MGN_WGRAD_GENERIC_BUDGET overrides)
+  int budget = 512;
+  if (!lds) {
+    if (const char* e = getenv("MGN_WGRAD_GENERIC_BUDGET")) {
+      const int b = atoi(e);
+      if (b >= 64 && b <= 1024) budget = b;
+    }
+  }
   int64_t tiles[MGN_MAX_WGRAD_JOBS], tot = 0;
   int n[MGN_MAX_WGRAD_JOBS];
   for (int j = 0; j < njobs; ++j) {

@@ -173,14 +173,14 @@ class DenseFn(torch.autograd.Function):
             jobs = []
             # the generic weight-gradient kernel is instantiated for the widest block count of a launch: with 64-wide inputs
             # 64-row slabs keep it on the 4-block instance (measured 94 us against 183 us for dW[192, 64] at 150 000 rows)
-            nslab = 64 if all(kw_ <= 64 for _, _, kw_ in srcs) else 128
+            nslab = 64 if (N <= 64 or all(kw_ <= 64 for _, _, kw_ in srcs)) else 128   # (a 64-wide side: 64 x 64 blocks on both)
             for j0 in range(0, N, nslab):
                 nj = min(nslab, N - j0)
                 A = dZ[:, j0:j0 + nj]
                 first = True
                 for src, koff, kw_all in srcs:
-                    for k0_ in range(0, kw_all, 128):
-                        nk = min(128, kw_all - k0_)
+                    for k0_ in range(0, kw_all, nslab):
+                        nk = min(nslab, kw_all - k0_)
                         B = src[:, k0_:k0_ + nk]
                         job = (A, int(dZ.stride(0)), nj // 16, B, int(src.stride(0)), nk // 16, nk, dW, j0 * K + koff + k0_, K)
                         if first and db is not None:
