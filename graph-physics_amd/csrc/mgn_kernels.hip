@@ -1909,8 +1909,12 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
   if (p.lds && fwd_x6(a)) {
     // 8-wave workgroups (one per CU) when every CU still gets a tile; MGN_NW=4/8 overrides
     int nw = (a.M >= 128 * 256) ? X6_FWD_NW_LARGE : 4;
-    if (const char* e = getenv("MGN_NW")) nw = (atoi(e) == 8) ? 8 : 4;
-    if (a.seg_out != nullptr) nw = 4;  // the partials are indexed by 4-wave tiles
+    bool nw6 = false;  // MGN_NW=6: the three-waves-per-SIMD instance of the edge update (experiment)
+    if (const char* e = getenv("MGN_NW")) {
+      nw = (atoi(e) == 8) ? 8 : 4;
+      nw6 = atoi(e) == 6;
+    }
+    if (a.seg_out != nullptr) nw = 4;  // (the 8-wave instance has no fused segment sum)
     const bool silu = (a.act == MGN_ACT_SILU);
     if (silu) nw = 4;  // the SiLU variant is built for 4-wave workgroups only
     static thread_local bool attr_done = false;
@@ -1918,7 +1922,7 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
       if (set_fwd_x6_attr<6, 4, 0>() || set_fwd_x6_attr<1, 4, 0>() || set_fwd_x6_attr<6, 8, 0>() || set_fwd_x6_attr<1, 8, 0>() ||
           set_fwd_x6_attr<6, 4, 1>() || set_fwd_x6_attr<1, 4, 1>() || set_fwd_x6_attr<6, 4, 0, ShEdge>() ||
           set_fwd_x6_attr<6, 4, 0, ShNode<2>>() || set_fwd_x6_attr<6, 4, 0, ShNode<0>>() || set_fwd_x6_attr<1, 4, 0, ShEdge>() ||
-          set_fwd_x6_attr<1, 4, 0, ShNode<2>>() || set_fwd_x6_attr<1, 4, 0, ShNode<0>>())
+          set_fwd_x6_attr<1, 4, 0, ShNode<2>>() || set_fwd_x6_attr<1, 4, 0, ShNode<0>>() || set_fwd_x6_attr<6, 6, 0, ShEdge>())
         return 1;
       attr_done = true;
     }
@@ -1930,7 +1934,11 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
       if (atoi(e) > 0 && (unsigned)atoi(e) < grid) grid = (unsigned)atoi(e);
     }
     const int shape = (nw == 4 && !silu) ? fwd_static_shape(a) : 0;
-    if (shape == 1) {
+    if (shape == 1 && nw6 && a.precision == 0) {
+      unsigned g6 = (unsigned)((a.M + 95) / 96);
+      if (g6 > 512u) g6 = 512u;
+      hipLaunchKernelGGL((k_mlp_fwd_x6<6, 6, 0, ShEdge>), dim3(g6), dim3(384), X6_FWD_LDS_BYTES(6), s, a);
+    } else if (shape == 1) {
       if (a.precision == 1)
         hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 0, ShEdge>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
       else
