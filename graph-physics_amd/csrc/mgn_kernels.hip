@@ -1418,6 +1418,111 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WgradLaunch L) {
   }
 }
 
+// Row-vector variant for jobs up to 64 x 64 (the 64 x 64 block jobs dense.py cuts the Transformer's / gated MLP's weight gradients
+// into): a lane fetches FOUR consecutive features of a row in one 16-byte load -- 16 lanes cover the 256 bytes of a 64-wide row, a
+// wave instruction four whole rows -- where the generic kernel above spends sixteen 4-byte loads per tile on A alone and fetches A
+// once per wave.  The feature a lane holds in component q is 4c + q, so MFMA block q multiplies the STRIDED feature set
+// {q, 4 + q, ..}: a permutation of the rows / columns of dW that the store undoes.  Every wave owns whole tiles (16 rows, no operand
+// is loaded twice) and a full 64 x 64 accumulator; the four waves are summed through LDS, the workgroup writes one partial in the
+// layout k_wgrad_red reads.  Needs lda % 4 == ldb % 4 == kw % 4 == 0 and 16-byte aligned operands (wgrad_job_row64).
+__global__ void __launch_bounds__(256, 2) k_wgrad_row64(const WgradLaunch L) {
+  constexpr int H = 64;
+  __shared__ float red[3][H * H + H];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  int j = 0;
+  while (j + 1 < L.njobs && (int)blockIdx.x >= L.wg0[j + 1]) ++j;
+  const mgn_wgrad_job J = L.job[j];
+  const int nwg = L.wg0[j + 1] - L.wg0[j];
+  const int wg = blockIdx.x - L.wg0[j];
+  const long ntiles = (J.M + 15) >> 4;
+  const long t0 = ntiles * wg / nwg, t1 = ntiles * (wg + 1) / nwg;
+  const bool a_on = 4 * c < 16 * J.nja, b_on = 4 * c < J.kw;
+
+  f32x4 acc[4][4];  // [qa][qb]
+#pragma unroll
+  for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) acc[qa][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};  // column sums of A over this lane's rows (bias gradient)
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 av[2][4], bv[2][4];
+  auto load_tile = [&](long tile, f32x4 (&a)[4], f32x4 (&b)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = tile * 16 + 4 * g + r;
+      const bool ok = row < J.M;
+      a[r] = (ok && a_on) ? ld4(J.A + row * J.lda + 4 * c) : zero;
+      b[r] = (ok && b_on) ? ld4(J.B + row * J.ldb + 4 * c) : zero;
+    }
+  };
+  auto mac_tile = [&](const f32x4 (&a)[4], const f32x4 (&b)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) acc[qa][qb] = MFMA16(a[r][qa], b[r][qb], acc[qa][qb]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs += a[r];
+  };
+  long tile = t0 + wv;
+  if (tile < t1) {
+    load_tile(tile, av[0], bv[0]);
+    for (; tile + 8 < t1; tile += 8) {  // two tiles per trip keeps buffer indices static
+      load_tile(tile + 4, av[1], bv[1]);
+      mac_tile(av[0], bv[0]);
+      load_tile(tile + 8, av[0], bv[0]);
+      mac_tile(av[1], bv[1]);
+    }
+    if (tile + 4 < t1) {
+      load_tile(tile + 4, av[1], bv[1]);
+      mac_tile(av[0], bv[0]);
+      mac_tile(av[1], bv[1]);
+    } else {
+      mac_tile(av[0], bv[0]);
+    }
+  }
+  // lane (c,g), block (qa,qb), reg v  ->  dW[16g + 4v + qa][4c + qb]; components qb are consecutive columns: one 16-byte value
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cs[q] = rowsum4(cs[q]);  // all g hold the sum over the wave's rows of features 4c..4c+3
+  auto put = [&](float* dst) {
+#pragma unroll
+    for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 o = {acc[qa][0][v], acc[qa][1][v], acc[qa][2][v], acc[qa][3][v]};
+        *(f32x4*)(dst + (16 * g + 4 * v + qa) * H + 4 * c) = o;
+      }
+    if (g == 0) *(f32x4*)(dst + H * H + 4 * c) = cs;
+  };
+  if (wv > 0) put(red[wv - 1]);
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+      for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const f32x4 o = *(const f32x4*)(red[w] + (16 * g + 4 * v + qa) * H + 4 * c);
+#pragma unroll
+          for (int qb = 0; qb < 4; ++qb) acc[qa][qb][v] += o[qb];
+        }
+      cs += *(const f32x4*)(red[w] + H * H + 4 * c);
+    }
+    float* P = L.partial + (size_t)blockIdx.x * (H * H + H);
+#pragma unroll
+    for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 o = {acc[qa][0][v], acc[qa][1][v], acc[qa][2][v], acc[qa][3][v]};
+        st4(P + (16 * g + 4 * v + qa) * H + 4 * c, o);
+      }
+    if (g == 0 && J.db != nullptr) st4(P + H * H + 4 * c, cs);
+  }
+}
+
 // LDS-staged variant for full 128 x 128 jobs (lda = ldb = 128): the workgroup streams
 // 32-row tiles of A (= dZ) and B (= X) through LDS by DMA, double buffered; every element is
 // fetched from L2/HBM once per workgroup instead of once per wave.  Tile image: row r at
@@ -2423,6 +2528,10 @@ int mgn_colred_batch(int n, const mgn_colred_job* jobs, void* stream) {
   return check_launch("mgn_colred_batch");
 }
 
+static bool wgrad_job_row64(const mgn_wgrad_job& j) {
+  return j.nja <= 4 && j.nkb <= 4 && j.kw <= 64 && (j.kw & 3) == 0 && (j.lda & 3) == 0 && (j.ldb & 3) == 0 &&
+         (((uintptr_t)j.A | (uintptr_t)j.B) & 15) == 0;
+}
 static int wgrad_plan(int njobs, const mgn_wgrad_job* jobs, int* wg0, bool lds) {
   // A fixed budget of workgroups -- at most what is co-resident (512 = 2 per CU for the LDS
   // kernel; the generic one could hold 1024) -- shared out in proportion to the rows of each job.
@@ -2510,7 +2619,11 @@ int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes,
       if (jobs[j].nkb > maxb) maxb = jobs[j].nkb;
     }
     if (L.njobs == 0) continue;
-    const int HB = maxb <= 1 ? 1 : maxb <= 2 ? 2 : maxb <= 4 ? 4 : 8;
+    int HB = maxb <= 1 ? 1 : maxb <= 2 ? 2 : maxb <= 4 ? 4 : 8;
+    // jobs up to 64 x 64 with 16-byte addressable rows: the row-vector kernel (MGN_WGRAD_NO_ROW64: the generic one, for A/B)
+    bool row64 = pass == 1 && HB <= 4 && getenv("MGN_WGRAD_NO_ROW64") == nullptr;
+    for (int j = 0; row64 && j < L.njobs; ++j) row64 = wgrad_job_row64(L.job[j]);
+    if (row64) HB = 4;
     L.H = 16 * HB;
     const int total = wgrad_plan(L.njobs, L.job, L.wg0, pass == 0);
     const size_t need = (size_t)total * (L.H * L.H + L.H) * sizeof(float);
@@ -2540,6 +2653,8 @@ int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes,
       } else {
         hipLaunchKernelGGL(k_wgrad_lds, dim3(total), dim3(256), smem, s, L);
       }
+    } else if (row64) {
+      hipLaunchKernelGGL(k_wgrad_row64, dim3(total), dim3(256), 0, s, L);
     } else {
       switch (HB) {
         case 8: hipLaunchKernelGGL(k_wgrad<8>, dim3(total), dim3(256), 0, s, L); break;

@@ -349,3 +349,35 @@ def test_fused_edge_backward_inside_the_training_step(dev):
             os.environ.pop("MGN_FUSED_BWD", None)
     for k in grads["0"]:
         assert rel_err(grads["1"][k], grads["0"][k]) < 5e-6, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,nf,kw,lda,ldb", [(1, 64, 64, 64, 64), (17, 48, 20, 192, 64), (1000, 64, 64, 192, 128), (33333, 16, 4, 16, 4),
+                                             (70001, 64, 60, 64, 64), (5, 32, 64, 68, 72)])
+def test_row_vector_weight_gradient_kernel(dev, monkeypatch, M, nf, kw, lda, ldb):
+    """k_wgrad_row64 (jobs up to 64 x 64 with 16-byte addressable rows: strided slabs of wider matrices, widths that are multiples
+    of 4 but not of 16, ragged row counts, the bias by-product) against fp64 torch -- and bit-for-bit the same call run to run; the
+    generic kernel (MGN_WGRAD_NO_ROW64) on the same jobs as a cross-check"""
+    g = torch.Generator().manual_seed(M + nf + kw)
+    A_full = torch.randn(M, lda, generator=g).to(dev)
+    B_full = torch.randn(M, ldb, generator=g).to(dev)
+    A, B = A_full[:, lda - nf:], B_full[:, :kw]          # a slab at a column offset (16-byte aligned: lda - nf is a multiple of 4)
+    nja, nkb = (nf + 15) // 16, (kw + 15) // 16
+    ref = (A.double().t() @ B.double())
+    ref_b = A.double().sum(0)
+
+    def run():
+        dW = torch.full((16 * nja, 16 * nkb), float("nan"), device=dev)
+        db = torch.full((16 * nja,), float("nan"), device=dev)
+        ops.wgrad([(A, lda, nja, B, ldb, nkb, kw, dW, 0, 16 * nkb, db)], dev)
+        return dW, db
+    dW, db = run()
+    dW2, db2 = run()
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    scale = float(ref.abs().max()) + 1e-30
+    assert float((dW[:nf, :kw].double() - ref).abs().max()) / scale < 2e-6
+    assert float((db[:nf].double() - ref_b).abs().max()) / (float(ref_b.abs().max()) + 1e-30) < 2e-6
+    assert float(dW[:nf, kw:].abs().max()) == 0.0 if kw < 16 * nkb else True   # columns past kw are zeros, not garbage
+    monkeypatch.setenv("MGN_WGRAD_NO_ROW64", "1")
+    dW3, db3 = run()
+    assert float((dW3[:nf, :kw] - dW[:nf, :kw]).abs().max()) / scale < 2e-6
