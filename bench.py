@@ -675,6 +675,7 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
         optim.step()
 
     torch.cuda.reset_peak_memory_stats(dev)
+    n_rec = ops.recompute_rounds(E, n, H, 4, args.rounds, 0, dev)   # what "auto" decides with the memory free right now
     t_tr = timed(whole_train_step, max(2, args.c4_steps - 1))
     rec["train_ms_per_step"] = round(1e3 * t_tr, 2)
     rec["node_train_steps_per_s"] = round(n / t_tr, 1)
@@ -684,8 +685,8 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
         rec["train_ms_per_step_raw_numbering"] = round(1e3 * timed(whole_train_step, 2), 2)
     finally:
         ops.set_node_renumbering("auto")
-    rec["train_activation_recompute"] = ops.get_activation_recompute() + (
-        " (on: saved activations would be %.0f GB)" % (ops.saved_activation_bytes(E, n, H, 4, args.rounds, 0) / 1e9))
+    rec["train_activation_recompute"] = "%s: %d of %d rounds recomputed in the backward pass, the others saved (all saves would be %.0f GB)" % (
+        ops.get_activation_recompute(), n_rec, args.rounds, ops.saved_activation_bytes(E, n, H, 4, args.rounds, 0) / 1e9)
     # What the same step costs WITHOUT the recompute (the N > 1 runs keep their saves): measured on a 5-round
     # model, whose saves fit, with recompute off and on; the ratio carries over (every round costs the same).
     # A 1 -> 8 speed-up read against train_ms_per_step contains the recompute switching off; read against
@@ -700,9 +701,11 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
             ops.set_activation_recompute(mode)
             t5[mode] = timed(lambda: whole_train_step(net5, opt5), 2)
         ops.set_activation_recompute(old_mode)
-        rec["scaling_baseline_ms"] = round(1e3 * t_tr * t5["off"] / t5["on"], 2)
-        rec["scaling_baseline_note"] = (f"train_ms_per_step x (no-recompute / recompute) measured on a {l5}-round model of the same mesh "
-                                        f"({1e3 * t5['off']:.1f} / {1e3 * t5['on']:.1f} ms): the single-GPU step as if its saves fitted")
+        extra = (t5["on"] / t5["off"] - 1.0) * n_rec / max(args.rounds, 1)   # share of the step that is re-run forward work
+        rec["scaling_baseline_ms"] = round(1e3 * t_tr / (1.0 + extra), 2)
+        rec["scaling_baseline_note"] = (f"train_ms_per_step / (1 + {n_rec}/{args.rounds} x (recompute / no-recompute - 1)), the ratio measured on a "
+                                        f"{l5}-round model of the same mesh ({1e3 * t5['on']:.1f} / {1e3 * t5['off']:.1f} ms): the single-GPU step "
+                                        "as if all its saves fitted")
         del net5, opt5
     except Exception as ex:  # noqa: BLE001
         ops.set_activation_recompute("auto")
@@ -713,7 +716,7 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
     share = partitioned(8, 0, False)
     rec["rank_share_of_8"] = dict(share, note="per-GPU compute of the 8-way partitioned step (no exchange on one GPU)",
                                   est_8gpu_node_train_steps_per_s_before_comms=round(n / (share["train_ms_per_step"] * 1e-3), 1))
-    rec["note"] = ("N=1: train_ms_per_step is the whole mesh on one GPU with activation recompute; the N>1 runs of this command carry "
+    rec["note"] = ("N=1: train_ms_per_step is the whole mesh on one GPU with PARTIAL activation recompute (as many rounds saved as fit); the N>1 runs of this command carry "
                    "the partitioned step (saves kept when they fit: recompute switches itself off)")
     return rec
 

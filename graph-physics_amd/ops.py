@@ -705,10 +705,11 @@ def processor_apply(x, e, topo, L, *params, spec: BlockSpec = DEFAULT_SPEC, halo
 _recompute_mode = _os.environ.get("MGN_RECOMPUTE", "auto")
 
 
-def set_activation_recompute(mode: str) -> None:
+def set_activation_recompute(mode) -> None:
+    """"off" | "on" | "auto", or an int: recompute exactly that many (the first) rounds and save the others"""
     global _recompute_mode
-    if mode not in ("off", "on", "auto"):
-        raise ValueError("activation recompute mode must be 'off', 'on' or 'auto'")
+    if not (mode in ("off", "on", "auto") or (isinstance(mode, int) and not isinstance(mode, bool) and mode >= 0)):
+        raise ValueError("activation recompute mode must be 'off', 'on', 'auto' or a number of rounds")
     _recompute_mode = mode
 
 
@@ -722,17 +723,28 @@ def saved_activation_bytes(E: int, Nn: int, H: int, NL: int, L: int, act: int) -
     return L * (E * per_row + Nn * (per_row + 4 * H))                                  # + agg per node
 
 
-def _want_recompute(E, Nn, H, NL, L, act, dev) -> bool:
+def recompute_rounds(E, Nn, H, NL, L, act, dev) -> int:
+    """how many of the L rounds keep only their inputs and are re-run in the backward pass (the FIRST ones: they are
+    differentiated last, when the saved rounds have been released).  "auto": as many rounds are saved as fit in
+    MGN_RECOMPUTE_FRACTION (default 0.5) of the free device memory -- 0 recomputed on the bench batch, 6 of 15 on the
+    1M-node mesh on one GPU (all 15 before round 3: one extra forward per step where 40 % of one is enough)."""
     if _recompute_mode == "on":
-        return True
+        return L
     if _recompute_mode == "off":
-        return False
+        return 0
+    if isinstance(_recompute_mode, int):
+        return min(_recompute_mode, L)
     try:
         free, _total = torch.cuda.mem_get_info(dev)
+        # what the caching allocator holds without using it is free for this purpose (else the answer would change from the second
+        # step on, when the first step's blocks sit in the cache)
+        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
     except Exception:  # noqa: BLE001
-        return False
+        return 0
     frac = float(_os.environ.get("MGN_RECOMPUTE_FRACTION", "0.5"))
-    return saved_activation_bytes(E, Nn, H, NL, L, act) > frac * free
+    per_round = saved_activation_bytes(E, Nn, H, NL, 1, act)
+    fit = int(frac * free // max(per_round, 1))
+    return max(0, L - fit)
 
 
 # ------------------------------------------------------------ generic MLP (R2)
@@ -1102,7 +1114,8 @@ class ProcessorFunction(torch.autograd.Function):
         # activation recompute (see set_activation_recompute): the forward keeps only every round's INPUTS
         # and runs the inference-mode launches; the backward re-runs a round in training mode right before
         # differentiating it.  2.5 KB per edge and round shrink to 0.5 KB.
-        recompute = need and _want_recompute(E, Nn, H, NL, L, act, dev) and halo is None
+        n_rec = recompute_rounds(E, Nn, H, NL, L, act, dev) if (need and halo is None) else 0
+        recompute = n_rec > 0
         Pd = Ps = None
         pending = None  # halo exchange in flight
         if split:
@@ -1112,9 +1125,9 @@ class ProcessorFunction(torch.autograd.Function):
         saved = []
         for i in range(L):
             x_in, e_in = x, e
-            x, e, Pd, Ps, S, pending = run_round(i, x, e, Pd, Ps, need and not recompute, split and i + 1 < L, pending)
+            x, e, Pd, Ps, S, pending = run_round(i, x, e, Pd, Ps, need and i >= n_rec, split and i + 1 < L, pending)
             if need:
-                saved.append(S if not recompute else dict(x=x_in, e=e_in))
+                saved.append(S if i >= n_rec else dict(x=x_in, e=e_in))
         # the closures address the packed weights by raw pointer: keep the buffer alive with them
         ctx.rerun = (run_round, project, pk if x6 else None) if recompute else None
         ctx.topo, ctx.L, ctx.saved_acts, ctx.prec, ctx.spec, ctx.halo = topo, L, (saved if need else None), prec, spec, halo
@@ -1229,7 +1242,8 @@ class ProcessorFunction(torch.autograd.Function):
             q = P[PB * i: PB * (i + 1)]
             We, be, se, Wn, bn, sn, gpar = _split_block(q, spec)
             S = saved[i]
-            if ctx.rerun is not None:  # activation recompute: this round's training-mode forward, now
+            saved[i] = None  # a round's activations are released as soon as it is differentiated
+            if ctx.rerun is not None and "He" not in S:  # activation recompute: this round's training-mode forward, now
                 run_round, project = ctx.rerun[:2]
                 Pd_i, Ps_i = project(i, S["x"]) if split else (None, None)
                 S = run_round(i, S["x"], S["e"], Pd_i, Ps_i, True, False, None)[4]

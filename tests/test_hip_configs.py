@@ -454,7 +454,7 @@ def test_activation_recompute_bit_identical_and_smaller(dev):
     x_in, e_in, cot = R.randn((N, 11), 1).to(dev), R.randn((g.edge_index.shape[1], 3), 2).to(dev), R.randn((N, 2), 3).to(dev)
     res = {}
     assert ops.get_activation_recompute() == "auto"
-    for mode in ("off", "on"):
+    for mode in ("off", "on", 4):   # 4: the first four of the six rounds re-run, the last two saved
         ops.set_activation_recompute(mode)
         try:
             net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=128).to(dev)
@@ -473,6 +473,9 @@ def test_activation_recompute_bit_identical_and_smaller(dev):
     worst = max(rel_err(res["on"][1][k], res["off"][1][k]) for k in res["off"][1])
     assert worst < 2e-6, worst                                 # re-run rounds: gradients to fp32 rounding
     assert res["on"][2] < 0.45 * res["off"][2], (res["on"][2], res["off"][2])
+    assert torch.equal(res[4][0], res["off"][0])
+    assert max(rel_err(res[4][1][k], res["off"][1][k]) for k in res["off"][1]) < 2e-6
+    assert res["on"][2] < res[4][2] < 0.75 * res["off"][2], (res["on"][2], res[4][2], res["off"][2])
 
 
 # ------------------------------------------------------------------ hub nodes (R0)
