@@ -56,6 +56,11 @@ __device__ __forceinline__ void head_reduce(float (&p)[4], int NH) {
   }
 }
 
+// The edge loops below are software-pipelined by hand: the column index of edge e + 2 and the gathered rows of edge e + 1 are
+// requested before edge e is processed (a lane walks ONE row's edges serially, and index -> row -> arithmetic is a dependent
+// chain of two memory latencies per edge otherwise; rows of a wave have different degrees, so the compiler does not do it).
+__device__ __forceinline__ float4 ldrow(const float* p, size_t row, int H, int l) { return *(const float4*)(p + row * H + 4 * l); }
+
 // y[i] and lse[i] (per feature: log-sum-exp of its head's scores) for every row i
 template <int LPR>
 __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
@@ -68,20 +73,38 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
   const float4 qv = *(const float4*)(q + (size_t)i * H + 4 * l);
   const float qq[4] = {qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale};
   float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-    const size_t j = (size_t)col[e];
-    const float4 kv = *(const float4*)(k + j * H + 4 * l);
-    const float4 vv = *(const float4*)(v + j * H + 4 * l);
-    float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
-    head_reduce<LPR>(p, NH);
-    const float vr[4] = {vv.x, vv.y, vv.z, vv.w};
+  const int e0 = rowptr[i], e1 = rowptr[i + 1];
+  if (e0 < e1) {
+    float4 kv = ldrow(k, (size_t)col[e0], H, l), vv = ldrow(v, (size_t)col[e0], H, l);
+    int jn = (e0 + 1 < e1) ? col[e0 + 1] : 0;
+    for (int e = e0; e < e1; ++e) {
+      float4 kn = kv, vn = vv;
+      if (e + 1 < e1) kn = ldrow(k, (size_t)jn, H, l), vn = ldrow(v, (size_t)jn, H, l);
+      if (e + 2 < e1) jn = col[e + 2];
+      float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
+      head_reduce<LPR>(p, NH);
+      const float vr[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float nm = fmaxf(m[r], p[r]);
-      const float corr = expf(m[r] - nm), w = expf(p[r] - nm);   // first edge: exp(-inf) = 0
-      s[r] = s[r] * corr + w;
-      acc[r] = acc[r] * corr + w * vr[r];
-      m[r] = nm;
+      for (int r = 0; r < 4; ++r) {
+#ifdef MGN_ATTN_ONE_EXP  // one exponential per head and edge: of the two factors exp(m - nm), exp(p - nm) one is exactly 1.  Same
+        // value, but hipcc contracts the multiply-adds around it differently: outputs move by a few ulp (7e-7 of the scale), the launch
+        // 236 -> ~190 us, and the 10-block N = 12000 parity test reads 1.19e-3 element-wise against its 1e-3 bar (tensor-scale and RMS
+        // readings unchanged at 1e-5).  The shipped form keeps the bits the bars were set on; -DMGN_ATTN_ONE_EXP builds this one.
+        const bool up = p[r] > m[r];
+        const float t = expf(-fabsf(p[r] - m[r]));        // first edge: exp(-inf) = 0
+        const float corr = up ? t : 1.f, w = up ? 1.f : t;
+        s[r] = s[r] * corr + w;
+        acc[r] = acc[r] * corr + w * vr[r];
+        m[r] = up ? p[r] : m[r];
+#else
+        const float nm = fmaxf(m[r], p[r]);
+        const float corr = expf(m[r] - nm), w = expf(p[r] - nm);   // first edge: exp(-inf) = 0
+        s[r] = s[r] * corr + w;
+        acc[r] = acc[r] * corr + w * vr[r];
+        m[r] = nm;
+#endif
+      }
+      kv = kn, vv = vn;
     }
   }
   float4 o, ls;
@@ -117,52 +140,91 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int gs = (NH >= 4) ? (NH >> 2) : 1;     // lanes 0 .. gs-1 hold one copy of every head between them
   const int nr = (NH >= 4) ? 4 : NH;
-  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-    const size_t j = (size_t)col[e];
-    const float4 kv = *(const float4*)(k + j * H + 4 * l);
-    const float4 vv = *(const float4*)(v + j * H + 4 * l);
-    const float kr[4] = {kv.x, kv.y, kv.z, kv.w};
-    float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
-    float dA[4] = {g[0] * vv.x, g[1] * vv.y, g[2] * vv.z, g[3] * vv.w};
-    head_reduce<LPR>(p, NH);
-    head_reduce<LPR>(dA, NH);
+  const int e0 = rowptr[i], e1 = rowptr[i + 1];
+  if (e0 < e1) {
+    float4 kv = ldrow(k, (size_t)col[e0], H, l), vv = ldrow(v, (size_t)col[e0], H, l);
+    int jn = (e0 + 1 < e1) ? col[e0 + 1] : 0;
+    for (int e = e0; e < e1; ++e) {
+      float4 kn = kv, vn = vv;
+      if (e + 1 < e1) kn = ldrow(k, (size_t)jn, H, l), vn = ldrow(v, (size_t)jn, H, l);
+      if (e + 2 < e1) jn = col[e + 2];
+      const float kr[4] = {kv.x, kv.y, kv.z, kv.w};
+      float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
+      float dA[4] = {g[0] * vv.x, g[1] * vv.y, g[2] * vv.z, g[3] * vv.w};
+      head_reduce<LPR>(p, NH);
+      head_reduce<LPR>(dA, NH);
+      float a4[4], d4[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float a = expf(p[r] - ls[r]);
-      const float ds = a * (dA[r] - D[r]);
-      acc[r] += ds * kr[r];
-      if (l < gs && r < nr) {  // head h = 4l + r (NH >= 4) or r (NH < 4)
-        a_out[(size_t)e * NH + 4 * l + r] = a;
-        ds_out[(size_t)e * NH + 4 * l + r] = ds;
+      for (int r = 0; r < 4; ++r) {
+        a4[r] = expf(p[r] - ls[r]);
+        d4[r] = a4[r] * (dA[r] - D[r]);
+        acc[r] += d4[r] * kr[r];
       }
+      if (NH == 4) {  // lane 0 holds one copy of the four heads: one 16-byte store each
+        if (l == 0) {
+          *(float4*)(a_out + (size_t)e * 4) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+          *(float4*)(ds_out + (size_t)e * 4) = make_float4(d4[0], d4[1], d4[2], d4[3]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (l < gs && r < nr) {  // head h = 4l + r (NH >= 4) or r (NH < 4)
+            a_out[(size_t)e * NH + 4 * l + r] = a4[r];
+            ds_out[(size_t)e * NH + 4 * l + r] = d4[r];
+          }
+      }
+      kv = kn, vv = vn;
     }
   }
   *(float4*)(dq + ro) = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
 }
 
-// backward, pass B (by column j through the column-grouped CSR: cptr / cperm index the row-sorted edges):
+// backward, pass B (by column j through the column-grouped order of the same edges: the t-th edge of that order is the
+// row-sorted edge cperm[t], whose row is crow[t]):
 //   dk[j,f] = scale * sum_e ds[e,h(f)] q[i_e,f];   dv[j,f] = sum_e a[e,h(f)] dy[i_e,f]
 template <int LPR>
 __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ q, const float* __restrict__ dy, const float* __restrict__ a_in,
                                                      const float* __restrict__ ds_in, const int32_t* __restrict__ cptr,
-                                                     const int32_t* __restrict__ cperm, const int32_t* __restrict__ row_of_edge, long N, int NH,
+                                                     const int32_t* __restrict__ cperm, const int32_t* __restrict__ crow, long N, int NH,
                                                      float scale, float* __restrict__ dk, float* __restrict__ dv) {
   constexpr int H = 4 * LPR;
   const long j = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
   if (j >= N) return;
   float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int t = cptr[j]; t < cptr[j + 1]; ++t) {
-    const size_t e = (size_t)cperm[t];
-    const size_t i = (size_t)row_of_edge[e];
-    const float4 qv = *(const float4*)(q + i * H + 4 * l);
-    const float4 gv = *(const float4*)(dy + i * H + 4 * l);
-    const float qr[4] = {qv.x, qv.y, qv.z, qv.w}, gr[4] = {gv.x, gv.y, gv.z, gv.w};
+  const int t0 = cptr[j], t1 = cptr[j + 1];
+  auto heads = [&](const float* __restrict__ src, size_t e, float (&o)[4]) {
+    if (NH == 4) {
+      const float4 t = *(const float4*)(src + e * 4);
+      o[0] = t.x, o[1] = t.y, o[2] = t.z, o[3] = t.w;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int h = (4 * l + r) % NH;
-      ak[r] += ds_in[e * NH + h] * qr[r];
-      av[r] += a_in[e * NH + h] * gr[r];
+      for (int r = 0; r < 4; ++r) o[r] = src[e * NH + (4 * l + r) % NH];
+    }
+  };
+  if (t0 < t1) {
+    float4 qv = ldrow(q, (size_t)crow[t0], H, l), gv = ldrow(dy, (size_t)crow[t0], H, l);
+    float dsv[4], aw[4];
+    heads(ds_in, (size_t)cperm[t0], dsv), heads(a_in, (size_t)cperm[t0], aw);
+    int in = 0, en = 0;
+    if (t0 + 1 < t1) in = crow[t0 + 1], en = cperm[t0 + 1];
+    for (int t = t0; t < t1; ++t) {
+      float4 qn = qv, gn = gv;
+      float dsn[4] = {0.f, 0.f, 0.f, 0.f}, awn[4] = {0.f, 0.f, 0.f, 0.f};
+      if (t + 1 < t1) {
+        qn = ldrow(q, (size_t)in, H, l), gn = ldrow(dy, (size_t)in, H, l);
+        heads(ds_in, (size_t)en, dsn), heads(a_in, (size_t)en, awn);
+      }
+      if (t + 2 < t1) in = crow[t + 2], en = cperm[t + 2];
+      const float qr[4] = {qv.x, qv.y, qv.z, qv.w}, gr[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ak[r] += dsv[r] * qr[r];
+        av[r] += aw[r] * gr[r];
+      }
+      qv = qn, gv = gn;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsv[r] = dsn[r], aw[r] = awn[r];
     }
   }
   *(float4*)(dk + (size_t)j * H + 4 * l) = make_float4(ak[0] * scale, ak[1] * scale, ak[2] * scale, ak[3] * scale);
@@ -226,7 +288,7 @@ extern "C" int mgn_sparse_attn_fwd(const float* q, const float* k, const float* 
 
 extern "C" int mgn_sparse_attn_bwd(const float* q, const float* k, const float* v, const float* y, const float* lse, const float* dy,
                                    const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
-                                   const int32_t* row_of_edge, int64_t N, int64_t E, int H, int num_heads, float* dq, float* dk, float* dv,
+                                   const int32_t* crow, int64_t N, int64_t E, int H, int num_heads, float* dq, float* dk, float* dv,
                                    float* ws, size_t ws_bytes, void* stream) {
   if (!attn_args_ok(N, H, num_heads) || E < 0) return afail(1, "mgn_sparse_attn_bwd: bad arguments");
   if (ws_bytes < (size_t)2 * E * num_heads * sizeof(float)) return afail(1, "mgn_sparse_attn_bwd: workspace too small (2 * E * num_heads floats)");
@@ -236,7 +298,7 @@ extern "C" int mgn_sparse_attn_bwd(const float* q, const float* k, const float* 
   float* a_e = ws;
   float* ds_e = ws + (size_t)E * num_heads;
   ATTN_DISPATCH(k_attn_bwd_row, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, dq, a_e, ds_e);
-  ATTN_DISPATCH(k_attn_bwd_col, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, row_of_edge, (long)N, num_heads, scale, dk, dv);
+  ATTN_DISPATCH(k_attn_bwd_col, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, dk, dv);
   return acheck("mgn_sparse_attn_bwd");
 }
 

@@ -35,6 +35,7 @@ class AttnTopology:
         self.N, self.E = t.N, t.E
         self.rowptr, self.col, self.row = t.rowptr_dst, t.src_s, t.dst_s
         self.cptr, self.cperm = t.rowptr_src, t.perm_src
+        self.crow = self.row.index_select(0, self.cperm.long()).contiguous()   # row of the t-th edge of the column-grouped order
         self.perm = t.perm_dst   # row-sorted position -> edge id in the caller's edge_index
 
 
@@ -84,7 +85,7 @@ class SparseAttentionFn(torch.autograd.Function):
         with torch.cuda.device(q.device):
             rc = _capi.lib().mgn_sparse_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(), lse.data_ptr(), dy.data_ptr(),
                                                  topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.cptr.data_ptr(), topo.cperm.data_ptr(),
-                                                 topo.row.data_ptr(), N, topo.E, H, nh, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                                 topo.crow.data_ptr(), N, topo.E, H, nh, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                                  ws.data_ptr(), ws.numel() * 4, ops._stream(q.device))
         _capi.check(rc, "mgn_sparse_attn_bwd", attn=True)
         return dq, dk, dv, None, None

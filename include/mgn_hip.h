@@ -503,12 +503,14 @@ const char* mgn_prep_last_error(void);
  * receives per feature the log-sum-exp of its head's scores (what the backward needs).  Rows without
  * edges produce zeros.  H in {16,32,64,128}; num_heads in {1,2,4,8,16} dividing H.
  * Backward: dq, dk, dv from dy; cptr[N+1] / cperm[E] group the same (row-sorted) edge positions by
- * COLUMN, row_of_edge[E] = i_e; ws = 2 * E * num_heads floats.  Deterministic, atomics-free. */
+ * COLUMN, crow[E] = the row of the t-th edge of that column-grouped order (= i of edge cperm[t]; [r3]: it was
+ * row_of_edge[E] indexed by the row-sorted edge before -- one dependent load more per edge); ws = 2 * E * num_heads
+ * floats.  Deterministic, atomics-free. */
 int mgn_sparse_attn_fwd(const float* q, const float* k, const float* v, const int32_t* rowptr, const int32_t* col,
                         int64_t N, int H, int num_heads, float* y, float* lse, void* stream);
 int mgn_sparse_attn_bwd(const float* q, const float* k, const float* v, const float* y, const float* lse, const float* dy,
                         const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
-                        const int32_t* row_of_edge, int64_t N, int64_t E, int H, int num_heads,
+                        const int32_t* crow, int64_t N, int64_t E, int H, int num_heads,
                         float* dq, float* dk, float* dv, float* ws, size_t ws_bytes, void* stream);
 /* The attention weights themselves (Attention.forward(..., return_attention=True), layers.py:543-559,688-697: the values of
  * the softmax-ed sparse matrix): attn[out_pos[e], h] = exp(score[e,h] - lse[i_e,h]) for the row-sorted edge e; out_pos

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Workload for profiling BASELINE configs[4] (bench.py's c5 record): a few training steps and forwards of the coarse-aneurysm
-Transformer on a 3-D mesh.  usage: [rocprofv3 --kernel-trace --stats -d OUT --] python3 tools/c5_step.py [nodes]"""
+Transformer on a 3-D mesh.  usage: [rocprofv3 --kernel-trace --stats -d OUT --] python3 tools/c5_step.py [nodes [sorted]]"""
 import os
 import sys
 import time
@@ -18,6 +18,9 @@ from graph_physics_amd import transformer as T
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150000
 pts = np.random.default_rng(0).random((n, 3)).astype(np.float32)
+if len(sys.argv) > 2 and sys.argv[2] == "sorted":   # experiment on the input: points numbered along a Morton curve
+    from graph_physics_amd import partition
+    pts = pts[np.argsort(partition.morton_keys(pts), kind="stable")]
 ei = PP.faces_to_edges(torch.from_numpy(Delaunay(pts).simplices.T.astype(np.int64)).to(dev), n)
 cfg = {"model": {"type": "transformer", "message_passing_num": 10, "hidden_size": 64, "node_input_size": 14, "output_size": 3, "edge_input_size": 0,
                  "num_heads": 4}, "training": {"use_temporal_block": False}}
