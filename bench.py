@@ -867,12 +867,38 @@ def main():
             ops.set_matrix_precision("fp32")
         torch.cuda.empty_cache()
     if not args.no_c4:
+        # N > 1: the partitioned record runs collectives no single-GPU box has exercised over RCCL.  The HEADLINE is measured by
+        # now and must reach stdout whatever happens here: a rank that raises may leave its peers inside a collective, so every rank
+        # arms a watchdog that -- after a deadline no healthy run comes near -- has rank 0 print the line without the record and
+        # ends the process (exit code 0 on every rank: nothing is left that could synchronise them).
+        wd = None
+        if world > 1:
+            import threading
+            wd_done = threading.Event()
+
+            def bail(why):
+                if rank == 0:
+                    out["c4"] = {"error": why}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+            def watchdog():
+                if not wd_done.wait(float(os.environ.get("MGN_BENCH_C4_DEADLINE_S", "480"))):
+                    bail("the partitioned 1M-node record did not finish before the deadline (a rank stuck in a collective?)")
+
+            wd = threading.Thread(target=watchdog, daemon=True)
+            wd.start()
         try:
             c4 = c4_record(args, gp, D, ops, harness, rank, world, dev)
         except Exception as ex:  # noqa: BLE001  (the headline must survive a failure of the extra record)
             c4 = {"error": f"{type(ex).__name__}: {ex}"}
-            if world > 1:
-                raise
+            if world > 1:   # the peers may be waiting for this rank inside a collective: no barrier can be trusted any more
+                print(f"[bench] rank {rank}: c4 record failed: {c4['error']}", file=sys.stderr, flush=True)
+                if rank == 0:
+                    bail(c4["error"])
+                wd_done.wait()   # never set: this rank idles until its own watchdog ends it (rank 0 prints meanwhile)
+        if wd is not None:
+            wd_done.set()
         if rank == 0:
             out["c4"] = c4
     if rank == 0:
