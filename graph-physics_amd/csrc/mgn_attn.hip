@@ -86,23 +86,15 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
       const float vr[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#ifdef MGN_ATTN_ONE_EXP  // one exponential per head and edge: of the two factors exp(m - nm), exp(p - nm) one is exactly 1.  Same
-        // value, but hipcc contracts the multiply-adds around it differently: outputs move by a few ulp (7e-7 of the scale), the launch
-        // 236 -> ~190 us, and the 10-block N = 12000 parity test reads 1.19e-3 element-wise against its 1e-3 bar (tensor-scale and RMS
-        // readings unchanged at 1e-5).  The shipped form keeps the bits the bars were set on; -DMGN_ATTN_ONE_EXP builds this one.
+        // online softmax with ONE exponential per head and edge: of the two factors exp(m - nm), exp(p - nm) one is exactly 1, so the
+        // running sums are rescaled only where the maximum moved (no multiply by an exact 1).  236 -> ~190 us per launch against the
+        // two-exponential form; same value, other rounding (outputs move by <= 1e-6 of the scale; the three parity readings of the
+        // 10-block model for both forms on three seeds: profiles/r03_attn_one_exp_readings.txt)
         const bool up = p[r] > m[r];
         const float t = expf(-fabsf(p[r] - m[r]));        // first edge: exp(-inf) = 0
-        const float corr = up ? t : 1.f, w = up ? 1.f : t;
-        s[r] = s[r] * corr + w;
-        acc[r] = acc[r] * corr + w * vr[r];
+        s[r] = up ? __builtin_fmaf(s[r], t, 1.f) : s[r] + t;
+        acc[r] = up ? __builtin_fmaf(acc[r], t, vr[r]) : __builtin_fmaf(t, vr[r], acc[r]);
         m[r] = up ? p[r] : m[r];
-#else
-        const float nm = fmaxf(m[r], p[r]);
-        const float corr = expf(m[r] - nm), w = expf(p[r] - nm);   // first edge: exp(-inf) = 0
-        s[r] = s[r] * corr + w;
-        acc[r] = acc[r] * corr + w * vr[r];
-        m[r] = nm;
-#endif
       }
       kv = kn, vv = vn;
     }
