@@ -93,38 +93,50 @@ __device__ __forceinline__ float rowsum4d(float v) {
 // fragment read touches then start 17 chunks apart, 4-5 LDS cycles per ds_read_b128) and persistent workgroups walk the row
 // tiles -- without it every wave re-reads the matrix from L1 / L2 next to its row traffic (64 -> 64 at 600 000 rows: 124 us, of
 // which 40 us are those loads; timing-only builds).  Used when the image fits 64 KB (3+ workgroups per CU).
+// [ob0, ob1): the output blocks of this launch.  An LDSW launch stages only their slice of the matrices, so a product whose padded image
+// exceeds 64 KB (the gated 64 -> 192 pair: 104 KB) runs as 2 or 3 launches with an LDS-resident slice each (the rows are re-read per
+// launch: L2 / Infinity-Cache hits for the most part; the prologue's side outputs are written by the first).  As an inner loop over
+// slices the same thing cost every instance 10-16 registers (occupancy 7 -> 5 waves per SIMD, 192 -> 64: 54 -> 72 us).
 template <int KB, bool BF, bool GATE, bool LDSW>
-__global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
+__global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a, const int ob0, const int ob1) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   constexpr int SP = 16 * KB + 4;   // padded row stride of the LDS image (floats)
   extern __shared__ __attribute__((aligned(16))) float lw_[];
+  const int NC = 16 * (ob1 - ob0);   // matrix rows of this launch
   if (LDSW) {
-    const int nvec = a.N * (KB * 4);   // f32x4 elements of one matrix
+    const int nvec = NC * (KB * 4);    // f32x4 elements of one matrix slice
     for (int i = threadIdx.x; i < nvec; i += 256) {
       const int n = i / (KB * 4), j = i % (KB * 4);
-      *(f32x4*)(lw_ + n * SP + 4 * j) = *(const f32x4*)(a.W + (size_t)n * a.ldw + 4 * j);
-      if (GATE) *(f32x4*)(lw_ + (a.N + n) * SP + 4 * j) = *(const f32x4*)(a.W2 + (size_t)n * a.ldw + 4 * j);
+      *(f32x4*)(lw_ + n * SP + 4 * j) = *(const f32x4*)(a.W + (size_t)(16 * ob0 + n) * a.ldw + 4 * j);
+      if (GATE) *(f32x4*)(lw_ + (NC + n) * SP + 4 * j) = *(const f32x4*)(a.W2 + (size_t)(16 * ob0 + n) * a.ldw + 4 * j);
     }
     __syncthreads();
   }
   const long ntiles = (a.M + 63) / 64;
+  const int K = 16 * KB, kb1 = a.K1 >> 4, kb2 = kb1 + (a.K2 >> 4);
+  // rows of the (up to three) input phases; a phase with an index row is GATHERED (x[dst], x[src] of an edge row: the
+  // concatenation cat[e, x_i, x_j] of GraphNetBlock.edge_update, layers.py:1044-1060, is never materialised)
+  auto load_rows = [&](long tl, f32x4 (&dst)[KB]) {
+    const long m_ = (tl * 4 + wv) * 16 + c;
+    const long mm_ = m_ < a.M ? m_ : a.M - 1;
+    const long r1 = a.idx != nullptr ? (long)a.idx[mm_] : mm_;
+    const long r2 = a.idx2 != nullptr ? (long)a.idx2[mm_] : mm_;
+    const long r3 = a.idx3 != nullptr ? (long)a.idx3[mm_] : mm_;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+      dst[kb] = (kb < kb1)   ? *(const f32x4*)(a.x + r1 * a.ldx + 16 * kb + 4 * g)
+                : (kb < kb2) ? *(const f32x4*)(a.x2 + r2 * a.ldx2 + 16 * (kb - kb1) + 4 * g)
+                             : *(const f32x4*)(a.x3 + r3 * a.ldx3 + 16 * (kb - kb2) + 4 * g);
+  };
+  // (requesting the NEXT tile's rows before this tile's products -- one more register set -- measured slower: 64 -> 64 23.8 -> 26.7 us,
+  //  192 -> 64 54 -> 71 us at 150 000 rows; the launches keep 3-8 workgroups per CU and the other waves cover the latency)
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   const long m = (tile * 4 + wv) * 16 + c;
   const bool valid = m < a.M;
   const long mm = valid ? m : a.M - 1;
-  const int K = 16 * KB, kb1 = a.K1 >> 4, kb2 = kb1 + (a.K2 >> 4);
-  // rows of the (up to three) input phases; a phase with an index row is GATHERED (x[dst], x[src] of an edge row: the
-  // concatenation cat[e, x_i, x_j] of GraphNetBlock.edge_update, layers.py:1044-1060, is never materialised)
-  const long r1 = a.idx != nullptr ? (long)a.idx[mm] : mm;
-  const long r2 = a.idx2 != nullptr ? (long)a.idx2[mm] : mm;
-  const long r3 = a.idx3 != nullptr ? (long)a.idx3[mm] : mm;
   f32x4 in[KB];
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb)
-    in[kb] = (kb < kb1)   ? *(const f32x4*)(a.x + r1 * a.ldx + 16 * kb + 4 * g)
-             : (kb < kb2) ? *(const f32x4*)(a.x2 + r2 * a.ldx2 + 16 * (kb - kb1) + 4 * g)
-                          : *(const f32x4*)(a.x3 + r3 * a.ldx3 + 16 * (kb - kb2) + 4 * g);
+  load_rows(tile, in);
   if (a.norm_scale != nullptr) {  // RMSNorm prologue, reference epsilon placement: scale * x / (||x|| / sqrt(K) + eps)
     float ss = 0.f;
 #pragma unroll
@@ -133,7 +145,7 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
       for (int r = 0; r < 4; ++r) ss = fmaf(in[kb][r], in[kb][r], ss);
     ss = rowsum4d(ss);
     const float inv = 1.0f / (sqrtf(ss) / sqrtf((float)K) + a.eps);
-    if (a.inv_out != nullptr && valid && g == 0) a.inv_out[mm] = inv;
+    if (a.inv_out != nullptr && valid && g == 0 && ob0 == 0) a.inv_out[mm] = inv;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) in[kb] = *(const f32x4*)(a.norm_scale + 16 * kb + 4 * g) * (in[kb] * inv);
     if (a.n_out != nullptr && valid) {
@@ -145,12 +157,12 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) in[kb] = bf16r4(in[kb]);
   }
-  const int NB = a.N >> 4;
+  const int NB = ob1, OB0 = ob0;
   constexpr bool PF = KB <= 8 && !LDSW;   // prefetch the next output block's fragments from L2 (registers allow it)
   const float* w1 = a.W + (size_t)c * a.ldw + 4 * g;
   const float* w2 = GATE ? a.W2 + (size_t)c * a.ldw + 4 * g : nullptr;
   const float* l1 = lw_ + c * SP + 4 * g;
-  const float* l2 = lw_ + (a.N + c) * SP + 4 * g;
+  const float* l2 = lw_ + (NC + c) * SP + 4 * g;
   f32x4 wa[KB], wb[GATE ? KB : 1];
   if (PF) {
 #pragma unroll
@@ -159,7 +171,7 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
       if (GATE) wb[kb] = *(const f32x4*)(w2 + 16 * kb);
     }
   }
-  for (int ob = 0; ob < NB; ++ob) {
+  for (int ob = OB0; ob < NB; ++ob) {
     const int n0 = 16 * ob + 4 * g;
     f32x4 acc = (a.b != nullptr) ? *(const f32x4*)(a.b + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acc2 = (GATE && a.b2 != nullptr) ? *(const f32x4*)(a.b2 + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -182,8 +194,8 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
     } else if (LDSW) {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        ca[kb] = *(const f32x4*)(l1 + 16 * ob * SP + 16 * kb);
-        if (GATE) cb[kb] = *(const f32x4*)(l2 + 16 * ob * SP + 16 * kb);
+        ca[kb] = *(const f32x4*)(l1 + 16 * (ob - OB0) * SP + 16 * kb);
+        if (GATE) cb[kb] = *(const f32x4*)(l2 + 16 * (ob - OB0) * SP + 16 * kb);
       }
     } else {
       const size_t cur = (size_t)16 * ob * a.ldw;
@@ -219,7 +231,11 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
     }
     f32x4 y;
 #pragma unroll
+#ifdef LIN_EXP_NOACT   // timing experiment only: what the activation (erf / exp per element) costs
+    for (int r = 0; r < 4; ++r) y[r] = acc[r];
+#else
     for (int r = 0; r < 4; ++r) y[r] = d_act(acc[r], a.act);
+#endif
     if (BF && a.act >= 0) y = bf16r4(y);
     if (GATE) {
       y = y * acc2;
@@ -236,15 +252,17 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a) {
 }
 
 template <int KB, bool LDSW>
-static int launch_linear_v(const mgn_linear_args& a, unsigned grid, size_t lds, hipStream_t s) {
+static int launch_linear_v(const mgn_linear_args& a, unsigned grid, size_t lds, int nchunk, hipStream_t s) {
   const bool bf = a.precision == 1, gate = a.W2 != nullptr;
+  const int nbc = (a.N >> 4) / nchunk;   // output blocks per launch
 #define LIN_GO(BF_, GATE_)                                                                                                            \
   do {                                                                                                                                \
     if (LDSW && lds > 48 * 1024) {                                                                                                    \
       if (hipFuncSetAttribute((const void*)k_linear<KB, BF_, GATE_, LDSW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return 2;                                                                                                                     \
     }                                                                                                                                 \
-    hipLaunchKernelGGL((k_linear<KB, BF_, GATE_, LDSW>), dim3(grid), dim3(256), lds, s, a);                                           \
+    for (int ch = 0; ch < nchunk; ++ch)                                                                                               \
+      hipLaunchKernelGGL((k_linear<KB, BF_, GATE_, LDSW>), dim3(grid), dim3(256), lds, s, a, ch * nbc, (ch + 1) * nbc);               \
   } while (0)
   if (bf && gate) LIN_GO(true, true);
   else if (bf) LIN_GO(true, false);
@@ -256,16 +274,22 @@ static int launch_linear_v(const mgn_linear_args& a, unsigned grid, size_t lds, 
 template <int KB>
 static int launch_linear(const mgn_linear_args& a, hipStream_t s) {
   const long ntiles = (a.M + 63) / 64;
-  const size_t img = (size_t)(a.W2 != nullptr ? 2 : 1) * a.N * (16 * KB + 4) * sizeof(float);
-  // the LDS-resident weight image pays once every workgroup walks several tiles and three or more workgroups fit a CU
-  if (img <= 64 * 1024 && ntiles >= 1024 && getenv("MGN_LINEAR_NO_LDS") == nullptr) {
+  const size_t full = (size_t)(a.W2 != nullptr ? 2 : 1) * a.N * (16 * KB + 4) * sizeof(float);
+  // the LDS-resident weight image pays once every workgroup walks several tiles and three or more workgroups fit a CU; an image
+  // above 64 KB is cut into 2 or 3 groups of output blocks (MGN_LINEAR_NO_CHUNK: such launches stay on the L2 path, for A/B)
+  const int NB = a.N >> 4;
+  int nchunk = 1;
+  while (nchunk < 4 && (full / nchunk > 64 * 1024 || NB % nchunk != 0)) ++nchunk;
+  if (nchunk > 1 && getenv("MGN_LINEAR_NO_CHUNK") != nullptr) nchunk = 4;
+  const size_t img = full / (nchunk < 4 ? nchunk : 1);
+  if (nchunk < 4 && ntiles >= 1024 && getenv("MGN_LINEAR_NO_LDS") == nullptr) {
     int per_cu = (int)((160 * 1024) / img);
     if (per_cu > 8) per_cu = 8;
     unsigned grid = 256u * (unsigned)per_cu;
     if ((long)grid > ntiles) grid = (unsigned)ntiles;
-    return launch_linear_v<KB, true>(a, grid, img, s);
+    return launch_linear_v<KB, true>(a, grid, img, nchunk, s);
   }
-  return launch_linear_v<KB, false>(a, (unsigned)ntiles, 0, s);
+  return launch_linear_v<KB, false>(a, (unsigned)ntiles, 0, 1, s);
 }
 
 extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
