@@ -697,6 +697,17 @@ def processor_apply(x, e, topo, L, *params, spec: BlockSpec = DEFAULT_SPEC, halo
         _call.grad = True
 
 
+#: Called by ProcessorFunction.backward right after a round's weight-gradient launches are queued, with that round's parameter
+#: tensors and their gradients (the tensors backward() will return for them): a data-parallel wrapper starts the all-reduce of a
+#: bucket of rounds while the earlier rounds are still being differentiated (distributed.OverlappedGradAllReduce).  None: no call.
+_grad_ready_hook = None
+
+
+def set_grad_ready_hook(fn) -> None:
+    global _grad_ready_hook
+    _grad_ready_hook = fn
+
+
 #: activation recompute of the processor: "off" (save every round's activations: 2.5 KB per edge + 3 KB per
 #: node and round), "on", or "auto" (default): on when the saves would not fit comfortably -- more than
 #: MGN_RECOMPUTE_FRACTION (0.5) of the free device memory.  The 1M-node / 6M-edge mesh needs ~270 GB of
@@ -1414,6 +1425,11 @@ class ProcessorFunction(torch.autograd.Function):
             else:
                 dx_new = dx
             grads[PB * i: PB * (i + 1)] = g
+            if _grad_ready_hook is not None and halo is None and side is None and not fuse:
+                # this round's weight / bias gradients are final once their launches are queued (the two RMSNorm scale gradients come
+                # out of the deferred reduction at the very end): a data-parallel wrapper may start reducing them now
+                late = {2 * NL, k_ + 2 * NL} if (spec.layer_norm and deferred is not None) else set()
+                _grad_ready_hook([(P[PB * i + t], g[t]) for t in range(len(g)) if t not in late])
             dx, de = dx_new, de_new
         if side is not None:
             for ev in wdone:

@@ -142,3 +142,73 @@ def test_partitioned_hip_ranks_equal_unpartitioned_oracle(world):
     if world == 8:
         assert min(peers[r] for r in range(world - 1)) < world - 2   # pairs inside the main mesh that exchange nothing
         assert max(peers.values()) >= 3                   # a rank with three or more peers
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import graph_physics_amd as gp
+    from graph_physics_amd import distributed as D
+    from graph_physics_amd import harness, ops
+
+    dev = torch.device("cuda:0")
+    Ld = 6
+    params = R.make_params(R.epd_param_shapes(Ld, H, 11, 3, 2), SEED)
+    g = gp.cylinder_mesh(700, 40 + rank)          # every rank its own mesh (data parallel)
+    graph = lambda: gp.Graph(x=R.randn((700, 11), 50 + rank).to(dev), edge_attr=g.edge_attr.to(dev), edge_index=g.edge_index.to(dev))  # noqa: E731
+    tgt, nt = R.randn((700, 2), 60 + rank).to(dev), torch.zeros(700, device=dev)
+    res = {}
+    for kind in ("flat", "overlapped"):
+        net = gp.EncodeProcessDecode(Ld, 11, 3, 2, hidden_size=H).to(dev)
+        net.load_state_dict(params)
+        # 600 KB buckets: several all-reduces go out while the backward pass is still running (6 rounds x 150 000 parameters)
+        sync = D.GradAllReduce() if kind == "flat" else D.OverlappedGradAllReduce(bucket_bytes=600 << 10)
+        for _ in range(2):   # twice: the bucket state resets between steps
+            net.zero_grad(set_to_none=True)
+            harness.l2_loss(net(graph()), tgt, nt).backward()
+            if kind == "overlapped":
+                assert len(sync._inflight) >= 2, len(sync._inflight)   # buckets were started inside backward()
+            sync(net.parameters())
+        if kind == "overlapped":
+            assert not sync._inflight and not sync._cur
+            sync.close()
+            assert ops._grad_ready_hook is None
+        res[kind] = {k: v.grad.clone() for k, v in net.named_parameters()}
+    # two ranks: a + b is one rounding whatever the bucket layout -> bit-identical; more ranks: the collective adds a chunk's four
+    # values in an order that depends on where the chunk sits in its buffer -> equal to rounding
+    if world == 2:
+        same = all(torch.equal(res["flat"][k], res["overlapped"][k]) for k in res["flat"])
+    else:
+        same = all(float((res["flat"][k] - res["overlapped"][k]).abs().max()) <= 1e-6 * float(res["flat"][k].abs().max()) for k in res["flat"])
+    # and it IS the average over the ranks: compare one tensor with the all-gathered local gradients
+    net = gp.EncodeProcessDecode(Ld, 11, 3, 2, hidden_size=H).to(dev)
+    net.load_state_dict(params)
+    harness.l2_loss(net(graph()), tgt, nt).backward()
+    key = "processor_list.3.edge_block.2.weight"
+    local = dict(net.named_parameters())[key].grad.cpu()
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    mean = sum(gathered) / world
+    err = float((res["overlapped"][key].cpu() - mean).abs().max() / mean.abs().max())
+    q.put((rank, same, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_overlapped_gradient_all_reduce_equals_the_flat_one(world):
+    """distributed.OverlappedGradAllReduce (buckets reduced while the backward pass runs) against GradAllReduce (one flat
+    all-reduce after it): the same gradients on every rank (bit-identical at world 2), and they are the mean of the ranks' local gradients"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, same, err in res:
+        assert same, rank
+        assert err < 1e-6, (rank, err)
