@@ -28,3 +28,10 @@ busy += cur_e - cur_s
 print(f"two steps: wall {wall / 2e6:.3f} ms per step, GPU busy {busy / 2e6:.3f} ms per step, idle {(wall - busy) / 2e6:.3f} ms per step over {len(seg) // 2} launches per step")
 for n, (t, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:14]:
     print(f"  before {n:40s} {t / 2e3:8.1f} us per step in {c // 2:3d} gaps ({t / max(c, 1) / 1e3:5.1f} us each)")
+
+per = defaultdict(lambda: [0, 0])
+for st, en, n in seg:
+    per[n][0] += en - st; per[n][1] += 1
+print("kernel time per step (top 30):")
+for n, (t, c) in sorted(per.items(), key=lambda kv: -kv[1][0])[:30]:
+    print(f"  {n:40s} {t / 2e3:9.1f} us per step in {c / 2:6.1f} launches")
