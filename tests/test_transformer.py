@@ -183,7 +183,11 @@ def _ref_dense(x, W, b, x2, W2, b2, scale, act, resid):
 @pytest.mark.parametrize("K1,K2,N,norm,gate,act,res,M", [
     (64, 0, 64, True, False, None, False, 1000), (64, 0, 192, True, True, "gelu", False, 333), (192, 0, 64, False, False, None, True, 257),
     (128, 128, 128, False, False, "silu", False, 700), (128, 0, 384, True, True, "silu", False, 130), (384, 0, 128, False, False, None, True, 65),
-    (16, 16, 48, True, False, "relu", True, 50), (64, 0, 64, False, False, None, False, 1)])
+    (16, 16, 48, True, False, "relu", True, 50), (64, 0, 64, False, False, None, False, 1),
+    # >= 1024 row tiles: the persistent instances with the matrices resident in LDS (what the 150 000-node record runs) -- one image
+    # (64 -> 64, 192 -> 64 + residual), and the gated 64 -> 192 pair cut into two output-block slices (two launches); ragged last tile
+    (64, 0, 64, True, False, None, True, 70001), (192, 0, 64, False, False, None, True, 66000), (64, 0, 192, True, True, "gelu", False, 70001),
+    (64, 64, 192, False, True, "silu", False, 65537)])
 def test_dense_linear_vs_torch_reference(dev, K1, K2, N, norm, gate, act, res, M):
     """DenseFn (one fused launch: norm prologue, two phases, activation, gated product, bias, residual) and its backward
     (same launch with W^T, mgn_act_gate_bwd, mgn_rownorm_bwd, mgn_wgrad slabs) against plain fp32 torch on the CPU."""
@@ -213,6 +217,37 @@ def test_dense_linear_vs_torch_reference(dev, K1, K2, N, norm, gate, act, res, M
     assert_close3(out, ref.detach(), FWD_TOL, "dense forward")
     for a, b_ in zip(gpu, cpu):
         assert rel_err(a.grad, b_.grad) < 2e-5, tuple(a.shape)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [0, 1])
+def test_dense_lds_resident_instances_equal_the_l2_path(dev, monkeypatch, precision):
+    """the persistent k_linear instances (matrices staged in LDS; the gated pair in two output-block slices) against the same launch
+    with every wave reading its fragments from L2 (MGN_LINEAR_NO_LDS): same products in the same order -> bit-identical, in the fp32 and
+    the bf16 matrix mode, side outputs (normalised rows, 1/rms, both pre-activations) included"""
+    from graph_physics_amd import dense as D
+
+    M = 70001
+    x = R.randn((M, 64), 1).to(dev)
+    sc = (1.0 + 0.1 * R.randn((64,), 2)).to(dev)
+    for N, gate in ((64, False), (192, True)):
+        W, b = (R.randn((N, 64), 3) * 0.125).to(dev), (R.randn((N,), 4) * 0.1).to(dev)
+        W2, b2 = ((R.randn((N, 64), 5) * 0.125).to(dev), (R.randn((N,), 6) * 0.1).to(dev)) if gate else (None, None)
+        outs = []
+        for no_lds in (False, True):
+            if no_lds:
+                monkeypatch.setenv("MGN_LINEAR_NO_LDS", "1")
+            else:
+                monkeypatch.delenv("MGN_LINEAR_NO_LDS", raising=False)
+            f = dict(dtype=torch.float32, device=dev)
+            o, inv, n_out = torch.empty(M, N, **f), torch.empty(M, **f), torch.empty(M, 64, **f)
+            z1, z2 = torch.empty(M, N, **f), (torch.empty(M, N, **f) if gate else None)
+            D.linear_launch(x, W, b, W2=W2, b2=b2, norm_scale=sc, act=2 if gate else -1, out=o, inv_out=inv, n_out=n_out, saveZ1=z1, saveZ2=z2,
+                            precision=precision)
+            outs.append([o, inv, n_out, z1] + ([z2] if gate else []))
+        monkeypatch.delenv("MGN_LINEAR_NO_LDS", raising=False)
+        for a, b_ in zip(*outs):
+            assert torch.equal(a, b_), (N, gate, precision)
 
 
 @pytest.mark.gpu
