@@ -1164,8 +1164,6 @@ class ProcessorFunction(torch.autograd.Function):
         dev = P[0].device
         H = P[1].numel()
         Nn = saved[0]["x"].shape[0]
-        if ctx.rerun is not None and _os.environ.get("MGN_FRONT") is not None:
-            raise RuntimeError("MGN_FRONT and activation recompute are mutually exclusive")
         f = dict(dtype=torch.float32, device=dev)
         dx = _f32c(dx) if dx is not None else torch.zeros(Nn, H, **f)
         de = _f32c(de) if de is not None else torch.zeros(E, H, **f)
@@ -1241,9 +1239,11 @@ class ProcessorFunction(torch.autograd.Function):
         gs = [[(torch.zeros_like if empty else torch.empty_like)(t) for t in P[PB * i: PB * (i + 1)]] for i in range(L)]
         # packed path: the dX launch of round i and the node chain of round i-1 work on the same
         # rows -> one launch (front stage of mgn_mlp_bwd); dZn double buffered across rounds
-        # (measured neutral at N = 30k rows -- 88 us fused vs 57 + 30 us: a launch costs as many tile
-        # times as it has GEMM units -- so it is opt-in: MGN_FRONT=1; tests/test_hip_parity.py covers it)
-        fuse = (x6 and _os.environ.get("MGN_FRONT") is not None and spec == DEFAULT_SPEC and halo is None and ctx.rerun is None)
+        # (a launch costs as many tile times as it has GEMM units -- 88 us fused against 57 + 30 us at 30k node rows -- but it is one
+        # launch tail less per round: +0.7-0.9 % on the bench step in two alternating A/B pairs (74.86 / 74.77 against 74.36 / 74.06
+        # steps/s), so it is ON by default since round 3; MGN_FRONT=0 keeps the two launches; tests/test_hip_parity.py compares both.
+        # Not under activation recompute -- the previous round's activations do not exist yet -- nor on a partitioned mesh.)
+        fuse = (x6 and _os.environ.get("MGN_FRONT", "1") != "0" and spec == DEFAULT_SPEC and halo is None and ctx.rerun is None)
         dZn_sets = [dZn, [torch.empty(Nn, H, **f) for _ in range(NL)] if fuse and L > 1 else dZn]
         node_done = False
         # scale-gradient partials of all chain launches, reduced by ONE launch at the end (MGN_NO_DEFER: per launch)
@@ -1425,7 +1425,7 @@ class ProcessorFunction(torch.autograd.Function):
             else:
                 dx_new = dx
             grads[PB * i: PB * (i + 1)] = g
-            if _grad_ready_hook is not None and halo is None and side is None and not fuse:
+            if _grad_ready_hook is not None and halo is None and side is None:
                 # this round's weight / bias gradients are final once their launches are queued (the two RMSNorm scale gradients come
                 # out of the deferred reduction at the very end): a data-parallel wrapper may start reducing them now
                 late = {2 * NL, k_ + 2 * NL} if (spec.layer_norm and deferred is not None) else set()

@@ -551,7 +551,7 @@ torch.save({"out": out.detach().cpu(), **{k: p.grad.cpu() for k, p in net.named_
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = code % (root, os.path.join(root, "tests", "golden"))
     res = {}
-    for tag, env in (("x6", {}), ("fp32", {"MGN_FP32_MFMA": "1"}), ("front", {"MGN_FRONT": "1"}), ("fused_sd", {"MGN_FUSED_SD": "1"})):
+    for tag, env in (("x6", {"MGN_FRONT": "0"}), ("fp32", {"MGN_FP32_MFMA": "1"}), ("front", {}), ("fused_sd", {"MGN_FRONT": "0", "MGN_FUSED_SD": "1"})):
         path = f"/tmp/_mgn_paths_{tag}_{os.getpid()}.pt"
         e = dict(os.environ, **env)
         for k_ in ("MGN_FP32_MFMA", "MGN_FRONT", "MGN_FUSED_SD"):
@@ -564,7 +564,7 @@ torch.save({"out": out.detach().cpu(), **{k: p.grad.cpu() for k, p in net.named_
     for k in res["x6"]:
         # gradients: the suite's 1e-4-per-round criterion (a pre-activation within rounding of 0 flips its ReLU mask)
         assert rel_err(res["x6"][k], res["fp32"][k]) < (2e-6 if k == "out" else 3e-4), k
-        # the fused "dX of round i + node chain of round i-1" launch (MGN_FRONT=1) is the same arithmetic
+        # the fused "dX of round i + node chain of round i-1" launch (the default; MGN_FRONT=0 = two launches) is the same arithmetic
         assert rel_err(res["front"][k], res["x6"][k]) < (1e-7 if k == "out" else 2e-5), k
         # the destination-side scatter of dZ0 fused into the backward chain (MGN_FUSED_SD=1): tree-ordered sums
         assert rel_err(res["fused_sd"][k], res["x6"][k]) < (1e-7 if k == "out" else 2e-5), k
