@@ -424,3 +424,48 @@ def test_coarse_aneurysm_config_bf16_mode_vs_mixed_oracle(dev):
     # single-block test holds 0.5 x gap, the whole model the suite's bf16 convention of 1.5 x gap (tests/test_hip_configs.py, plate)
     assert e16 < 1.5 * gap + 1e-3, (e16, gap)
     print(f"coarse-aneurysm bf16: engine vs mixed oracle {e16:.2e}, mixed oracle vs fp32 {gap:.2e}")
+
+
+@pytest.mark.gpu
+def test_coarse_aneurysm_full_size_is_equivariant_under_renumbering_and_local(dev):
+    """BASELINE configs[4] at the bench record's FULL size (150 000 nodes, E ~ 2.3 M: the persistent LDS-resident dense launches, the
+    attention kernels over 2.3 M edges) through two size-independent properties of the model:
+      * renumbering the nodes permutes the output rows (every kernel walks other rows in another order: equal to rounding);
+      * locality: the output on 600 seed nodes equals the ORACLE's output on their 10-hop closure (the construction of the 1M-node
+        MeshGraphNet tests) -- a closure of ~10 blocks of a 3-D mesh is large, so the seeds sit in one corner and the oracle runs on
+        the sub-mesh within reach."""
+    import graph_physics_amd as gp
+
+    N, seed = 150000, 808
+    pos, ei, _ = R.delaunay_graph(N, seed, dim=3)
+    net = gp.get_model(ANEURYSM).to(dev)
+    params = R.variant_params(net.state_dict(), seed)
+    net.load_state_dict(params)
+    x_in = R.randn((N, 23), seed + 1)
+    with torch.no_grad():
+        out = net(gp.Graph(x=x_in.to(dev), edge_index=ei.to(dev), pos=pos.to(dev))).cpu()
+        perm = torch.from_numpy(np.random.default_rng(seed).permutation(N))      # new id of old node i: perm[i]
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(N)
+        out_p = net(gp.Graph(x=x_in[inv].to(dev), edge_index=perm[ei].to(dev), pos=pos[inv].to(dev))).cpu()
+    assert_close3(out_p[perm], out, FWD_TOL, "coarse-aneurysm forward at 150 000 nodes, renumbered")
+    # locality against the oracle: seeds = the 40 nodes nearest to a corner; 10 blocks reach 10 hops
+    d = (pos ** 2).sum(1)
+    seeds = torch.topk(-d, 40).indices.numpy()
+    src, dst = ei[0].numpy(), ei[1].numpy()
+    reach = np.zeros(N, dtype=bool)
+    reach[seeds] = True
+    for _ in range(10):
+        nxt = reach.copy()
+        nxt[dst[reach[src]]] = True      # attention rows = edge_index[0] attend to edge_index[1]: information flows col -> row
+        nxt[src[reach[dst]]] = True      # (the mesh is symmetric: either direction closes the same set)
+        reach = nxt
+    nodes = np.nonzero(reach)[0]
+    assert nodes.size < 110000, nodes.size   # (10 hops from a corner of a 53 x 53 x 53-node cube reach most of it: the oracle takes a few seconds on it)
+    loc = -np.ones(N, dtype=np.int64)
+    loc[nodes] = np.arange(nodes.size)
+    keep = reach[src] & reach[dst]
+    sub_ei = torch.from_numpy(np.stack([loc[src[keep]], loc[dst[keep]]]))
+    with torch.no_grad():
+        ref = O.etd_forward(x_in[torch.from_numpy(nodes)], sub_ei, params, 10, 4)
+    assert_close3(out[torch.from_numpy(seeds)], ref[torch.from_numpy(loc[seeds])], FWD_TOL, "coarse-aneurysm forward at 150 000 nodes, seeds vs oracle")
