@@ -433,7 +433,7 @@ def test_coarse_aneurysm_full_size_is_equivariant_under_renumbering_and_local(de
       * renumbering the nodes permutes the output rows (every kernel walks other rows in another order: equal to rounding);
       * locality: the output on 600 seed nodes equals the ORACLE's output on their 10-hop closure (the construction of the 1M-node
         MeshGraphNet tests) -- a closure of ~10 blocks of a 3-D mesh is large, so the seeds sit in one corner and the oracle runs on
-        the sub-mesh within reach."""
+        the sub-mesh within reach; the same construction gives every parameter gradient of the full-size backward pass."""
     import graph_physics_amd as gp
 
     N, seed = 150000, 808
@@ -466,6 +466,22 @@ def test_coarse_aneurysm_full_size_is_equivariant_under_renumbering_and_local(de
     loc[nodes] = np.arange(nodes.size)
     keep = reach[src] & reach[dst]
     sub_ei = torch.from_numpy(np.stack([loc[src[keep]], loc[dst[keep]]]))
-    with torch.no_grad():
-        ref = O.etd_forward(x_in[torch.from_numpy(nodes)], sub_ei, params, 10, 4)
-    assert_close3(out[torch.from_numpy(seeds)], ref[torch.from_numpy(loc[seeds])], FWD_TOL, "coarse-aneurysm forward at 150 000 nodes, seeds vs oracle")
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.etd_forward(x_in[torch.from_numpy(nodes)], sub_ei, p, 10, 4)
+    assert_close3(out[torch.from_numpy(seeds)], ref.detach()[torch.from_numpy(loc[seeds])], FWD_TOL, "coarse-aneurysm forward at 150 000 nodes, seeds vs oracle")
+    # ... and every parameter gradient of the full-size backward pass (row-vector weight gradients, norm backward, both attention passes
+    # over 2.3 M edges): the cotangent lives on the seeds, so the gradient is a function of the closure only
+    cot = R.randn((seeds.size, 3), seed + 3)
+    (ref[torch.from_numpy(loc[seeds])] * cot).sum().backward()
+    net.zero_grad(set_to_none=True)
+    out_g = net(gp.Graph(x=x_in.to(dev), edge_index=ei.to(dev), pos=pos.to(dev)))
+    (out_g[torch.from_numpy(seeds).to(dev)] * cot.to(dev)).sum().backward()
+    worst = 0.0
+    for k, t in net.named_parameters():
+        gref = p[k].grad
+        if k.endswith("k_proj.bias"):          # softmax-invariant: rounding noise on both sides
+            continue
+        e = rel_err(t.grad, gref)
+        worst = max(worst, e)
+        assert e < (2e-3 if ("encoder" in k or "decode" in k) else 2e-4), (k, e)
+    print(f"coarse-aneurysm N=150000: worst parameter-gradient error {worst:.2e}")
