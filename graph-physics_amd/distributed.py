@@ -69,7 +69,9 @@ class OverlappedGradAllReduce(GradAllReduce):
     additions depends on an element's place in its buffer: equal to rounding); the bucket sequence depends on tensor sizes only, so
     every rank issues the same collectives in the same order.  The listener is process-global (``ops.set_grad_ready_hook``): a
     backward pass that must NOT take part -- a rank stepping alone, another model -- needs ``close()`` first.  xGMI is point-to-point and a
-    ring all-reduce of 9 MB is latency-bound: 4 MB buckets = three collectives per step for the 15-round model."""
+    ring all-reduce of 9 MB is latency-bound: 4 MB buckets = three collectives per step for the 15-round model.
+    Assumes one backward pass per step into empty gradients (``zero_grad(set_to_none=True)``, as ``harness.Engine`` does): the
+    bucketed values REPLACE ``.grad``, they are not added to an accumulated one."""
 
     def __init__(self, group=None, bucket_bytes: int = 4 << 20):
         super().__init__(group, True)
