@@ -205,6 +205,10 @@ SYMBOLS = {
     "mgn_clip_adamw_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(OptTensor)]),
     "mgn_clip_adamw": (C.c_int, [C.c_int, C.POINTER(OptTensor), C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_clip_adamw_table_bytes": (C.c_size_t, [C.c_int, C.POINTER(OptTensor)]),
+    "mgn_clip_adamw_table": (C.c_int, [C.c_int, C.POINTER(OptTensor), C.c_void_p, C.c_size_t]),
+    "mgn_clip_adamw_t": (C.c_int, [C.c_int, C.POINTER(OptTensor), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mgn_halo_unpack_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mgn_gate_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -236,7 +240,7 @@ _lock = threading.Lock()
 
 #: ABI version this binding was written against (mgn_version() of the library must match: the
 #: ctypes structs above mirror exactly that header)
-EXPECTED_VERSION = 131
+EXPECTED_VERSION = 132
 HASH_PATH = os.path.join(_CSRC, "libmgn_hip.srchash")
 LOCK_PATH = os.path.join(_CSRC, ".build.lock")
 

@@ -702,6 +702,140 @@ extern "C" int mgn_clip_adamw(int n, const mgn_opt_tensor* t, float max_norm, co
   return pcheck("mgn_clip_adamw");
 }
 
+// ---- the same tail in TWO launches whatever the number of tensors (376 for the 15-round model: four launches of each kernel above,
+// each under-filling the GPU -- 130 us of a 3.3 ms one-mesh step).  What is fixed across steps (parameter / moment pointers, lengths,
+// the block -> tensor map) lives in a device table built once (mgn_clip_adamw_table); only the gradient pointers change from step
+// to step, and 480 of them fit the kernel-argument block.
+#define OPT_MAX_G 480
+struct OptStatic {
+  float* p;
+  float* m;
+  float* v;
+  int len;
+  int blk0;
+};
+struct OptG {
+  int n, total_blocks;
+  const OptStatic* tab;
+  const int* blk2t;
+  float* g[OPT_MAX_G];
+};
+__global__ void __launch_bounds__(256) k_sumsq_partial_t(const OptG L, float* __restrict__ part, float* __restrict__ step) {
+  __shared__ float red[256];
+  const int t = L.blk2t[blockIdx.x];
+  const OptStatic T = L.tab[t];
+  const long i0 = (long)((int)blockIdx.x - T.blk0) * OPT_CHUNK;
+  const float* g = L.g[t];
+  float s = 0.f;
+  for (long i = i0 + threadIdx.x; i < i0 + OPT_CHUNK && i < T.len; i += 256) s = fmaf(g[i], g[i], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = red[0];
+    if (blockIdx.x == 0) *step += 1.f;
+  }
+}
+__global__ void __launch_bounds__(256) k_clip_adamw_t(const OptG L, const float* __restrict__ part, const float* __restrict__ lr_p,
+                                                      const float* __restrict__ step_p, float beta1, float beta2, float eps, float wd,
+                                                      float max_norm, float* __restrict__ norm_out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < L.total_blocks; i += 256) s += part[i];   // same partials in the same order as k_clip_adamw: same norm
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  const float norm = sqrtf(red[0]);
+  if (norm_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
+  float coef = 1.f;
+  if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);  // clip_grad_norm_
+  const float lr = *lr_p, step = *step_p;
+  const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  const int t = L.blk2t[blockIdx.x];
+  const OptStatic T = L.tab[t];
+  const long i0 = (long)((int)blockIdx.x - T.blk0) * OPT_CHUNK;
+  float *p = T.p, *g = L.g[t], *m = T.m, *v = T.v;
+  for (long i = i0 + threadIdx.x; i < i0 + OPT_CHUNK && i < T.len; i += 256) {
+    const float gi = g[i] * coef;
+    g[i] = gi;
+    float pi = p[i] * (1.f - lr * wd);           // decoupled weight decay
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    p[i] = pi;
+  }
+}
+
+static size_t opt_table_bytes(int n, const mgn_opt_tensor* t) {
+  size_t blocks = 0;
+  for (int i = 0; i < n; ++i) blocks += (size_t)opt_blocks(t[i].n);
+  return (size_t)n * sizeof(OptStatic) + blocks * sizeof(int);
+}
+extern "C" size_t mgn_clip_adamw_table_bytes(int n, const mgn_opt_tensor* t) {
+  if (n < 1 || n > OPT_MAX_G) return 0;   // 0: too many tensors for the table form -- use mgn_clip_adamw
+  return opt_table_bytes(n, t);
+}
+// builds the device table of the tensors' FIXED fields (p, m, v, n; the g fields are ignored) -- a blocking host-to-device copy,
+// once per parameter set, outside any stream capture
+extern "C" int mgn_clip_adamw_table(int n, const mgn_opt_tensor* t, void* table, size_t table_bytes) {
+  if (n < 1 || n > OPT_MAX_G || table == nullptr) return pfail(1, "mgn_clip_adamw_table: bad arguments (at most 480 tensors)");
+  if (table_bytes < opt_table_bytes(n, t)) return pfail(1, "mgn_clip_adamw_table: table too small");
+  size_t blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (t[i].p == nullptr || t[i].m == nullptr || t[i].v == nullptr || t[i].n < 0 || t[i].n > 2147483647LL)
+      return pfail(1, "mgn_clip_adamw_table: null tensor / size out of range");
+    blocks += (size_t)opt_blocks(t[i].n);
+  }
+  const size_t bytes = (size_t)n * sizeof(OptStatic) + blocks * sizeof(int);
+  char* host = (char*)malloc(bytes);
+  if (host == nullptr) return pfail(2, "mgn_clip_adamw_table: out of host memory");
+  OptStatic* tab = (OptStatic*)host;
+  int* b2t = (int*)(host + (size_t)n * sizeof(OptStatic));
+  int b = 0;
+  for (int i = 0; i < n; ++i) {
+    tab[i].p = t[i].p, tab[i].m = t[i].m, tab[i].v = t[i].v, tab[i].len = (int)t[i].n, tab[i].blk0 = b;
+    const int nb = opt_blocks(t[i].n);
+    for (int k = 0; k < nb; ++k) b2t[b + k] = i;
+    b += nb;
+  }
+  const hipError_t e = hipMemcpy(table, host, bytes, hipMemcpyHostToDevice);
+  free(host);
+  if (e != hipSuccess) return pfail(2, "mgn_clip_adamw_table: copy failed");
+  return 0;
+}
+// the step itself: g[i] = this step's gradient of tensor i of the table; two launches; ws as for mgn_clip_adamw
+extern "C" int mgn_clip_adamw_t(int n, const mgn_opt_tensor* t, const void* table, float max_norm, const float* lr, float* step, float beta1,
+                                float beta2, float eps, float weight_decay, float* grad_norm_out, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n < 1 || n > OPT_MAX_G || table == nullptr || lr == nullptr || step == nullptr) return pfail(1, "mgn_clip_adamw_t: bad arguments");
+  if (ws_bytes < mgn_clip_adamw_workspace_bytes(n, t)) return pfail(1, "mgn_clip_adamw_t: workspace too small");
+  OptG L;
+  L.n = n;
+  int b = 0;
+  for (int i = 0; i < n; ++i) {
+    if (t[i].g == nullptr) return pfail(1, "mgn_clip_adamw_t: null gradient");
+    L.g[i] = t[i].g;
+    b += opt_blocks(t[i].n);
+  }
+  L.total_blocks = b;
+  L.tab = (const OptStatic*)table;
+  L.blk2t = (const int*)((const char*)table + (size_t)n * sizeof(OptStatic));
+  float* part = (float*)ws;
+  hipLaunchKernelGGL(k_sumsq_partial_t, dim3(b), dim3(256), 0, s, L, part, step);
+  hipLaunchKernelGGL(k_clip_adamw_t, dim3(b), dim3(256), 0, s, L, (const float*)part, lr, (const float*)step, beta1, beta2, eps, weight_decay,
+                     max_norm, grad_norm_out);
+  return pcheck("mgn_clip_adamw_t");
+}
+
 // ============================================================== halo exchange (8e)
 // The partitioned large-mesh path exchanges one [rows, H] block per round and neighbour: the send
 // rows are packed straight from the node kernel's output (mgn_gather_rows) and, in the backward

@@ -71,6 +71,7 @@ class FusedClipAdamW:
         self.norm_t = torch.zeros((), dtype=torch.float32, device=dev)
         self.param_groups = [{"lr": float(lr)}]
         self._ws = None
+        self._table, self._table_key = None, None   # device table of the tensors' fixed fields (mgn_clip_adamw_table)
 
     def set_lr(self, lr: float):
         self.param_groups[0]["lr"] = float(lr)
@@ -98,11 +99,28 @@ class FusedClipAdamW:
         need = L.mgn_clip_adamw_workspace_bytes(len(live), arr)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        # two launches whatever the number of tensors: parameter / moment pointers and lengths sit in a device table built once per
+        # parameter set (a blocking copy: the first, eager step builds it -- before any capture), the gradient pointers travel as
+        # kernel arguments (MGN_OPT_NO_TABLE: the 96-tensors-per-launch form, for A/B; same bits)
+        import os as _os
+        key = tuple((arr[i].p, arr[i].m, arr[i].v, arr[i].n) for i in range(len(live)))
+        tb = L.mgn_clip_adamw_table_bytes(len(live), arr) if _os.environ.get("MGN_OPT_NO_TABLE") is None else 0
         with torch.cuda.device(self.device):
-            rc = L.mgn_clip_adamw(len(live), arr, float(self.max_norm), self.lr_t.data_ptr(), self.step_t.data_ptr(),
-                                  float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                                  self.norm_t.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
-                                  torch.cuda.current_stream(self.device).cuda_stream)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            if tb > 0:
+                if self._table_key != key:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("FusedClipAdamW: the parameter table must be built by an eager step before the capture")
+                    self._table = torch.empty(tb, dtype=torch.uint8, device=self.device)
+                    C.check(L.mgn_clip_adamw_table(len(live), arr, self._table.data_ptr(), tb), "mgn_clip_adamw_table", prep=True)
+                    self._table_key = key
+                rc = L.mgn_clip_adamw_t(len(live), arr, self._table.data_ptr(), float(self.max_norm), self.lr_t.data_ptr(),
+                                        self.step_t.data_ptr(), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                        float(self.weight_decay), self.norm_t.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream)
+            else:
+                rc = L.mgn_clip_adamw(len(live), arr, float(self.max_norm), self.lr_t.data_ptr(), self.step_t.data_ptr(),
+                                      float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                                      self.norm_t.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream)
         C.check(rc, "mgn_clip_adamw", prep=True)
 
 

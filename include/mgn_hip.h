@@ -453,6 +453,16 @@ size_t mgn_clip_adamw_workspace_bytes(int n, const mgn_opt_tensor* tensors);
 int mgn_clip_adamw(int n, const mgn_opt_tensor* tensors, float max_norm, const float* lr, float* step,
                    float beta1, float beta2, float eps, float weight_decay, float* grad_norm_out,
                    void* ws, size_t ws_bytes, void* stream);
+/* [r3] The same tail in TWO launches whatever the number of tensors (up to 480): the fields that do not change from step to step
+ * (p, m, v, n) live in a device table built once per parameter set -- mgn_clip_adamw_table: a BLOCKING host-to-device copy, not to be
+ * called under stream capture; table_bytes from mgn_clip_adamw_table_bytes (0: too many tensors, use mgn_clip_adamw) -- and
+ * mgn_clip_adamw_t takes the step's gradient pointers (tensors[i].g; the other fields must equal the table's) as kernel arguments.
+ * Same arithmetic in the same order as mgn_clip_adamw: bit-identical results. */
+size_t mgn_clip_adamw_table_bytes(int n, const mgn_opt_tensor* tensors);
+int mgn_clip_adamw_table(int n, const mgn_opt_tensor* tensors, void* table, size_t table_bytes);
+int mgn_clip_adamw_t(int n, const mgn_opt_tensor* tensors, const void* table, float max_norm, const float* lr, float* step,
+                     float beta1, float beta2, float eps, float weight_decay, float* grad_norm_out,
+                     void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------- halo exchange
  * One-hop halo of the node-partitioned large mesh (no reference counterpart: the reference's

@@ -381,3 +381,34 @@ def test_row_vector_weight_gradient_kernel(dev, monkeypatch, M, nf, kw, lda, ldb
     monkeypatch.setenv("MGN_WGRAD_NO_ROW64", "1")
     dW3, db3 = run()
     assert float((dW3[:nf, :kw] - dW[:nf, :kw]).abs().max()) / scale < 2e-6
+
+
+@pytest.mark.gpu
+def test_optimizer_table_form_equals_the_chunked_form(dev, monkeypatch):
+    """mgn_clip_adamw_t (two launches, parameter table on the device, gradient pointers as kernel arguments) against mgn_clip_adamw
+    (96 tensors per launch): parameters, both moments, clipped gradients and the norm bit for bit over three steps with fresh
+    gradient tensors each step, 376 tensors as the 15-round model has them (sizes 1 .. 49 152)"""
+    from graph_physics_amd import harness
+
+    shapes = [(128, 384), (128,), (128, 128), (128,), (128, 128), (128,), (128, 128), (128,), (128,), (128, 256), (1,), (2, 128)] * 31 + [(7, 3)] * 4
+    res = {}
+    for form in ("table", "chunked"):
+        if form == "chunked":
+            monkeypatch.setenv("MGN_OPT_NO_TABLE", "1")
+        else:
+            monkeypatch.delenv("MGN_OPT_NO_TABLE", raising=False)
+        gen = torch.Generator().manual_seed(3)
+        params = [torch.nn.Parameter(torch.randn(*s, generator=gen).to(dev)) for s in shapes]
+        opt = harness.FusedClipAdamW(params, 1e-3, max_norm=1.0)
+        for step in range(3):
+            for p in params:
+                p.grad = (torch.randn(*p.shape, generator=gen) * (10.0 if step == 1 else 0.01)).to(dev)   # step 1 clips, the others do not
+            opt.step()
+        assert (opt._table is not None) == (form == "table")
+        res[form] = ([p.detach().clone() for p in params], [m.clone() for m in opt.exp_avg], [v.clone() for v in opt.exp_avg_sq],
+                     [p.grad.clone() for p in params], opt.norm_t.clone())
+    monkeypatch.delenv("MGN_OPT_NO_TABLE", raising=False)
+    for a, b in zip(res["table"][:4], res["chunked"][:4]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert torch.equal(res["table"][4], res["chunked"][4])
