@@ -205,6 +205,10 @@ SYMBOLS = {
     "mgn_clip_adamw_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(OptTensor)]),
     "mgn_clip_adamw": (C.c_int, [C.c_int, C.POINTER(OptTensor), C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mgn_masked_mse_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgn_masked_mse_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgn_clip_adamw_table_bytes": (C.c_size_t, [C.c_int, C.POINTER(OptTensor)]),
     "mgn_clip_adamw_table": (C.c_int, [C.c_int, C.POINTER(OptTensor), C.c_void_p, C.c_size_t]),
     "mgn_clip_adamw_t": (C.c_int, [C.c_int, C.POINTER(OptTensor), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,

@@ -702,6 +702,96 @@ extern "C" int mgn_clip_adamw(int n, const mgn_opt_tensor* t, float max_norm, co
   return pcheck("mgn_clip_adamw");
 }
 
+// ============================================================== masked mean-squared error (R8)
+// loss = mean over the rows whose node type is one of `types`, and over their O columns, of (out - target)^2
+// (graphphysics/training/loss.py:70-75 with the masks of lightning_module.py:27-35) -- in torch a dozen elementwise / reduction launches
+// forward and as many backward; here two launches forward (per-block partials, then a fixed-order finish that also stores
+// 1 / (rows x O) for the backward) and one backward: d_out = g * 2 (out - target) * w / (rows x O).  Deterministic, no atomics.
+#define MSE_PART 256
+__device__ __forceinline__ float mse_w(float t, float t0, float t1, float t2, float t3) {
+  return (t == t0 || t == t1 || t == t2 || t == t3) ? 1.f : 0.f;
+}
+__global__ void __launch_bounds__(256) k_mse_partial(const float* __restrict__ out, int ldo, const float* __restrict__ tgt, int ldt,
+                                                     const float* __restrict__ type, int ldty, long N, int O, float t0, float t1, float t2,
+                                                     float t3, float* __restrict__ part) {
+  __shared__ float s1[256], s2[256];
+  float a = 0.f, c = 0.f;
+  for (long n = (long)blockIdx.x * 256 + threadIdx.x; n < N; n += (long)MSE_PART * 256) {
+    const float w = mse_w(type[n * ldty], t0, t1, t2, t3);
+    if (w != 0.f) {
+      for (int o = 0; o < O; ++o) {
+        const float d = out[n * ldo + o] - tgt[n * ldt + o];
+        a = fmaf(d, d, a);
+      }
+      c += 1.f;
+    }
+  }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = c;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) {
+      s1[threadIdx.x] += s1[threadIdx.x + k];
+      s2[threadIdx.x] += s2[threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[2 * blockIdx.x] = s1[0], part[2 * blockIdx.x + 1] = s2[0];
+}
+__global__ void __launch_bounds__(256) k_mse_final(const float* __restrict__ part, int O, float* __restrict__ loss, float* __restrict__ inv) {
+  __shared__ float s1[256], s2[256];
+  s1[threadIdx.x] = part[2 * threadIdx.x];
+  s2[threadIdx.x] = part[2 * threadIdx.x + 1];
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) {
+      s1[threadIdx.x] += s1[threadIdx.x + k];
+      s2[threadIdx.x] += s2[threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float den = s2[0] * (float)O;   // 0 selected rows: 0 / 0 = nan, as torch's mean of an empty selection
+    *loss = s1[0] / den;
+    *inv = 1.f / den;
+  }
+}
+__global__ void __launch_bounds__(256) k_mse_bwd(const float* __restrict__ out, int ldo, const float* __restrict__ tgt, int ldt,
+                                                 const float* __restrict__ type, int ldty, long N, int O, float t0, float t1, float t2, float t3,
+                                                 const float* __restrict__ inv, const float* __restrict__ g, float* __restrict__ d_out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * O) return;
+  const long n = i / O;
+  const int o = (int)(i % O);
+  const float w = mse_w(type[n * ldty], t0, t1, t2, t3);
+  d_out[i] = (w != 0.f) ? (*g) * 2.f * (out[n * ldo + o] - tgt[n * ldt + o]) * (*inv) : 0.f;
+}
+// types[ntypes <= 4]: the node-type codes that take part; part: 2 * 256 floats of scratch; loss, inv: device scalars
+extern "C" int mgn_masked_mse_fwd(const float* out, int ldo, const float* tgt, int ldt, const float* type, int ldty, int64_t N, int O,
+                                  const float* types, int ntypes, float* part, float* loss, float* inv, void* stream) {
+  if (out == nullptr || tgt == nullptr || type == nullptr || part == nullptr || loss == nullptr || inv == nullptr || N < 0 || O < 1 ||
+      ntypes < 1 || ntypes > 4 || types == nullptr)
+    return pfail(1, "mgn_masked_mse_fwd: bad arguments (1..4 node types)");
+  float t[4];
+  for (int k = 0; k < 4; ++k) t[k] = types[k < ntypes ? k : 0];
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mse_partial, dim3(MSE_PART), dim3(256), 0, s, out, ldo, tgt, ldt, type, ldty, (long)N, O, t[0], t[1], t[2], t[3], part);
+  hipLaunchKernelGGL(k_mse_final, dim3(1), dim3(256), 0, s, (const float*)part, O, loss, inv);
+  return pcheck("mgn_masked_mse_fwd");
+}
+extern "C" int mgn_masked_mse_bwd(const float* out, int ldo, const float* tgt, int ldt, const float* type, int ldty, int64_t N, int O,
+                                  const float* types, int ntypes, const float* inv, const float* g, float* d_out, void* stream) {
+  if (out == nullptr || tgt == nullptr || type == nullptr || inv == nullptr || g == nullptr || d_out == nullptr || N < 0 || O < 1 ||
+      ntypes < 1 || ntypes > 4 || types == nullptr)
+    return pfail(1, "mgn_masked_mse_bwd: bad arguments (1..4 node types)");
+  if (N == 0) return 0;
+  float t[4];
+  for (int k = 0; k < 4; ++k) t[k] = types[k < ntypes ? k : 0];
+  hipLaunchKernelGGL(k_mse_bwd, dim3((unsigned)((N * O + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, ldo, tgt, ldt, type, ldty,
+                     (long)N, O, t[0], t[1], t[2], t[3], inv, g, d_out);
+  return pcheck("mgn_masked_mse_bwd");
+}
+
 // ---- the same tail in TWO launches whatever the number of tensors (376 for the 15-round model: four launches of each kernel above,
 // each under-filling the GPU -- 130 us of a 3.3 ms one-mesh step).  What is fixed across steps (parameter / moment pointers, lengths,
 // the block -> tensor map) lives in a device table built once (mgn_clip_adamw_table); only the gradient pointers change from step

@@ -453,6 +453,15 @@ size_t mgn_clip_adamw_workspace_bytes(int n, const mgn_opt_tensor* tensors);
 int mgn_clip_adamw(int n, const mgn_opt_tensor* tensors, float max_norm, const float* lr, float* step,
                    float beta1, float beta2, float eps, float weight_decay, float* grad_norm_out,
                    void* ws, size_t ws_bytes, void* stream);
+/* [r3] The loss of the training step (graphphysics/training/loss.py:70-75 with the node-type masks of lightning_module.py:27-35):
+ *   loss = mean over the rows whose type (type[n * ldty], compared as a float like the reference's `node_type == NodeType.X`) is one
+ *   of types[0..ntypes) (ntypes <= 4), and over their O columns, of (out - target)^2
+ * -- two launches (part: 512 floats of scratch; loss and inv = 1 / (rows x O) are device scalars), one launch for
+ * d_out = g * 2 (out - target) * w * inv.  `types` is a HOST array.  Deterministic (fixed-order partials). */
+int mgn_masked_mse_fwd(const float* out, int ldo, const float* target, int ldt, const float* type, int ldty, int64_t N, int O,
+                       const float* types, int ntypes, float* part, float* loss, float* inv, void* stream);
+int mgn_masked_mse_bwd(const float* out, int ldo, const float* target, int ldt, const float* type, int ldty, int64_t N, int O,
+                       const float* types, int ntypes, const float* inv, const float* g, float* d_out, void* stream);
 /* [r3] The same tail in TWO launches whatever the number of tensors (up to 480): the fields that do not change from step to step
  * (p, m, v, n) live in a device table built once per parameter set -- mgn_clip_adamw_table: a BLOCKING host-to-device copy, not to be
  * called under stream capture; table_bytes from mgn_clip_adamw_table_bytes (0: too many tensors, use mgn_clip_adamw) -- and

@@ -412,3 +412,42 @@ def test_optimizer_table_form_equals_the_chunked_form(dev, monkeypatch):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert torch.equal(res["table"][4], res["chunked"][4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,O", [(30160, 2), (1, 3), (70001, 3), (257, 1)])
+def test_fused_masked_mse_equals_the_torch_formula(dev, monkeypatch, N, O):
+    """harness.l2_loss on the device (mgn_masked_mse_fwd / _bwd: three launches) against its own torch formula (MGN_TORCH_LOSS) and the
+    oracle: loss and gradient, node types read through a strided view as the training step passes them, an upstream factor in the
+    backward pass; a batch without a single selected row gives nan like torch's mean of an empty selection"""
+    from graph_physics_amd import harness
+
+    g = torch.Generator().manual_seed(N + O)
+    x = torch.randn(N, 5, generator=g)
+    x[:, 2] = torch.randint(0, 7, (N,), generator=g).float()
+    x = x.to(dev)
+    nt = x[:, 2]                                           # stride 5
+    out = torch.randn(N, O, generator=g).to(dev).requires_grad_(True)
+    tgt = torch.randn(N, O, generator=g).to(dev)
+    res = {}
+    for form in ("fused", "torch"):
+        if form == "torch":
+            monkeypatch.setenv("MGN_TORCH_LOSS", "1")
+        else:
+            monkeypatch.delenv("MGN_TORCH_LOSS", raising=False)
+        out.grad = None
+        loss = harness.l2_loss(out, tgt, nt)
+        (3.0 * loss).backward()
+        res[form] = (loss.detach().clone(), out.grad.clone())
+    monkeypatch.delenv("MGN_TORCH_LOSS", raising=False)
+    ref = O_l2(out.detach().cpu(), tgt.cpu(), nt.cpu())
+    if bool(torch.isnan(ref)):
+        assert bool(torch.isnan(res["fused"][0]))
+        return
+    assert abs(float(res["fused"][0]) - float(ref)) < 2e-6 * abs(float(ref))
+    assert abs(float(res["fused"][0]) - float(res["torch"][0])) < 2e-6 * abs(float(ref))
+    assert rel_err(res["fused"][1], res["torch"][1]) < 1e-6
+
+
+def O_l2(out, tgt, nt):
+    return O.l2_loss(out, tgt, nt)
