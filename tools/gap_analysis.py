@@ -10,9 +10,8 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[:40]))
 rows.sort()
 # the training steps: from the third-last k_clip_adamw group to the end
-idx = [i for i, r in enumerate(rows) if r[2].startswith("k_sumsq_partial")]
-# steps are delimited by the first k_sumsq_partial of each optimiser tail (4 launches per tail)
-starts = [i for j, i in enumerate(idx) if j % 4 == 0]
+# steps are delimited by the first k_sumsq_partial* launch of each optimiser tail (one launch, or several in a row)
+starts = [i for i, r in enumerate(rows) if r[2].startswith("k_sumsq_partial") and not (i > 0 and rows[i - 1][2].startswith("k_sumsq_partial"))]
 a, b = starts[-3], starts[-1]          # two whole steps
 seg = rows[a:b]
 wall = seg[-1][1] - seg[0][0]
