@@ -187,14 +187,15 @@ class DenseFn(torch.autograd.Function):
                             job = job + (db[j0:j0 + nj],)
                         first = False
                         jobs.append(job)
-            if M > 0:
-                ops.wgrad(jobs, dev, prec)
-            return dW, db
+            return dW, db, jobs
 
-        dW, db = wgrad_of(dZ1, has_b)
+        dW, db, jobs = wgrad_of(dZ1, has_b)
         dW2 = db2 = None
-        if W2 is not None:
-            dW2, db2 = wgrad_of(dZ2, has_b2)
+        if W2 is not None:   # both matrices of a gated product in ONE weight-gradient launch (and one reduction)
+            dW2, db2, jobs2 = wgrad_of(dZ2, has_b2)
+            jobs = jobs + jobs2
+        if M > 0:
+            ops.wgrad(jobs, dev, prec)
         ctx.aux = None
         return (dxs[0] if want[0] else None, dxs[1] if want[1] else None, dxs[2] if want[2] else None, dW, db, dW2, db2,
                 dscale, dy if has_res else None, None, None, None)
