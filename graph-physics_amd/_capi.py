@@ -16,8 +16,12 @@ _REPO = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("MGN_LIB") or os.path.join(_CSRC, "libmgn_hip.so")
 SOURCES = [os.path.join(_CSRC, "mgn_kernels.hip"), os.path.join(_CSRC, "mgn_prep.hip"), os.path.join(_CSRC, "mgn_attn.hip"),
            os.path.join(_CSRC, "mgn_dense.hip")]
-DEPS = [os.path.join(_CSRC, "mgn_x6.inc"), os.path.join(_CSRC, "mgn_fused.inc")]  # included by the source
+DEPS = [os.path.join(_CSRC, "mgn_x6.inc"), os.path.join(_CSRC, "mgn_fused.inc"), os.path.join(_CSRC, "mgn_pp.inc")]  # included by the source
 HEADER = os.path.join(_REPO, "include", "mgn_hip.h")
+# No packed-fp32 VALU (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) in device code: beside a SIMD partner that streams MFMAs
+# one of them takes ~70 cycles instead of ~6 (tools/coissue_probe.hip; plain VALU: 8), and hipcc forms them everywhere --
+# the SLP vectorizer out of scalar code, the legalizer out of float4 arithmetic (csrc/Makefile carries the same flags).
+DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 MAX_LAYERS = 8
 MAX_PHASES = 3
@@ -267,6 +271,7 @@ def source_hash() -> str:
     for f in SOURCES + DEPS + [HEADER]:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read() + b"\0")
+    h.update(" ".join(DEVICE_FLAGS).encode())  # a library built with other code-generation flags is stale too
     return h.hexdigest()
 
 
@@ -299,7 +304,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if not force and not needs_build():  # another rank built it while we waited
                 return LIB_PATH
             tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + DEVICE_FLAGS + [
                    "-I", os.path.join(_REPO, "include"), "-o", tmp] + SOURCES
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:

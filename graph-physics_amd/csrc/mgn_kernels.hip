@@ -1656,6 +1656,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
 }
 
 #include "mgn_x6.inc"
+#include "mgn_pp.inc"
 #include "mgn_fused.inc"
 
 // dW[r,k] = sum over the job's workgroup partials.  64 outputs x 4 partial-lanes per block:
@@ -2013,6 +2014,22 @@ static int fwd_static_shape(const mgn_mlp_fwd_args& a) {
   return 0;
 }
 
+// The ping-pong edge update (mgn_pp.inc) takes a ShEdge launch when it is fp32-grade, its four units lie back to back,
+// the messages are not written (fused aggregation only), the saves are all there or all absent, and every CU gets at
+// least two 128-row tiles (on a one-tile launch the alternation only doubles the tile's latency).  MGN_PP=0: off.
+static bool fwd_pp_ok(const mgn_mlp_fwd_args& a) {
+  const char* env = getenv("MGN_PP");
+  if (env == nullptr || atoi(env) == 0) return false;  // opt-in while the kernel is being tuned
+  const int64_t min_rows = (env != nullptr && atoi(env) == 2) ? 1 : 2 * 128 * 256;  // MGN_PP=2: any size (tests)
+  if (a.precision != 0 || a.y_out != nullptr || a.M < min_rows) return false;
+  for (int u = 1; u < 4; ++u)
+    if ((const char*)a.wpk[u] != (const char*)a.wpk[0] + (size_t)u * MGN_WPACK_BYTES) return false;
+  const bool all = a.saveU && a.saveR && a.saveH[0] && a.saveH[1] && a.saveH[2] && a.saveM[0] && a.saveM[1] && a.saveM[2];
+  const bool none = !a.saveU && !a.saveR && !a.saveH[0] && !a.saveH[1] && !a.saveH[2] && !a.saveM[0] && !a.saveM[1] && !a.saveM[2];
+  // rows past M are computed as copies of row M - 1 and stored there again: the outputs must alias no input
+  return (all || none) && a.resid != nullptr && a.scale != nullptr && a.out != a.resid && a.out != a.src[0];
+}
+
 template <int HB>
 static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
   const bool ragged = fwd_ragged(a);
@@ -2045,6 +2062,22 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
       if (atoi(e) > 0 && (unsigned)atoi(e) < grid) grid = (unsigned)atoi(e);
     }
     const int shape = (nw == 4 && !silu) ? fwd_static_shape(a) : 0;
+    if (shape == 1 && !nw6 && fwd_pp_ok(a)) {
+      static thread_local bool pp_attr = false;
+      if (!pp_attr) {
+        if (hipFuncSetAttribute((const void*)k_edge_fwd_pp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_edge_fwd_pp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess)
+          return 1;
+        pp_attr = true;
+      }
+      unsigned gp = (unsigned)((a.M + 127) / 128);
+      if (gp > 256u) gp = 256u;
+      if (a.saveU != nullptr)
+        hipLaunchKernelGGL((k_edge_fwd_pp<true>), dim3(gp), dim3(512), PP_LDS_BYTES, s, a);
+      else
+        hipLaunchKernelGGL((k_edge_fwd_pp<false>), dim3(gp), dim3(512), PP_LDS_BYTES, s, a);
+      return 0;
+    }
     if (shape == 1 && nw6 && a.precision == 0) {
       unsigned g6 = (unsigned)((a.M + 95) / 96);
       if (g6 > 512u) g6 = 512u;
