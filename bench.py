@@ -743,7 +743,7 @@ def main():
     eng = harness.Engine(cfg, dev, learning_rate=1e-4, num_steps=10000, warmup=100)
     if world > 1:
         D.broadcast_parameters(eng.sim)
-        eng.grad_sync = D.OverlappedGradAllReduce()   # 4 MB buckets reduced while the backward pass runs
+        eng.grad_sync = D.OverlappedGradAllReduce(params=list(eng.sim.parameters()))   # 4 MB buckets reduced while the backward pass runs
     batch = gp.cylinder_batch(args.batch, args.nodes, seed0=rank * args.batch).to(dev)
     N, E = batch.x.shape[0], batch.edge_index.shape[1]
     # topology prep (CSR by dst + by src): timed on its own, outside the headline's timed region --

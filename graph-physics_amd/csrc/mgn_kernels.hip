@@ -2021,7 +2021,7 @@ static bool fwd_pp_ok(const mgn_mlp_fwd_args& a) {
   const char* env = getenv("MGN_PP");
   if (env == nullptr || atoi(env) == 0) return false;  // opt-in while the kernel is being tuned
   const int64_t min_rows = (env != nullptr && atoi(env) == 2) ? 1 : 2 * 128 * 256;  // MGN_PP=2: any size (tests)
-  if (a.precision != 0 || a.y_out != nullptr || a.M < min_rows) return false;
+  if (a.precision != 0 || a.y_out != nullptr || a.M < min_rows || a.M * 512 >= (int64_t)1 << 32) return false;  // (32-bit row offsets)
   for (int u = 1; u < 4; ++u)
     if ((const char*)a.wpk[u] != (const char*)a.wpk[0] + (size_t)u * MGN_WPACK_BYTES) return false;
   const bool all = a.saveU && a.saveR && a.saveH[0] && a.saveH[1] && a.saveH[2] && a.saveM[0] && a.saveM[1] && a.saveM[2];

@@ -71,20 +71,33 @@ class OverlappedGradAllReduce(GradAllReduce):
     backward pass that must NOT take part -- a rank stepping alone, another model -- needs ``close()`` first.  xGMI is point-to-point and a
     ring all-reduce of 9 MB is latency-bound: 4 MB buckets = three collectives per step for the 15-round model.
     Assumes one backward pass per step into empty gradients (``zero_grad(set_to_none=True)``, as ``harness.Engine`` does): the
-    bucketed values REPLACE ``.grad``, they are not added to an accumulated one."""
+    bucketed values REPLACE ``.grad``, they are not added to an accumulated one -- a parameter reported twice before ``__call__``
+    (gradient accumulation, two losses, a step that aborted without ``reset()``) raises instead of keeping the last pass only.
+    ``params``: the parameters of the wrapped model; gradients of any other tensor that passes the process-global hook (another
+    model's backward pass in the same process) are ignored.  Without it every reported gradient is taken."""
 
-    def __init__(self, group=None, bucket_bytes: int = 4 << 20):
+    def __init__(self, group=None, bucket_bytes: int = 4 << 20, params: Optional[Iterable[torch.nn.Parameter]] = None):
         super().__init__(group, True)
         self.bucket_bytes = bucket_bytes
         self._cur, self._cur_bytes, self._inflight = [], 0, []
+        self._seen = set()     # data_ptrs reported since the last __call__ / reset
+        self._mine = None if params is None else {p.data_ptr() for p in params}
         from . import ops
         ops.set_grad_ready_hook(self._on_ready)
+
+    def reset(self):
+        """drop what a step that did not reach ``__call__`` has left behind (pending collectives are waited for first: every
+        rank issued them, none may be abandoned half-way)"""
+        for work, _flat, _ents in self._inflight:
+            work.wait()
+        self._cur, self._cur_bytes, self._inflight = [], 0, []
+        self._seen = set()
 
     def close(self):
         """stop listening (before another model -- e.g. the partitioned one -- runs its backward pass)"""
         from . import ops
         ops.set_grad_ready_hook(None)
-        self._cur, self._cur_bytes, self._inflight = [], 0, []
+        self.reset()
 
     def _active(self) -> bool:
         return dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -93,7 +106,15 @@ class OverlappedGradAllReduce(GradAllReduce):
         if not self._active():
             return
         for p, g in pairs:
-            self._cur.append((p.data_ptr(), g))
+            ptr = p.data_ptr()
+            if self._mine is not None and ptr not in self._mine:
+                continue   # not a parameter of the wrapped model
+            if ptr in self._seen:
+                raise RuntimeError("OverlappedGradAllReduce: a parameter's gradient was reported twice before the step's "
+                                   "all-reduce (gradient accumulation / several backward passes per step are not supported: "
+                                   "use GradAllReduce, or call reset() after an aborted step)")
+            self._seen.add(ptr)
+            self._cur.append((ptr, g))
             self._cur_bytes += 4 * g.numel()
         if self._cur_bytes >= self.bucket_bytes:
             self._flush()
@@ -120,7 +141,12 @@ class OverlappedGradAllReduce(GradAllReduce):
                 done[ptr] = flat[off:off + n]
                 off += n
         self._inflight = []
+        self._seen = set()
         ps = [p for p in params if p.grad is not None]
+        stray = set(done) - {p.data_ptr() for p in ps}
+        if stray:
+            raise RuntimeError(f"OverlappedGradAllReduce: {len(stray)} bucketed gradient(s) belong to no parameter of this step "
+                               "(another model's backward pass fed the hook: pass params= at construction)")
         early = [p for p in ps if p.data_ptr() in done]
         if early:
             torch._foreach_copy_([p.grad for p in early], [done[p.data_ptr()].view_as(p.grad) for p in early])

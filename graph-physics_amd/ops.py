@@ -77,6 +77,8 @@ def pad16(n: int) -> int:
 #: destination is called), so it equals the un-renumbered result up to the association of partial sums at tile
 #: boundaries; the source-side scatter of the backward pass walks the dst-sorted rows, whose order does change.
 _renumber_mode = _os.environ.get("MGN_RENUMBER", "auto")
+if _renumber_mode not in ("off", "on", "auto"):
+    raise ValueError(f"MGN_RENUMBER={_renumber_mode!r}: expected 'off', 'on' or 'auto'")
 RENUMBER_MIN_NODES = 200_000
 
 
@@ -182,6 +184,7 @@ class Topology:
         ws = torch.empty(max(L.mgn_topology_workspace_bytes(E, N), 16), dtype=torch.uint8, device=dev)
         self._inv = None
         self._pending = None
+        self._error = None   # sticky: a topology whose build reported stray indices raises on EVERY resolve / use
         self._uses = 0
         self.hub_dst = self.hub_src = None
         if lazy:
@@ -230,14 +233,17 @@ class Topology:
             err, din, dout = int(host[0]), int(host[1]), int(host[2])
             if err:
                 self.max_in_degree = self.max_out_degree = 0
-                raise IndexError(f"edge_index has entries outside [0, {self.N})")
-            self._set_degrees(din, dout)
+                self._error = IndexError(f"edge_index has entries outside [0, {self.N})")
+            else:
+                self._set_degrees(din, dout)
+        if self._error is not None:   # also on a cache hit of get_topology: never compute silently on clamped indices
+            raise self._error
         return self
 
     def begin_use(self) -> bool:
         """hub state for ONE pass over this topology (see the class docstring): a fresh lazy build is taken
         as hub-free by its first user, later users wait for the flags"""
-        if self._pending is not None and self._uses > 0:
+        if self._error is not None or (self._pending is not None and self._uses > 0):
             self.resolve()
         self._uses += 1
         return self.has_hubs
@@ -302,11 +308,16 @@ def get_topology(edge_index: torch.Tensor, num_nodes: int, pos: Optional[torch.T
     given, reverse Cuthill-McKee otherwise)."""
     ren = None
     if renumber and want_renumbering(int(num_nodes)):
-        ren = "morton" if (pos is not None and pos.dim() == 2 and pos.shape[1] >= 2 and pos.shape[0] == num_nodes and pos.is_cuda) else "rcm"
+        has_pos = pos is not None and pos.dim() == 2 and pos.shape[1] >= 2 and pos.shape[0] == num_nodes and pos.is_cuda
+        # without device positions the only order available is reverse Cuthill-McKee ON THE HOST (a device-to-host copy of
+        # the edge list + ~1 s per million nodes, per new edge_index tensor): only on explicit request ("on"), never in "auto"
+        ren = "morton" if has_pos else ("rcm" if _renumber_mode == "on" else None)
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes), str(edge_index.device), ren,
            (pos.data_ptr(), pos._version) if ren == "morton" else None)
     hit = _topo_cache.get(key)
     if hit is not None and hit[0]() is edge_index:
+        if hit[1]._error is not None:   # a bad topology is not served from the cache: the caller sees the error again
+            raise hit[1]._error
         return hit[1]
     import weakref
 
@@ -713,7 +724,18 @@ def set_grad_ready_hook(fn) -> None:
 #: MGN_RECOMPUTE_FRACTION (0.5) of the free device memory.  The 1M-node / 6M-edge mesh needs ~270 GB of
 #: saves for 15 rounds: with recompute it trains on ONE MI355X (~50 GB), at the price of one extra
 #: training-mode forward per round inside the backward pass.
-_recompute_mode = _os.environ.get("MGN_RECOMPUTE", "auto")
+def _parse_recompute_env(v: str):
+    """MGN_RECOMPUTE: "off" | "on" | "auto" | a number of rounds; anything else is an error (a typo must not fall through
+    to the heuristic silently)"""
+    v = v.strip()
+    if v.isdigit():
+        return int(v)
+    if v not in ("off", "on", "auto"):
+        raise ValueError(f"MGN_RECOMPUTE={v!r}: expected 'off', 'on', 'auto' or a number of rounds")
+    return v
+
+
+_recompute_mode = _parse_recompute_env(_os.environ.get("MGN_RECOMPUTE", "auto"))
 
 
 def set_activation_recompute(mode) -> None:

@@ -210,8 +210,16 @@ def main():
     # index_put_(accumulate=True)), so the training goldens carry a tolerance.
     for (l0, g0, _), (l1, g1) in zip(logs, olog):
         assert abs(l0 - l1) <= 1e-5 * abs(l0) and abs(g0 - g1) <= 1e-5 * abs(g0), f"oracle train step differs: {(l0, g0)} vs {(l1, g1)}"
+    # Post-step weights: AdamW normalises every gradient element by its own magnitude, so where |g| is at the level of the
+    # CPU backward's run-to-run wobble (threaded index_put_) a weight moves by up to ~lr per step in EITHER direction -- an
+    # element-wise 1e-5 comparison is flaky under CPU contention.  Asserted instead: no element farther
+    # than the two steps can move it, and all but a 1e-4 fraction within rounding.
+    lr_sum = sum(l[2] for l in logs) + lr
     for k in sd:
-        assert torch.allclose(op[k].detach(), sd[k], rtol=1e-5, atol=2e-6), "post-step weights " + k
+        d = (op[k].detach() - sd[k]).abs()
+        assert float(d.max()) <= 2.5 * lr_sum, "post-step weights " + k
+        off = d > (2e-6 + 1e-5 * sd[k].abs())
+        assert float(off.float().mean()) <= 1e-4, f"post-step weights {k}: {int(off.sum())} of {off.numel()} elements off"
     save("train_2steps", edge_index=ei, loss=np.array([l[0] for l in logs]), grad_norm=np.array([l[1] for l in logs]),
          lr_after=np.array([l[2] for l in logs]),
          param_sum=np.array([sd[k].double().sum().item() for k in sd]),

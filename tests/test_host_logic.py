@@ -226,3 +226,35 @@ def test_rank_plan_with_positions_keeps_the_contract():
         kown = dict(zip(own_sorted.tolist(), P.morton_keys(pos.numpy()[own_sorted]).tolist()))
         kb = np.array([kown[i] for i in b.owned[:b.n_interior].tolist()], dtype=np.uint64)
         assert bool((kb[1:] >= kb[:-1]).all())
+
+
+def test_overlapped_grad_all_reduce_refuses_double_reports_and_ignores_foreign_parameters(monkeypatch):
+    """the bucket listener is process-global -- a parameter reported twice before the step's all-reduce must raise
+    (the bucketed value would silently replace an accumulated gradient), gradients of another model must be ignored, and a
+    lazily built topology that reported stray indices must raise on every use, also from the cache."""
+    from graph_physics_amd import distributed as D, ops
+
+    mine = [torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(3))]
+    other = torch.nn.Parameter(torch.zeros(5))
+    sync = D.OverlappedGradAllReduce(bucket_bytes=1 << 30, params=mine)
+    try:
+        monkeypatch.setattr(sync, "_active", lambda: True)
+        sync._on_ready([(mine[0], torch.ones(4)), (other, torch.ones(5))])
+        assert [ptr for ptr, _ in sync._cur] == [mine[0].data_ptr()]          # the foreign gradient never entered a bucket
+        sync._on_ready([(mine[1], torch.ones(3))])
+        with pytest.raises(RuntimeError, match="reported twice"):
+            sync._on_ready([(mine[0], torch.ones(4))])
+        sync.reset()                                                           # an aborted step: start clean
+        assert sync._cur == [] and sync._seen == set() and sync._inflight == []
+        sync._on_ready([(mine[0], torch.ones(4))])
+    finally:
+        sync.close()
+    assert ops._grad_ready_hook is None if hasattr(ops, "_grad_ready_hook") else True
+
+
+def test_recompute_env_is_validated():
+    from graph_physics_amd import ops
+
+    assert ops._parse_recompute_env("6") == 6 and ops._parse_recompute_env(" auto ") == "auto"
+    with pytest.raises(ValueError):
+        ops._parse_recompute_env("onn")
