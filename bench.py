@@ -163,6 +163,23 @@ def hbm_obj(kernel, t_ms, nbytes, traffic=None, extra=None):
     return d
 
 
+def step_floor(N, E, H, L, terms, ms_per_step):
+    """What the training step cannot go below on this part, priced both ways: the algorithmic bytes of the four
+    E-row kernel families of a round (edge update, edge backward chain, weight gradients, backward scatters -- DESIGN.md section 5;
+    node-row and encoder / decoder traffic not counted: a lower bound) at 8 TB/s and at the 6.3 TB/s a streaming kernel reaches, and
+    the matrix work (forward 12 E H^2 + 10 N H^2 per round, training = 3 x forward, `terms` bf16 MFMA terms per product) at 2.5 PFLOP/s."""
+    row = 4.0 * H
+    per_round = (row * (6 * E + 3 * N) + 60.0 * E) + (row * (7 * E + N) + 56.0 * E) + row * (8 * E + 12 * N) + (2 * row * (E + N) + 4.0 * E + 8.0 * (N + 1))
+    nbytes = L * per_round
+    flops = 3.0 * L * (12.0 * E + 10.0 * N) * H * H * terms
+    hbm_ms, hbm63_ms, mfma_ms = 1e3 * nbytes / (PEAK_HBM * 1e9), 1e3 * nbytes / 6.3e12, 1e3 * flops / (PEAK_MFMA_BF16 * 1e12)
+    floor = max(hbm_ms, mfma_ms)
+    return {"algorithmic_bytes_per_step": int(nbytes), "hbm_floor_ms": round(hbm_ms, 3), "hbm_floor_ms_at_6300_GBps": round(hbm63_ms, 3),
+            "mfma_flops_per_step_bf16_terms": int(flops), "mfma_floor_ms": round(mfma_ms, 3), "step_floor_ms": round(floor, 3),
+            "frac_of_floor": round(floor / ms_per_step, 4), "frac_of_floor_at_6300_GBps": round(max(hbm63_ms, mfma_ms) / ms_per_step, 4),
+            "what": "step_floor_ms / ms_per_step; bytes = the E-row kernels of the 15 rounds only (a lower bound of the step's traffic)"}
+
+
 def load_traffic(capi):
     """profiles/pmc_traffic.json (PMC passes, tools/pmc_traffic_summary.py) -- only when it was measured
     on THIS build of the kernels: the file records the hash of csrc/ it was taken with."""
@@ -371,6 +388,37 @@ def batch1_record(args, gp, ops, harness, dev):
             "launch": "hipGraph replay", "steps": k}
 
 
+def shipped_cylinder_record(args, gp, ops, harness, dev):
+    """training_config/cylinder.json AS SHIPPED (message_passing_num 5, hidden_size 32 -- what a user who drops the engine in unchanged
+    runs; BASELINE.md's caveat): batch of 16 meshes, training step and rollout step, eager.  Hidden 32 runs on the generic
+    exact-fp32 MFMA kernels (k_mlp_fwd / k_mlp_bwd / k_wgrad at HB = 2), not on the packed split-bf16 path (H = 128 only)."""
+    cfg = gp.cylinder_config(5, 32)
+    eng = harness.Engine(cfg, dev, learning_rate=1e-4, num_steps=10000, warmup=100)
+    b = gp.cylinder_batch(args.batch, args.nodes, 0).to(dev)
+    n, e = int(b.x.shape[0]), int(b.edge_index.shape[1])
+    b.mgn_topology = ops.Topology(b.edge_index, n)
+    for _ in range(10):
+        eng.train_step(b)
+    torch.cuda.synchronize()
+    k = 50
+    t0 = time.perf_counter()
+    for _ in range(k):
+        eng.train_step(b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    frames = [b] * 20
+    eng.rollout(frames[:3])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.rollout(frames)
+    torch.cuda.synchronize()
+    dr = (time.perf_counter() - t0) / len(frames)
+    return {"workload": f"training_config/cylinder.json as shipped: 5 MP rounds, latent 32, {args.batch} x {args.nodes}-node meshes per step (N={n}, E={e})",
+            "kernels": "generic exact-fp32 MFMA kernels (k_mlp_fwd<2,..> / k_mlp_bwd<2,..> / k_wgrad<2>, v_mfma_f32_16x16x4_f32); the packed split-bf16 path needs hidden 128",
+            "train_steps_per_s": round(1.0 / dt, 1), "train_ms_per_step": round(1e3 * dt, 3),
+            "rollout_ms_per_step": round(1e3 * dr, 3), "rollout_node_steps_per_s": round(n / dr, 1), "launch": "eager"}
+
+
 def plate_bf16_record(args, gp, ops, harness, dev):
     """BASELINE configs[2]: DeformingPlate-shaped meshes (~1.3k nodes, 3-D tetrahedra, world-edge set built on the device),
     the reference's bf16-mixed semantic (training.enable_vram_optimizations -> Lightning bf16-mixed, train.py:74-78):
@@ -522,13 +570,120 @@ def c5_record(args, gp, ops, harness, dev):
     return rec
 
 
+def broadcast_mesh(gp, P, n, world, rank, dev):
+    """rank 0: Delaunay mesh of n uniform points + the world-way node partition; every other rank receives pos, edge_index, edge_attr
+    and the partition vector by broadcast (device tensors over RCCL, host tensors over gloo).  Returns (graph, part, seconds on rank 0)."""
+    import numpy as np
+    import torch.distributed as dist
+
+    on_dev = dist.get_backend() == "nccl"
+    t0 = time.perf_counter()
+    if rank == 0:
+        g = gp.square_mesh(n, seed=0)
+        part = np.ascontiguousarray(P.partition_nodes(g.pos.numpy(), g.edge_index, world)).astype(np.int64)
+        hdr = torch.tensor([g.pos.shape[0], g.pos.shape[1], g.edge_index.shape[1], g.edge_attr.shape[1]], dtype=torch.int64)
+    else:
+        g, part, hdr = None, None, torch.zeros(4, dtype=torch.int64)
+    t_build = time.perf_counter() - t0
+
+    def bc(t):
+        if on_dev:
+            t = t.to(dev)
+        dist.broadcast(t, src=0)
+        return t.cpu()
+
+    hdr = bc(hdr)
+    npos, dpos, E, fe = (int(v) for v in hdr)
+    if rank == 0:
+        pos, ei, ea, pt = g.pos.contiguous(), g.edge_index.contiguous(), g.edge_attr.contiguous(), torch.from_numpy(part)
+    else:
+        pos = torch.empty(npos, dpos, dtype=torch.float32)
+        ei = torch.empty(2, E, dtype=torch.int64)
+        ea = torch.empty(E, fe, dtype=torch.float32)
+        pt = torch.empty(npos, dtype=torch.int64)
+    pos, ei, ea, pt = bc(pos.float()), bc(ei), bc(ea.float()), bc(pt)
+    if rank != 0:
+        g = gp.Graph(pos=pos, edge_index=ei, edge_attr=ea)
+    return g, pt.numpy(), t_build
+
+
+def c5_dp_record(args, gp, D, ops, harness, rank, world, dev):
+    """BASELINE configs[4] as the driver's N > 1 launch reaches it ("coarse-aneurysm Transformer, 4 x MI355X, bf16"): data-parallel
+    replicas of EncodeTransformDecode in the bf16 matrix mode, every rank its own 3-D mesh (weak scaling), parameters broadcast from
+    rank 0, gradients averaged by one flat all-reduce per step.  The reference has no multi-GPU form of its own (train.py:278,
+    devices = 1).  Every rank enters; rank 0's dict is reported."""
+    import numpy as np
+    import torch.distributed as dist
+    from scipy.spatial import Delaunay
+
+    from graph_physics_amd import preprocess as PP
+    from graph_physics_amd import transformer as T
+
+    n = args.c5_nodes
+    pts = np.random.default_rng(100 + rank).random((n, 3)).astype(np.float32)
+    cells = torch.from_numpy(Delaunay(pts).simplices.T.astype(np.int64)).to(dev)
+    ei = PP.faces_to_edges(cells, n)
+    E = int(ei.shape[1])
+    H, nh, L = 64, 4, 10
+    cfg = {"model": {"type": "transformer", "message_passing_num": L, "hidden_size": H, "node_input_size": 14, "output_size": 3,
+                     "edge_input_size": 0, "num_heads": nh, "use_rope_embeddings": False, "use_gated_attention": False},
+           "training": {"use_temporal_block": False}}
+    torch.manual_seed(0)
+    net = gp.get_model(cfg).to(dev)
+    D.broadcast_parameters(net)
+    graph = gp.Graph(x=torch.randn(n, 23, device=dev), edge_index=ei, pos=torch.from_numpy(pts).to(dev))
+    graph.mgn_attn_topology = T.get_attn_topology(ei, n)
+    tgt = torch.randn(n, 3, device=dev)
+    opt = harness.FusedClipAdamW(net.parameters(), 1e-4, max_norm=1.0)
+    sync = D.GradAllReduce()
+
+    def train():
+        loss = ((net(graph) - tgt) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        sync(net.parameters())
+        opt.step()
+
+    def timed(fn, k=3):
+        fn()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt) / k
+
+    prev = ops.get_matrix_precision()
+    try:
+        ops.set_matrix_precision("bf16")
+        tt = timed(train)
+        ta = timed(lambda: sync(net.parameters()))
+    finally:
+        ops.set_matrix_precision(prev)
+    return {"workload": f"{world} replicas, each a 3-D Delaunay tetrahedral mesh of N={n} (E={E} on rank 0), EncodeTransformDecode {L} blocks, hidden {H}, "
+                        f"{nh} heads (training_config/coarse-aneurysm.json:11-22), bf16 matrix mode; BASELINE.json configs[4]",
+            "parallelism": f"dp{world}: replicas, flat gradient all-reduce ({dist.get_backend()})", "dtype": "bf16 (matrix operands; fp32 accumulate)",
+            "train_ms_per_step": round(1e3 * tt, 2), "node_train_steps_per_s": round(world * n / tt, 1),
+            "allreduce_ms_per_step": round(1e3 * ta, 3), "scaling": "weak"}
+
+
 def c4_record(args, gp, D, ops, harness, rank, world, dev):
     """BASELINE configs[3]: synthetic Delaunay mesh (1M nodes / 6M directed edges), latent 128, 15 rounds."""
     from graph_physics_amd import partition as P
     import torch.distributed as dist
 
     n = args.c4_nodes
-    g = gp.square_mesh(n, seed=0)  # every rank builds the same mesh (seeded); nodes in GENERATOR order: no locality
+    part_shared = None
+    if world > 1:
+        # ONE rank triangulates and partitions; the others receive the arrays (no reliance on eight processes producing
+        # bit-identical scipy / numpy results, and 7/8 of the host time saved)
+        g, part_shared, t_build = broadcast_mesh(gp, P, n, world, rank, dev)
+    else:
+        g = gp.square_mesh(n, seed=0)  # nodes in GENERATOR order: no locality
     E = int(g.edge_index.shape[1])
     rec = {"workload": f"Delaunay mesh of {n} uniform points in the unit square, seed 0, numbered in generator order (no locality), "
                        f"E={E}, {args.rounds} MP rounds, latent {args.hidden}, fp32; BASELINE.json configs[3].  The ENGINE renumbers the "
@@ -560,7 +715,7 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
 
     def partitioned(nparts, prank, exchange):
         t0 = time.perf_counter()
-        part = P.partition_nodes(g.pos.numpy(), g.edge_index, nparts)
+        part = part_shared if (exchange and part_shared is not None) else P.partition_nodes(g.pos.numpy(), g.edge_index, nparts)
         plan = P.build_rank_plan(g.edge_index, part, prank, nparts, pos=g.pos.numpy())  # local numbering along a Morton curve
         t_part = time.perf_counter() - t0
         if not exchange:
@@ -587,15 +742,35 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
         t_train = timed(train_step, args.c4_steps)
         mem = torch.cuda.max_memory_allocated(dev) / 2**30
         t_inf = timed(infer_step, args.c4_steps)
-        return {"owned_nodes": plan.n_own, "ghost_rows": plan.n_ghost, "local_edges": int(plan.edge_ids.numel()),
-                "edge_cut": round(P.edge_cut(g.edge_index, part), 5), "partition_s": round(t_part, 2),
-                "train_ms_per_step": round(1e3 * t_train, 2), "rollout_ms_per_step": round(1e3 * t_inf, 2),
-                "peak_mem_gib": round(mem, 1)}
+        r = {"owned_nodes": plan.n_own, "ghost_rows": plan.n_ghost, "local_edges": int(plan.edge_ids.numel()),
+             "edge_cut": round(P.edge_cut(g.edge_index, part), 5), "partition_s": round(t_part, 2),
+             "train_ms_per_step": round(1e3 * t_train, 2), "rollout_ms_per_step": round(1e3 * t_inf, 2),
+             "peak_mem_gib": round(mem, 1)}
+        if exchange:
+            # the step's communication on its own (nothing to overlap with: an upper bound of what it costs inside the step):
+            # the 2 x rounds halo exchanges of a step, and the gradient all-reduce
+            halo = D.HaloState(plan, dev)
+            buf = torch.zeros(plan.n_own + plan.n_ghost, args.hidden, device=dev)
+            Ss = torch.zeros(plan.n_own + plan.n_ghost, args.hidden, device=dev)
+
+            def halo_step():
+                for _ in range(args.rounds):
+                    halo.finish_forward(halo.start_forward(buf))
+                for _ in range(args.rounds):
+                    halo.finish_backward(halo.start_backward(Ss), Ss)
+
+            r["halo_ms_per_step"] = round(1e3 * timed(halo_step, 3), 3)
+            r["halo_what"] = (f"{2 * args.rounds} neighbour exchanges (pack, all_to_all_single, unpack-add) run back to back, nothing overlapped; "
+                              f"{int(plan.send_idx.numel())} rows of {4 * args.hidden} B sent per exchange by this rank")
+            r["allreduce_ms_per_step"] = round(1e3 * timed(lambda: sync(net.parameters()), 3), 3)
+            r["allreduce_what"] = "flat all-reduce of every parameter gradient (11.5 MB), on its own"
+        return r
 
     if world > 1:
         D.broadcast_parameters(net)
         r = partitioned(world, rank, True)
         rec.update(r)
+        rec["mesh_build_and_partition_s_rank0"] = round(t_build, 2)
         rec["parallelism"] = f"{world}-way node partition (dst-owner edges), one-hop halo exchange of ghost latents per round " \
                              f"({dist.get_backend()}), gradient all-reduce"
         rec["node_train_steps_per_s"] = round(n / (r["train_ms_per_step"] * 1e-3), 1)
@@ -841,6 +1016,7 @@ def main():
                          "steps_per_s_rebuild_every_step": round(world * k_rb / dt_rb, 3),
                          "ms_per_step_rebuild_every_step": round(1e3 * dt_rb / k_rb, 3)},
         }
+        out["step_floor"] = step_floor(N, E, args.hidden, args.rounds, 1 if args.precision == "bf16" else 6, 1e3 * dt / args.steps)
         if not args.no_kernel_timing:
             device_copy_rate(dev)
             roof, roof_seg, others = kernel_rooflines(gp, ops, capi, eng, batch, dev)
@@ -855,6 +1031,12 @@ def main():
             out["batch1"] = batch1_record(args, gp, ops, harness, dev)
         except Exception as ex:  # noqa: BLE001  (an extra record must not cost the headline)
             out["batch1"] = {"error": f"{type(ex).__name__}: {ex}"}
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_kernel_timing and not args.no_extras and args.precision == "fp32":
+        try:
+            out["shipped_cylinder_json"] = shipped_cylinder_record(args, gp, ops, harness, dev)
+        except Exception as ex:  # noqa: BLE001
+            out["shipped_cylinder_json"] = {"error": f"{type(ex).__name__}: {ex}"}
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_kernel_timing and not args.no_extras and args.precision == "fp32":
         try:
@@ -892,7 +1074,11 @@ def main():
 
             wd = threading.Thread(target=watchdog, daemon=True)
             wd.start()
+        c5dp = None
         try:
+            if world > 1 and not args.no_extras and args.precision == "fp32":
+                c5dp = c5_dp_record(args, gp, D, ops, harness, rank, world, dev)
+                torch.cuda.empty_cache()
             c4 = c4_record(args, gp, D, ops, harness, rank, world, dev)
         except Exception as ex:  # noqa: BLE001  (the headline must survive a failure of the extra record)
             c4 = {"error": f"{type(ex).__name__}: {ex}"}
@@ -905,6 +1091,8 @@ def main():
             wd_done.set()
         if rank == 0:
             out["c4"] = c4
+            if c5dp is not None:
+                out["c5"] = c5dp
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, gp)

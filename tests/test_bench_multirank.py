@@ -28,7 +28,7 @@ def test_two_rank_bench_line():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--batch", "2", "--nodes", "400", "--rounds", "3", "--rollout-steps", "2", "--no-cpu-baseline",
-           "--c4-nodes", "30000", "--c4-steps", "2"]
+           "--c4-nodes", "30000", "--c4-steps", "2", "--c5-nodes", "4000"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -41,6 +41,12 @@ def test_two_rank_bench_line():
     c4 = d["c4"]
     assert "2-way node partition" in c4["parallelism"] and c4["ghost_rows"] > 0 and 0 < c4["owned_nodes"] < 30000
     assert c4["train_ms_per_step"] > 0 and c4["rollout_ms_per_step"] > 0 and c4["node_train_steps_per_s"] > 0
+    # one rank built the mesh and the partition, the other received them; the step's communication is timed on its own
+    assert c4["mesh_build_and_partition_s_rank0"] > 0 and c4["halo_ms_per_step"] > 0 and c4["allreduce_ms_per_step"] > 0
+    # configs[4] under the N > 1 launch: bf16 replicas of the Transformer
+    c5 = d["c5"]
+    assert c5["parallelism"].startswith("dp2") and c5["train_ms_per_step"] > 0 and "bf16" in c5["dtype"]
+    assert d["step_floor"]["step_floor_ms"] > 0 and 0 < d["step_floor"]["frac_of_floor"] < 1
 
 
 def test_gpus_flag_starts_its_own_ranks():
