@@ -256,6 +256,45 @@ def test_c4_gradients_at_full_size_via_closure(dev, recompute):
     print(f"C4 gradients (recompute {recompute}): worst parameter {worst:.2e}")
 
 
+def test_c4_relu_gradients_at_full_size_via_closure(dev):
+    """The DEFAULT activation at the 1M-node size (every shipped JSON is ReLU, the large-M gradient
+    checks ran SiLU networks): same closure construction, ReLU network, flip-aware bar -- a gradient either agrees with the
+    fp32 oracle to GRAD_TOL, or (a pre-activation within rounding of zero took the other branch) is as close to the fp64
+    oracle as the fp32 oracle itself is (x2)."""
+    g = _c4_mesh()
+    N, ei = g.x.shape[0], g.edge_index
+    L = 2
+    params = R.make_params(R.epd_param_shapes(L, 128, 11, 3, 2), 16)
+    x_in = torch.randn(N, 11, generator=torch.Generator().manual_seed(12))
+    seeds = np.concatenate([np.arange(0, 300), np.arange(N // 2, N // 2 + 300), np.arange(N - 300, N)])
+    cot = R.randn((seeds.size, 2), 18)
+    nodes, kept, loc, sub_ei = _closure(ei, N, seeds, L)
+
+    def oracle(dtype):
+        P = {k: v.clone().to(dtype).requires_grad_(True) for k, v in params.items()}
+        ref = O.epd_forward(x_in[nodes].to(dtype), g.edge_attr[torch.from_numpy(kept)].to(dtype), sub_ei, P, L)
+        (ref[loc[seeds]] * cot.to(dtype)).sum().backward()
+        return ref.detach(), P
+
+    ref32, P32 = oracle(torch.float32)
+    _, P64 = oracle(torch.float64)
+    net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=128).to(dev)   # ReLU (the default)
+    net.load_state_dict(params)
+    graph = gp.Graph(x=x_in.to(dev), edge_attr=g.edge_attr.to(dev), edge_index=ei.to(dev), pos=g.pos.to(dev))
+    out = net(graph)
+    (out[torch.from_numpy(seeds).to(dev)] * cot.to(dev)).sum().backward()
+    assert_close3(out.detach().cpu()[seeds], ref32[loc[seeds]], FWD_TOL, "forward on the seeds (ReLU)")
+    worst32, flipped = 0.0, []
+    for k, p in net.named_parameters():
+        e32 = rel_err(p.grad, P32[k].grad)
+        worst32 = max(worst32, e32)
+        if e32 >= GRAD_TOL:
+            h64, c64 = rel_err(p.grad, P64[k].grad), rel_err(P32[k].grad, P64[k].grad)
+            assert h64 < 2.0 * c64 + 1e-6, (k, e32, h64, c64)
+            flipped.append(k)
+    print(f"C4 ReLU gradients: worst parameter vs the fp32 oracle {worst32:.2e}; {len(flipped)} parameter(s) judged against fp64")
+
+
 # ------------------------------------------------------------------ noise with overlapping ranges
 def test_noise_overlapping_ranges_apply_one_after_the_other(dev):
     from graph_physics_amd import preprocess as PP
