@@ -33,20 +33,30 @@ class RMSNorm(nn.Module):
 
     def __init__(self, d: int, p: float = -1.0, eps: float = 1e-8, bias: bool = False):
         super().__init__()
-        if bias or (0.0 <= p <= 1.0):
-            raise NotImplementedError("partial / biased RMSNorm is not on the MeshGraphNet path")
-        if eps != ops.EPS:
-            raise NotImplementedError("the engine uses the reference default eps=1e-8")
         self.d, self.p, self.eps, self.bias = d, p, eps, bias
         self.scale = nn.Parameter(torch.ones(d))
+        if self.bias:
+            self.offset = nn.Parameter(torch.zeros(d))   # layers.py:100-101 (same state_dict key)
+
+    @property
+    def is_default(self) -> bool:
+        """the form build_mlp constructs (whole-row norm, no offset, eps 1e-8): the one the fused kernels implement"""
+        return (not self.bias) and not (0.0 <= self.p <= 1.0) and self.eps == ops.EPS
 
     def forward(self, x):
         ops._require_device(x)
-        if x.shape[-1] <= 384:   # engine kernel (csrc/mgn_dense.hip), forward and backward
+        if self.is_default and x.shape[-1] <= 384:   # engine kernel (csrc/mgn_dense.hip), forward and backward
             from .dense import rms_norm
             return rms_norm(x, self.scale)
-        rms = x.norm(2, dim=-1, keepdim=True) / (self.d ** 0.5)
-        return self.scale * (x / (rms + self.eps))
+        # partial (p in [0, 1]) / biased / non-default eps (layers.py:113-128): reachable only by constructing the module
+        # directly (build_mlp never does) -- the reference's formula with elementwise device ops (differentiable)
+        if 0.0 <= self.p <= 1.0:
+            k = int(self.d * self.p)
+            norm_x, d_x = x[..., :k].norm(2, dim=-1, keepdim=True), k
+        else:
+            norm_x, d_x = x.norm(2, dim=-1, keepdim=True), self.d
+        y = self.scale * (x / (norm_x / (d_x ** 0.5) + self.eps))
+        return y + self.offset if self.bias else y
 
 
 class ReLU(nn.Module):
@@ -87,6 +97,8 @@ class MLP(nn.Sequential):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lin = [m for m in self if isinstance(m, nn.Linear)]
         norm = self[len(self) - 1] if isinstance(self[len(self) - 1], RMSNorm) else None
+        if norm is not None and not norm.is_default:
+            raise NotImplementedError("a partial / biased RMSNorm at the end of an MLP is not fused: call the entries one by one")
         params = []
         for m in lin:
             params += [m.weight, m.bias]

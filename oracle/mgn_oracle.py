@@ -46,6 +46,20 @@ def rms_norm(x: torch.Tensor, scale: torch.Tensor, eps: float = 1e-8) -> torch.T
     return scale * x_normed  # layers.py:129
 
 
+def rms_norm_general(x: torch.Tensor, scale: torch.Tensor, d: int, p: float = -1.0, eps: float = 1e-8,
+                     offset: torch.Tensor = None) -> torch.Tensor:
+    """RMSNorm.forward with every constructor option (layers.py:104-129): p in [0, 1] norms the first int(d * p) columns only
+    (:113-121), bias adds ``offset`` (:126-127); eps outside the root (:123-124)."""
+    if p < 0.0 or p > 1.0:
+        norm_x, d_x = x.norm(2, dim=-1, keepdim=True), d
+    else:
+        k = int(d * p)
+        norm_x, d_x = x[..., :k].norm(2, dim=-1, keepdim=True), k
+    rms_x = norm_x / math.sqrt(d_x)
+    y = scale * (x / (rms_x + eps))
+    return y + offset if offset is not None else y
+
+
 # --------------------------------------------------------------------------- R2
 #: bf16-mixed evaluation (set by :func:`bf16_mixed`).  The reference trains with Lightning
 #: ``precision="bf16-mixed"`` when ``training.enable_vram_optimizations`` is set (train.py:74-78,

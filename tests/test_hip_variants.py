@@ -220,3 +220,26 @@ def test_build_mlp_gelu_vs_oracle(dev):
         if fin == hid:
             assert rel_err(xd.grad, xo.grad) < 1e-4
     assert isinstance(mlp[1], torch.nn.Module) and float((mlp[1](torch.tensor([1.0], device=dev)) - 0.8413447).abs()) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["partial", "biased", "partial_biased_eps"])
+def test_rmsnorm_constructor_variants_vs_reference_golden(dev, name):
+    """RMSNorm(d, p, eps, bias) built directly (layers.py:73-129; build_mlp only makes the default form): same state_dict keys
+    (`scale`, `offset`), forward and every gradient against the reference-minted fixture (missing 5)."""
+    from test_oracle_golden import rmsnorm_case
+
+    kw, scale, offset, x, cot, want = rmsnorm_case(name)
+    m = gp.layers.RMSNorm(kw["d"], p=kw["p"], eps=kw["eps"], bias=kw["bias"]).to(dev)
+    sd = {"scale": scale}
+    if kw["bias"]:
+        sd["offset"] = offset
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd)
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    (y * cot.to(dev)).sum().backward()
+    assert rel_err(y, want["y"]) < 2e-6 and rel_err(xd.grad, want["dx"]) < 1e-5 and rel_err(m.scale.grad, want["dscale"]) < 1e-5
+    if kw["bias"]:
+        assert rel_err(m.offset.grad, want["doffset"]) < 1e-5
+    with pytest.raises(NotImplementedError):   # not silently fused as the default norm
+        gp.layers.MLP(torch.nn.Linear(kw["d"], kw["d"]), gp.layers.ReLU(), torch.nn.Linear(kw["d"], kw["d"]), m).to(dev)(xd.detach())

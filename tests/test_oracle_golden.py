@@ -176,3 +176,29 @@ def test_block_variants_oracle_vs_golden(name):
             assert torch.allclose(gr, g[f"{name}.blk.g.{k}"], rtol=1e-5, atol=1e-6), k
         elif f"{name}.blk.g.{k}.norm" in g:
             assert abs(float(gr.norm()) - float(g[f"{name}.blk.g.{k}.norm"])) < 1e-5 * float(gr.norm()), k
+
+
+RMSNORM_CASES = {"partial": dict(d=64, p=0.25, eps=1e-8, bias=False), "biased": dict(d=48, p=-1.0, eps=1e-8, bias=True),
+                 "partial_biased_eps": dict(d=128, p=0.5, eps=1e-5, bias=True)}
+
+
+def rmsnorm_case(name):
+    """inputs of tests/golden/make_golden_rmsnorm.py (same numpy streams) + the reference's outputs"""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rmsnorm_variants.npz"))
+    kw = RMSNORM_CASES[name]
+    i = list(RMSNORM_CASES).index(name)
+    d = kw["d"]
+    return kw, R.randn((d,), 900 + i) * 0.3 + 1.0, R.randn((d,), 910 + i) * 0.2, R.randn((37, d), 920 + i), R.randn((37, d), 930 + i), \
+        {k.split(".", 1)[1]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(name + ".")}
+
+
+@pytest.mark.parametrize("name", list(RMSNORM_CASES))
+def test_rmsnorm_variants_oracle_vs_golden(name):
+    """partial / biased RMSNorm (layers.py:104-129): the oracle's restatement against the reference-minted fixture"""
+    kw, scale, offset, x, cot, want = rmsnorm_case(name)
+    xo, so = x.clone().requires_grad_(True), scale.clone().requires_grad_(True)
+    y = O.rms_norm_general(xo, so, kw["d"], kw["p"], kw["eps"], offset if kw["bias"] else None)
+    (y * cot).sum().backward()
+    assert torch.equal(y.detach(), want["y"])
+    assert torch.allclose(xo.grad, want["dx"], rtol=1e-6, atol=1e-7) and torch.allclose(so.grad, want["dscale"], rtol=1e-6, atol=1e-6)
