@@ -260,9 +260,29 @@ __device__ __forceinline__ float act_f(float z, int act) {
 __device__ __forceinline__ float dact_f(float z, int act) { return act == MGN_ACT_GELU ? dgelu_f(z) : dsilu_f(z); }
 
 // ========================================================================= forward
+// bf16 matrix mode of the GENERIC kernels [r4] (any supported width; precision == 1 as in the packed kernels): every Linear
+// takes operands rounded to bf16 and returns a bf16 value, fp32 accumulation in between -- on the exact-fp32 MFMA, whose products
+// of bf16-representable operands are exact (the semantic of the reference under Lightning bf16-mixed, train.py:74-78,268-293).
+// The caller hands over weights and biases already rounded; the kernels round the row operands and each layer's result.
+__device__ __forceinline__ float bf16_round(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const unsigned r = u + 0x7fffu + ((u >> 16) & 1u);   // round to nearest even (finite values)
+  return __builtin_bit_cast(float, ((u & 0x7f800000u) == 0x7f800000u ? u : r) & 0xffff0000u);
+}
+template <int HB, int MT>
+__device__ __forceinline__ void round_tl(f32x4 (&v)[MT][HB]) {
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[t][ib][r] = bf16_round(v[t][ib][r]);
+}
+
 template <int HB, int MT, bool RAGGED>
 __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_mlp_fwd_args a) {
   constexpr int H = 16 * HB;
+  const bool bf = a.precision == 1;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   const long row0 = ((long)blockIdx.x * 4 + wv) * (16 * MT);
@@ -296,6 +316,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_ml
   if (RAGGED && !full0) {  // ragged layer 0 (encoders: 11 / 3 input features): guarded generic path
     for (int pp = 0; pp < a.nphase; ++pp) {
       if (pp > 0) load_tl<HB, MT, RAGGED>(in, a.src[pp], a.idx[pp], a.kw[pp], mm, g, nkb);
+      if (bf) round_tl<HB, MT>(in);
       gemm_tl<HB, MT>(acc, in, a.W[0] + koff, ktot, nib0, nkb, c, g);
       koff += 16 * nkb;
     }
@@ -309,6 +330,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_ml
 #pragma unroll
     for (int t = 0; t < MT; ++t) nx[t] = dummy[t];
     if (layer_open) {  // layer 0, phase p; prefetch the gathered rows of phase p+1
+      if (bf) round_tl<HB, MT>(in);   // (the rows of this phase: loaded above or by the previous call's prefetch)
       Wp = a.W[0] + koff;
       ldw = ktot;
       if (p + 1 < a.nphase) {
@@ -318,6 +340,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_ml
         for (int t = 0; t < MT; ++t) nx[t] = sp + (ip ? (long)ip[mm[t]] : mm[t]) * H + 4 * g;
       }
     } else {  // layer l >= 1: the accumulator IS the next B operand
+      if (bf) round_tl<HB, MT>(acc);   // the previous Linear returns bf16
       if (act_smooth(a.act) && a.saveZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.saveZ[l - 1], acc, H, mm, valid, g);
 #pragma unroll
       for (int t = 0; t < MT; ++t)
@@ -325,6 +348,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_ml
         for (int ib = 0; ib < HB; ++ib)
 #pragma unroll
           for (int r = 0; r < 4; ++r) in[t][ib][r] = act_f(acc[t][ib][r], a.act);
+      if (bf && act_smooth(a.act)) round_tl<HB, MT>(in);   // a smooth activation of a bf16 tensor is bf16 again (ReLU: exact)
       if (a.saveH[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.saveH[l - 1], in, H, mm, valid, g);
       const int nib = (l == a.NL - 1) ? nib_last : HB;
       init_bias<HB, MT>(acc, a.b[l], nib, g);
@@ -346,6 +370,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_fwd(const mgn_ml
     }
   }
   // ---- epilogue: RMSNorm (reference epsilon placement), residual, stores
+  if (bf) round_tl<HB, MT>(acc);   // the last Linear's bf16 result (norm, residual in fp32)
   if (a.scale != nullptr) {
     const float sqrt_d = sqrtf((float)H);
 #pragma unroll
@@ -494,6 +519,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
       }
       if (a.dscale != nullptr) colsum_to_lds<HB, MT>(lds_w + a.NL * H, du, c, g);
     }
+    if (a.precision == 1) round_tl<HB, MT>(dz);   // the gradient of a bf16 Linear output is bf16 (see k_mlp_fwd)
     if (a.dZ[a.NL - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.dZ[a.NL - 1], dz, 16 * nkb_last, mm, valid, g);
     if (a.db[a.NL - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (a.NL - 1) * H, dz, c, g);
     // ---- dgrad chain with ReLU masks from the saved activations, then the requested
@@ -514,6 +540,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
           for (int r = 0; r < 4; ++r)
             dz[t][ib][r] = !valid[t] ? 0.f : act_smooth(a.act) ? acc[t][ib][r] * dact_f(dz[t][ib][r], a.act)
                                                                        : (dz[t][ib][r] > 0.f ? acc[t][ib][r] : 0.f);
+      if (a.precision == 1) round_tl<HB, MT>(dz);
       if (a.dZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.dZ[l - 1], dz, H, mm, valid, g);
       if (a.db[l - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
       --l;
@@ -565,6 +592,7 @@ __global__ void __launch_bounds__(256, (MT >= 4) ? 1 : 2) k_mlp_bwd(const mgn_ml
             for (int r = 0; r < 4; ++r)
               dz[t][ib][r] = !valid[t] ? 0.f : act_smooth(a.act) ? acc[t][ib][r] * dact_f(dz[t][ib][r], a.act)
                                                                          : (dz[t][ib][r] > 0.f ? acc[t][ib][r] : 0.f);
+        if (a.precision == 1) round_tl<HB, MT>(dz);
         if (a.dZ[l - 1] != nullptr) store_tl<HB, MT, RAGGED>(a.dZ[l - 1], dz, H, mm, valid, g);
         if (a.db[l - 1] != nullptr) colsum_to_lds<HB, MT>(lds_w + (l - 1) * H, dz, c, g);
         --l;
@@ -2460,8 +2488,8 @@ int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream) {
     return fail(1, "mgn_mlp_fwd: GELU runs on the generic kernels only (no packed weights / gathers / post-products)");
   if (a.act == MGN_ACT_SILU && plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && !fwd_x6(a) && a.NL > 1)
     return fail(1, "mgn_mlp_fwd: SiLU is not available on the exact-fp32 LDS generation (pass packed weights)");
-  if (a.precision == 1 && !(plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && fwd_x6(a)))
-    return fail(1, "mgn_mlp_fwd: bf16 matrix mode needs the packed split-bf16 path (H = 128, full widths, wpk)");
+  if (a.precision == 1 && plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && !fwd_x6(a))
+    return fail(1, "mgn_mlp_fwd: at H = 128 with full widths the bf16 matrix mode needs the packed split-bf16 path (wpk); other shapes run it on the generic kernels");
   if (a.nphase < 1 || a.nphase > MGN_MAX_PHASES) return fail(1, "mgn_mlp_fwd: nphase out of range");
   for (int p = 0; p < a.nphase; ++p)
     if (a.kw[p] < 1 || a.kw[p] > a.H) return fail(1, "mgn_mlp_fwd: phase width out of range");
@@ -2508,8 +2536,8 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   }
   if (a.n_front != 0 && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
     return fail(1, "mgn_mlp_bwd: the front stage needs the packed split-bf16 path (H = 128, full widths, wpk, Ms, no dOut2)");
-  if (a.precision == 1 && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
-    return fail(1, "mgn_mlp_bwd: bf16 matrix mode needs the packed split-bf16 path (H = 128, full widths, wpk, Ms)");
+  if (a.precision == 1 && plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && !bwd_x6(a))
+    return fail(1, "mgn_mlp_bwd: at H = 128 with full widths the bf16 matrix mode needs the packed split-bf16 path (wpk, Ms); other shapes run it on the generic kernels");
   if (a.seg_out != nullptr && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
     return fail(1, "mgn_mlp_bwd: the fused segment sum of dZ[0] needs the packed split-bf16 path (fp32-grade, ReLU, dZ[0], no front stage)");
   if (a.M == 0) return 0;

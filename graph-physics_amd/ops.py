@@ -817,6 +817,13 @@ class MlpFunction(torch.autograd.Function):
             bl = torch.nn.functional.pad(bl, (0, op - out_w))
         Wk = [W0] + Ws[1:-1] + [Wl]
         bk = bs[:-1] + [bl]
+        # bf16 matrix mode on the generic kernels (widths off the packed path, e.g. hidden 32): operands rounded here (weights,
+        # biases) and in the kernel (rows, layer results) -- precision = 1, see mgn_hip.h.  The packed H = 128 modes of this
+        # function stay fp32-grade (encoders / decoder: ~4 % of the step's matrix work).
+        prec = 1 if (_matrix_precision == "bf16" and not (H == 128 and out_w == H and X6_ENABLED and act != 2)) else 0
+        if prec:
+            Wk = [w.to(torch.bfloat16).to(torch.float32) for w in Wk]
+            bk = [b.to(torch.bfloat16).to(torch.float32) for b in bk]
         need = any(ctx.needs_input_grad) and _saving()
         f = dict(dtype=torch.float32, device=dev)
         y = torch.empty(M, out_w, **f)
@@ -849,8 +856,9 @@ class MlpFunction(torch.autograd.Function):
             wpack([(Wk[l].data_ptr(), H, False, units[l]) for l in range(NL)], dev)
             mlp_fwd(M, H, [(x, None, H)], Wk, bk, scale, out_w, None, y, None, saveH, U, R, wpk=units, saveM=Ms, saveZ=Zs, act=act)
         else:
-            mlp_fwd(M, H, [(x, None, kin)], Wk, bk, scale, out_w, None, y, None, saveH, U, R, act=act, saveZ=Zs)
+            mlp_fwd(M, H, [(x, None, kin)], Wk, bk, scale, out_w, None, y, None, saveH, U, R, act=act, saveZ=Zs, precision=prec)
         ctx.meta = (NL, H, kin, out_w, has_norm, kp != kin, op != out_w, act, mode)
+        ctx.prec, ctx.Wk_rounded = prec, (Wk if prec else None)
         # inputs / parameters through save_for_backward (autograd's version counter then catches an
         # in-place update between forward and backward); padded weight copies and the activations
         # the kernels wrote are ours and live until the graph is freed
@@ -869,6 +877,9 @@ class MlpFunction(torch.autograd.Function):
         x, Ws = t[0], list(t[1:1 + NL])
         scale = t[1 + NL] if has_norm else None
         Wk = [ctx.pads[0] if pad0 else Ws[0]] + Ws[1:-1] + [ctx.pads[1] if padl else Ws[-1]]
+        prec = getattr(ctx, "prec", 0)
+        if prec:
+            Wk = ctx.Wk_rounded
         saveH, U, R, Ms, Zs = ctx.saved_acts
         dy = _f32c(dy)
         M, dev = x.shape[0], x.device
@@ -899,7 +910,7 @@ class MlpFunction(torch.autograd.Function):
             WT = [None] + [Wk[l].t().contiguous() for l in range(1, NL)]
             din = [(Wk[0].t().contiguous(), None, dx)] if want_dx else []
             # bias gradients are a by-product of the weight-gradient kernel (it reads dZ anyway)
-            mlp_bwd(M, H, NL, dy, None, None, out_w, U, R, scale, saveH, WT, dZ, din, [None] * NL, dscale, act=act, Zs=Zs)
+            mlp_bwd(M, H, NL, dy, None, None, out_w, U, R, scale, saveH, WT, dZ, din, [None] * NL, dscale, act=act, Zs=Zs, precision=prec)
         ins = [x] + list(saveH)
         in_w = [kin] + [H] * (NL - 1)
         dWs = [mk(widths[l], pad16(in_w[l]), **f) for l in range(NL)]
@@ -991,8 +1002,13 @@ class ProcessorFunction(torch.autograd.Function):
         split = (H == 128) and NL <= 4 and not spec.rope and (x6 or act == 0) and L > 0 and E > 0
         prec = 1 if _matrix_precision == "bf16" else 0
         if prec and not x6 and L > 0 and E > 0:
-            raise NotImplementedError("bf16 matrix mode needs hidden_size=128 (the packed split-bf16 kernels)")
-        prec = prec if x6 else 0
+            # [r4] bf16 matrix mode off the packed path (any supported width, e.g. the shipped cylinder.json's hidden 32): the
+            # generic kernels round the row operands and every layer's result to bf16 (precision = 1); the weights and biases of
+            # the Linear layers go in rounded (the RMSNorm scales, gate positions stay fp32: autocast does not touch them)
+            k_ = spec.mlp_params
+            for i_ in range(L):
+                for j_ in list(range(2 * NL)) + list(range(k_, k_ + 2 * NL)) + ([2 * k_, 2 * k_ + 1] if spec.gate else []):
+                    P[i_ * PB + j_] = P[i_ * PB + j_].to(torch.bfloat16).to(torch.float32)
         if halo is not None and not (x6 and split):
             raise NotImplementedError("the partitioned path runs on the packed H = 128 kernels (no RoPE)")
         # (the fused aggregation's second stage walks a node's tile partials serially: hub topologies take the
@@ -1092,7 +1108,8 @@ class ProcessorFunction(torch.autograd.Function):
                             wpk=[unit(i, u) for u in range(ne)] if x6 else (), **common)
                 else:
                     mlp_fwd(M, H, [(e[sl], None, H), (x, topo.dst_s[sl], H), (x, topo.src_s[sl], H)], We, be, se, H, e[sl], e_new[sl], y,
-                            sv(He), Ue[sl] if Ue is not None else None, Re[sl] if Re is not None else None, act=act, saveZ=sv(Ze))
+                            sv(He), Ue[sl] if Ue is not None else None, Re[sl] if Re is not None else None, act=act, saveZ=sv(Ze),
+                            precision=prec)
                 if fuse_agg:
                     n0, n1 = part_rows
                     seg_fix(rowptr[n0:n1 + 1], seg[3], agg[n0:n1])   # the kernel summed inside its wave tiles

@@ -146,7 +146,9 @@ typedef struct {
   /* matrix precision of the packed path: 0 = fp32-grade (bf16x3 operands, 6 product terms);
    * 1 = bf16 (operands rounded to bf16, ONE term, fp32 accumulate; biases, RMSNorm, residuals
    * and every stored tensor stay fp32) -- the semantic of the reference under bf16-mixed
-   * autocast (train.py:74-78,268-293), BASELINE configs[2]. */
+   * autocast (train.py:74-78,268-293), BASELINE configs[2].  [r4] Off the packed path (H != 128, ragged widths: the generic
+   * kernels) precision = 1 rounds the row operands and every layer's result to bf16 in the kernel; the caller passes W[] / b[]
+   * already rounded (mgn_mlp_bwd: WT[] / WT0[] likewise, and every dZ it writes is a bf16 value). */
   int precision;
   /* out = act(z) instead of z (generic ragged-input kernel only; no norm / residual): lets an
    * encoder run its narrow first layer stand-alone and the three full layers on the packed path
