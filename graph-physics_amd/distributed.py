@@ -303,10 +303,12 @@ class HipBackend:
     def order_edges(self, edge_attr, ctx):
         return edge_attr[ctx.perm_dst.long()]
 
-    def block(self, block, x, e, ctx):
+    def block(self, block, x, e, ctx, pos=None, phi=None):
         from . import ops
         from .layers import _block_params
-        return ops.processor_apply(x, e, ctx, 1, *_block_params(block), spec=block.spec)
+        return ops.processor_apply(x, e, ctx, 1, *_block_params(block), spec=block.spec,
+                                   pos=pos if block.use_rope else None, phi=phi if block.use_gate else None,
+                                   rope_inv_freq=block._rope_inv_freq if block.use_rope else None)
 
 
 class PartitionedEPD(torch.nn.Module):
@@ -323,20 +325,31 @@ class PartitionedEPD(torch.nn.Module):
         self.backend = backend if backend is not None else HipBackend()
         self._ctx = None
         self._halo = None
+        self._pos_full = None   # [n_own + n_ghost, D]: owned positions + the ghosts' (exchanged once per plan)
         # what the un-partitioned forward would apply and this path does not: refuse instead of silently
-        # computing another function (processors.py:203-209 temporal block; layers.py:1020-1026 RoPE needs the
-        # positions of ghost nodes)
+        # computing another function (processors.py:203-209: the temporal block attends over ALL nodes' previous latents)
         if getattr(model, "use_temporal_block", False) or getattr(model, "temporal_block", None) is not None:
             raise NotImplementedError("PartitionedEPD: use_temporal_block is not supported on a partitioned mesh")
-        if getattr(model, "use_rope", False):
-            raise NotImplementedError("PartitionedEPD: use_rope_embeddings is not supported on a partitioned mesh")
 
-    def forward(self, x_in_own: torch.Tensor, edge_attr_loc: torch.Tensor, phi_own: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``phi_own``: the owned rows of ``graph.phi`` (only read by blocks with the sigmoid gate, layers.py:1091-1098)."""
+    def forward(self, x_in_own: torch.Tensor, edge_attr_loc: torch.Tensor, phi_own: Optional[torch.Tensor] = None,
+                pos_own: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``phi_own``: the owned rows of ``graph.phi`` (only read by blocks with the sigmoid gate, layers.py:1091-1098).
+        ``pos_own``: the owned rows of ``graph.pos`` -- required with ``use_rope_embeddings`` (layers.py:1020-1026 rotates
+        x_src by pos[src] - pos[dst]: a rank needs the positions of its ghost sources; they travel ONCE per plan, by the same
+        neighbour exchange as the latents, and are kept)."""
         plan, be, m = self.plan, self.backend, self.model
         dev = x_in_own.device
         if phi_own is not None and phi_own.reshape(-1).shape[0] != plan.n_own:
             raise ValueError("phi_own must hold one value per owned node")
+        use_rope = bool(getattr(m, "use_rope", False))
+        if use_rope:
+            if pos_own is None:
+                raise ValueError("Graph data must contain `pos` when use_rope_embeddings=True.")   # processors.py:188-191
+            if pos_own.shape[0] != plan.n_own:
+                raise ValueError("pos_own must hold one row per owned node")
+            if self._pos_full is None or self._pos_full.device != dev:
+                p_own = pos_own.detach().to(dev, torch.float32).contiguous()
+                self._pos_full = torch.cat([p_own, HaloExchange.apply(p_own, plan, self.group)], dim=0)
         if self._ctx is None:
             self._ctx = be.prepare(plan.edge_index.to(dev), plan.n_own + plan.n_ghost)
         x_own = be.mlp(m.nodes_encoder, x_in_own)
@@ -354,12 +367,17 @@ class PartitionedEPD(torch.nn.Module):
             x_own, _ = ops.processor_apply(x_own, e, self._ctx, len(blocks), *params, spec=blocks[0].spec, halo=self._halo,
                                            phi=phi_own)
         else:
+            # per-block path (RoPE, gated-MLP blocks, widths off the packed kernels): the ghost LATENTS are exchanged before
+            # every block (HaloExchange: differentiable, fixed-order backward), the block runs on owned + ghost rows and the
+            # ghost rows of its output -- nodes without their in-edges here -- are dropped.  phi: the gate reads it per
+            # node, so the ghosts' values never matter (zeros).
+            phi_full = None
             if phi_own is not None:
-                raise NotImplementedError("PartitionedEPD: graph.phi is only supported on the fused H = 128 path")
+                phi_full = torch.cat([phi_own.reshape(-1).to(dev, torch.float32), torch.zeros(plan.n_ghost, device=dev)])
             for blk in blocks:
                 x_gh = HaloExchange.apply(x_own, plan, self.group)
                 x_full = torch.cat([x_own, x_gh], dim=0)
-                x_full, e = be.block(blk, x_full, e, self._ctx)
+                x_full, e = be.block(blk, x_full, e, self._ctx, pos=self._pos_full if use_rope else None, phi=phi_full)
                 x_own = x_full[: plan.n_own]
         return be.mlp(m.decode_module, x_own)
 

@@ -33,8 +33,9 @@ class OracleBackend:
     def order_edges(self, edge_attr, ctx):
         return edge_attr
 
-    def block(self, block, x, e, ctx):
-        return O.graph_net_block(x, e, ctx, self._sd(block), "")
+    def block(self, block, x, e, ctx, pos=None, phi=None):
+        variant = {"use_rope": block.use_rope, "rope_axes": block.rope_axes, "rope_base": block.rope_base, "use_gate": block.use_gate}
+        return O.graph_net_block(x, e, ctx, self._sd(block), "", variant=variant, pos=pos, phi=phi)
 
 
 def _free_port():
@@ -101,6 +102,79 @@ def test_partitioned_forward_backward_equals_unpartitioned(world):
     for rank, owned, out, loss, grads in res:
         full[torch.from_numpy(owned)] = torch.from_numpy(out)
         total += loss  # each rank holds its share of the global masked mean
+        for k, g in grads.items():
+            assert torch.allclose(torch.from_numpy(g), params[k].grad, rtol=2e-4, atol=1e-6), (rank, k)
+    assert abs(total - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
+    assert torch.allclose(full, ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+ROPE_VARIANT = {"use_gate": True, "use_rope": True, "rope_axes": 2, "rope_base": 100.0}
+
+
+def _worker_partition_rope(rank, world, port, q):
+    """RoPE + sigmoid gate with graph.phi on a partitioned mesh: the ghost sources' POSITIONS travel once
+    per plan, the ghost latents before every block (per-block path of PartitionedEPD)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import graph_physics_amd as gp
+    from graph_physics_amd import distributed as D
+    from graph_physics_amd import partition as P
+
+    L, H, N, seed = 2, 32, 140, 15
+    pos, ei, ea = R.delaunay_graph(N, seed)
+    net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H, use_rope_embeddings=True, rope_pos_dimension=2, rope_base=100.0,
+                                 use_gated_attention=True)
+    net.load_state_dict(R.variant_params(net.state_dict(), seed))
+    x_in, e_in = R.randn((N, 11), 11), R.randn((ei.shape[1], 3), 12)
+    phi = R.randn((N,), 14)
+    tgt = R.randn((N, 2), 13)
+    nt = torch.zeros(N)
+    part = P.partition_nodes(pos.numpy(), ei, world)
+    plan = P.build_rank_plan(ei, part, rank, world)
+    pm = D.PartitionedEPD(net, plan, backend=OracleBackend())
+    with pytest.raises(ValueError, match="pos"):   # the reference's error when graph.pos is missing (processors.py:188-191)
+        pm(x_in[plan.owned], e_in[plan.edge_ids], phi_own=phi[plan.owned])
+    out = pm(x_in[plan.owned], e_in[plan.edge_ids], phi_own=phi[plan.owned], pos_own=pos[plan.owned])
+    assert pm._pos_full.shape[0] == plan.n_own + plan.n_ghost and torch.equal(pm._pos_full[plan.n_own:], pos[plan.ghost].float())
+    loss = D.partitioned_loss(out, tgt[plan.owned], nt[plan.owned])
+    loss.backward()
+    D.GradAllReduce(average=False)(net.parameters())
+    grads = {k: v.grad.numpy().copy() for k, v in net.named_parameters()}
+    q.put((rank, plan.owned.numpy().copy(), out.detach().numpy().copy(), float(loss.detach()), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partitioned_rope_and_gate_phi_equal_unpartitioned_world4():
+    world = 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_partition_rope, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import graph_physics_amd as gp
+
+    L, H, N, seed = 2, 32, 140, 15
+    pos, ei, ea = R.delaunay_graph(N, seed)
+    net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H, use_rope_embeddings=True, rope_pos_dimension=2, rope_base=100.0,
+                                 use_gated_attention=True)
+    params = {k: v.clone().requires_grad_(True) for k, v in R.variant_params(net.state_dict(), seed).items()}
+    x_in, e_in = R.randn((N, 11), 11), R.randn((ei.shape[1], 3), 12)
+    phi, tgt, nt = R.randn((N,), 14), R.randn((N, 2), 13), torch.zeros(N)
+    ref = O.epd_forward(x_in, e_in, ei, params, L, variant=ROPE_VARIANT, pos=pos, phi=phi)
+    ref_loss = O.l2_loss(ref, tgt, nt)
+    ref_loss.backward()
+    full = torch.zeros_like(ref)
+    total = 0.0
+    for rank, owned, out, loss, grads in res:
+        full[torch.from_numpy(owned)] = torch.from_numpy(out)
+        total += loss
         for k, g in grads.items():
             assert torch.allclose(torch.from_numpy(g), params[k].grad, rtol=2e-4, atol=1e-6), (rank, k)
     assert abs(total - float(ref_loss)) < 1e-5 * abs(float(ref_loss))

@@ -169,8 +169,8 @@ def test_bench_refuses_a_gpus_flag_that_contradicts_the_launch():
 
 # ---------------------------------------------------------------- round 3: host logic of the new options
 def test_partitioned_model_refuses_what_it_would_silently_drop():
-    """PartitionedEPD applies neither the temporal block nor RoPE: a model that has them must not construct
-    (the un-partitioned forward would compute another function)."""
+    """PartitionedEPD does not apply the temporal block: a model that has it must not construct (the un-partitioned forward would
+    compute another function); RoPE constructs [r4] and asks for the owned positions like the reference asks for graph.pos."""
     from graph_physics_amd import distributed as D
     from graph_physics_amd import partition as P
 
@@ -178,8 +178,7 @@ def test_partitioned_model_refuses_what_it_would_silently_drop():
     plan = P.build_rank_plan(ei, P.partition_nodes(pos.numpy(), ei, 2), 0, 2)
     with pytest.raises(NotImplementedError, match="temporal"):
         D.PartitionedEPD(gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_temporal_block=True), plan)
-    with pytest.raises(NotImplementedError, match="rope"):
-        D.PartitionedEPD(gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_rope_embeddings=True, rope_pos_dimension=2), plan)
+    D.PartitionedEPD(gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_rope_embeddings=True, rope_pos_dimension=2), plan)
     pm = D.PartitionedEPD(gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_gated_attention=True), plan)
     with pytest.raises(ValueError, match="phi_own"):
         pm(torch.zeros(plan.n_own, 11), torch.zeros(plan.edge_ids.numel(), 3), phi_own=torch.zeros(plan.n_own + 1))
