@@ -144,6 +144,86 @@ def test_partitioned_hip_ranks_equal_unpartitioned_oracle(world):
         assert max(peers.values()) >= 3                   # a rank with three or more peers
 
 
+ROPE_VARIANT = {"use_gate": True, "use_rope": True, "rope_axes": 2, "rope_base": 100.0}
+
+
+def _rope_net(gp, act_silu=True):
+    from graph_physics_amd import layers
+    layers.set_use_silu_activation(act_silu)
+    try:
+        net = gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=H, use_rope_embeddings=True, rope_pos_dimension=2, rope_base=100.0,
+                                     use_gated_attention=True)
+    finally:
+        layers.set_use_silu_activation(False)
+    return net
+
+
+def _worker_rope(rank, world, port, q):
+    """RoPE + sigmoid gate (graph.phi) on the partitioned mesh with the HIP engine's per-block path: ghost positions exchanged once,
+    ghost latents before every block"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import graph_physics_amd as gp
+    from graph_physics_amd import distributed as D
+    from graph_physics_amd import partition as P
+
+    dev = torch.device("cuda:0")
+    pos, ei, part = _case(world)
+    N = pos.shape[0]
+    net = _rope_net(gp)
+    net.load_state_dict(R.variant_params(net.state_dict(), SEED + 20))
+    net = net.to(dev)
+    x_in, e_in, tgt, nt = _inputs(N, ei.shape[1])
+    phi = R.randn((N,), 44)
+    plan = P.build_rank_plan(ei, part, rank, world, pos=pos.numpy())
+    pm = D.PartitionedEPD(net, plan)
+    out = pm(x_in[plan.owned].to(dev), e_in[plan.edge_ids].to(dev), phi_own=phi[plan.owned].to(dev), pos_own=pos[plan.owned].to(dev))
+    assert pm._halo is None   # the per-block path, not the fused processor node
+    loss = D.partitioned_loss(out, tgt[plan.owned].to(dev), nt[plan.owned].to(dev))
+    loss.backward()
+    D.GradAllReduce(average=False)(net.parameters())
+    grads = {k: v.grad.cpu().numpy().copy() for k, v in net.named_parameters()}
+    q.put((rank, plan.owned.numpy().copy(), out.detach().cpu().numpy().copy(), float(loss.detach()), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partitioned_rope_gate_phi_hip_world4_equals_unpartitioned_oracle():
+    world = 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_rope, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    import graph_physics_amd as gp
+
+    pos, ei, part = _case(world)
+    N = pos.shape[0]
+    net = _rope_net(gp)
+    params = {k: v.clone().requires_grad_(True) for k, v in R.variant_params(net.state_dict(), SEED + 20).items()}
+    x_in, e_in, tgt, nt = _inputs(N, ei.shape[1])
+    phi = R.randn((N,), 44)
+    ref = O.epd_forward(x_in, e_in, ei, params, 2, act="silu", variant=ROPE_VARIANT, pos=pos, phi=phi)
+    ref_loss = O.l2_loss(ref, tgt, nt)
+    ref_loss.backward()
+    full = torch.zeros_like(ref)
+    total = 0.0
+    for rank, owned, out, loss, grads in res:
+        full[torch.from_numpy(owned)] = torch.from_numpy(out)
+        total += loss
+        for k, g in grads.items():
+            gref = params[k].grad
+            err = float((torch.from_numpy(g) - gref).abs().max() / gref.abs().max().clamp_min(1e-30))
+            assert err < 3e-4, (rank, k, err)
+    assert abs(total - float(ref_loss.detach())) < 1e-5 * abs(float(ref_loss.detach()))
+    assert float((full - ref.detach()).abs().max() / ref.detach().abs().max()) < 1e-5
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
