@@ -22,7 +22,11 @@
 #include "mgn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_d __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_d __attribute__((ext_vector_type(8)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MFMA_BF16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_d, (a)), __builtin_bit_cast(bf16x8_d, (b)), (c), 0, 0, 0)
 
 static thread_local char g_derr[256] = "";
 extern "C" const char* mgn_dense_last_error(void) { return g_derr; }
@@ -47,6 +51,17 @@ __device__ __forceinline__ void bf16r2(float a, float b, float& ra, float& rb) {
   const unsigned q = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_d));
   ra = __uint_as_float(q << 16);
   rb = __uint_as_float(q & 0xffff0000u);
+}
+// two T-layout blocks (features 16 kb + 4g + r and 16 (kb + 1) + 4g + r of a row / of a weight row) -> the 8 bf16 of one
+// K = 32 MFMA operand; A (weights) and B (rows) use the same element order, so the contraction pairs feature with feature
+__device__ __forceinline__ u32x4_d pack_bf16x8(const f32x4& lo, const f32x4& hi) {
+  u32x4_d o;
+  const f32x2_d a = {lo[0], lo[1]}, b = {lo[2], lo[3]}, c_ = {hi[0], hi[1]}, d = {hi[2], hi[3]};
+  o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_d));
+  o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_d));
+  o[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(c_, bf16x2_d));
+  o[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2_d));
+  return o;
 }
 __device__ __forceinline__ float bf16r(float v) {
   float a, b;
@@ -153,7 +168,16 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a, const i
       for (int kb = 0; kb < KB; ++kb) *(f32x4*)(a.n_out + mm * K + 16 * kb + 4 * g) = in[kb];
     }
   }
-  if (BF) {
+  // [r4] bf16 matrix mode on the bf16 MATRIX pipe: with an even number of input blocks a product is KB / 2 MFMAs of
+  // 16x16x32 (bf16 operands packed from the same registers, fp32 accumulate) instead of 4 KB exact-fp32 MFMAs of twice the
+  // issue time each on operands rounded by three VALU instructions per pair -- the mode was SLOWER than fp32 before
+  // (c5: 22.4 vs 21.0 ms per training step).  Same operand values (round to nearest even), fp32 accumulation.
+  constexpr bool BFM = BF && (KB % 2 == 0);
+  u32x4_d xb[BFM ? KB / 2 : 1];
+  if (BFM) {
+#pragma unroll
+    for (int s_ = 0; s_ < KB / 2; ++s_) xb[s_] = pack_bf16x8(in[2 * s_], in[2 * s_ + 1]);
+  } else if (BF) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) in[kb] = bf16r4(in[kb]);
   }
@@ -205,6 +229,13 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a, const i
         if (GATE) cb[kb] = *(const f32x4*)(w2 + cur + 16 * kb);
       }
     }
+    if (BFM) {
+#pragma unroll
+      for (int s_ = 0; s_ < KB / 2; ++s_) {
+        acc = MFMA_BF16(pack_bf16x8(ca[2 * s_], ca[2 * s_ + 1]), xb[s_], acc);
+        if (GATE) acc2 = MFMA_BF16(pack_bf16x8(cb[2 * s_], cb[2 * s_ + 1]), xb[s_], acc2);
+      }
+    } else {
     if (BF) {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
@@ -223,6 +254,7 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a, const i
 #endif
         if (GATE) acc2 = MFMA16(cb[kb][r], in[kb][r], acc2);
       }
+    }
     }
     if (BF) acc = bf16r4(acc), acc2 = bf16r4(acc2);   // a bf16 nn.Linear returns bf16
     if (valid) {
