@@ -61,25 +61,46 @@ __device__ __forceinline__ void head_reduce(float (&p)[4], int NH) {
 // chain of two memory latencies per edge otherwise; rows of a wave have different degrees, so the compiler does not do it).
 __device__ __forceinline__ float4 ldrow(const float* p, size_t row, int H, int l) { return *(const float4*)(p + row * H + 4 * l); }
 
+// bf16 matrix mode (the *_b16 entry points): the key / value rows are STORED as bf16 (8 bytes per lane instead of 16: they are the
+// outputs of bf16-mode projections, so the narrowing is exact), the scaled query, y and the incoming dy are rounded to bf16 where the
+// reference holds bf16 tensors (layers.py:509-510; scores / softmax / AV stay fp32, layers.py:49-70).
+__device__ __forceinline__ float bf16r(float x) {
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+  return __builtin_bit_cast(float, u);
+}
+template <bool B16>
+__device__ __forceinline__ float4 ldkv(const void* p, size_t row, int H, int l) {
+  if constexpr (B16) {
+    const uint2 t = *(const uint2*)((const uint16_t*)p + row * H + 4 * l);
+    return make_float4(__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xffff0000u),
+                       __builtin_bit_cast(float, t.y << 16), __builtin_bit_cast(float, t.y & 0xffff0000u));
+  } else {
+    return ldrow((const float*)p, row, H, l);
+  }
+}
+template <bool B16>
+__device__ __forceinline__ float qscaled(float q, float scale, float sd) { return B16 ? bf16r(q / sd) : q * scale; }
+
 // y[i] and lse[i] (per feature: log-sum-exp of its head's scores) for every row i
-template <int LPR>
-__global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+template <int LPR, bool B16>
+__global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
                                                  const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
-                                                 float scale, float* __restrict__ y, float* __restrict__ lse) {
+                                                 float scale, float sd, float* __restrict__ y, float* __restrict__ lse, float* __restrict__ y_raw) {
   constexpr int H = 4 * LPR;
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
   if (i >= N) return;
   const float4 qv = *(const float4*)(q + (size_t)i * H + 4 * l);
-  const float qq[4] = {qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale};
+  const float qq[4] = {qscaled<B16>(qv.x, scale, sd), qscaled<B16>(qv.y, scale, sd), qscaled<B16>(qv.z, scale, sd), qscaled<B16>(qv.w, scale, sd)};
   float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int e0 = rowptr[i], e1 = rowptr[i + 1];
   if (e0 < e1) {
-    float4 kv = ldrow(k, (size_t)col[e0], H, l), vv = ldrow(v, (size_t)col[e0], H, l);
+    float4 kv = ldkv<B16>(k, (size_t)col[e0], H, l), vv = ldkv<B16>(v, (size_t)col[e0], H, l);
     int jn = (e0 + 1 < e1) ? col[e0 + 1] : 0;
     for (int e = e0; e < e1; ++e) {
       float4 kn = kv, vn = vv;
-      if (e + 1 < e1) kn = ldrow(k, (size_t)jn, H, l), vn = ldrow(v, (size_t)jn, H, l);
+      if (e + 1 < e1) kn = ldkv<B16>(k, (size_t)jn, H, l), vn = ldkv<B16>(v, (size_t)jn, H, l);
       if (e + 2 < e1) jn = col[e + 2];
       float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
       head_reduce<LPR>(p, NH);
@@ -107,6 +128,11 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
     op[r] = (s[r] > 0.f) ? acc[r] / s[r] : 0.f;        // a row without edges attends to nothing: zeros
     lp[r] = (s[r] > 0.f) ? m[r] + logf(s[r]) : 0.f;
   }
+  if (B16) {  // y leaves as a bf16 tensor; the backward's D = sum_d dy y is the fp32 softmax's own (the unrounded rows)
+    if (y_raw != nullptr) *(float4*)(y_raw + (size_t)i * H + 4 * l) = o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) op[r] = bf16r(op[r]);
+  }
   *(float4*)(y + (size_t)i * H + 4 * l) = o;
   if (lse != nullptr) *(float4*)(lse + (size_t)i * H + 4 * l) = ls;
 }
@@ -114,18 +140,21 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
 // backward, pass A (by row): dq[i]; per edge and head the attention weight a and the score gradient ds
 //   D[h] = sum_d dy[i,d,h] y[i,d,h];  a = exp(score - lse);  dA = sum_d dy[i,d,h] v[j,d,h];  ds = a (dA - D)
 //   dq[i,f] = scale * sum_e ds[e,h(f)] k[j_e,f]
-template <int LPR>
-__global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+template <int LPR, bool B16>
+__global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
                                                      const float* __restrict__ y, const float* __restrict__ lse, const float* __restrict__ dy,
                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
-                                                     float scale, float* __restrict__ dq, float* __restrict__ a_out, float* __restrict__ ds_out) {
+                                                     float scale, float sd, float* __restrict__ dq, float* __restrict__ a_out,
+                                                     float* __restrict__ ds_out) {
   constexpr int H = 4 * LPR;
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
   if (i >= N) return;
   const size_t ro = (size_t)i * H + 4 * l;
-  const float4 qv = *(const float4*)(q + ro), yv = *(const float4*)(y + ro), gv = *(const float4*)(dy + ro), lv = *(const float4*)(lse + ro);
-  const float qq[4] = {qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale};
+  const float4 qv = *(const float4*)(q + ro), yv = *(const float4*)(y + ro), lv = *(const float4*)(lse + ro);
+  float4 gv = *(const float4*)(dy + ro);
+  if (B16) gv = make_float4(bf16r(gv.x), bf16r(gv.y), bf16r(gv.z), bf16r(gv.w));
+  const float qq[4] = {qscaled<B16>(qv.x, scale, sd), qscaled<B16>(qv.y, scale, sd), qscaled<B16>(qv.z, scale, sd), qscaled<B16>(qv.w, scale, sd)};
   const float g[4] = {gv.x, gv.y, gv.z, gv.w}, ls[4] = {lv.x, lv.y, lv.z, lv.w};
   float D[4] = {gv.x * yv.x, gv.y * yv.y, gv.z * yv.z, gv.w * yv.w};
   head_reduce<LPR>(D, NH);
@@ -134,11 +163,11 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
   const int nr = (NH >= 4) ? 4 : NH;
   const int e0 = rowptr[i], e1 = rowptr[i + 1];
   if (e0 < e1) {
-    float4 kv = ldrow(k, (size_t)col[e0], H, l), vv = ldrow(v, (size_t)col[e0], H, l);
+    float4 kv = ldkv<B16>(k, (size_t)col[e0], H, l), vv = ldkv<B16>(v, (size_t)col[e0], H, l);
     int jn = (e0 + 1 < e1) ? col[e0 + 1] : 0;
     for (int e = e0; e < e1; ++e) {
       float4 kn = kv, vn = vv;
-      if (e + 1 < e1) kn = ldrow(k, (size_t)jn, H, l), vn = ldrow(v, (size_t)jn, H, l);
+      if (e + 1 < e1) kn = ldkv<B16>(k, (size_t)jn, H, l), vn = ldkv<B16>(v, (size_t)jn, H, l);
       if (e + 2 < e1) jn = col[e + 2];
       const float kr[4] = {kv.x, kv.y, kv.z, kv.w};
       float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
@@ -168,17 +197,21 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
       kv = kn, vv = vn;
     }
   }
+  if (B16) {  // back through float(bf16(q / sd)) * sd: the gradient is a bf16 tensor between the two casts
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = bf16r(acc[r] * scale * sd) / (sd * scale);
+  }
   *(float4*)(dq + ro) = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
 }
 
 // backward, pass B (by column j through the column-grouped order of the same edges: the t-th edge of that order is the
 // row-sorted edge cperm[t], whose row is crow[t]):
 //   dk[j,f] = scale * sum_e ds[e,h(f)] q[i_e,f];   dv[j,f] = sum_e a[e,h(f)] dy[i_e,f]
-template <int LPR>
+template <int LPR, bool B16>
 __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ q, const float* __restrict__ dy, const float* __restrict__ a_in,
                                                      const float* __restrict__ ds_in, const int32_t* __restrict__ cptr,
                                                      const int32_t* __restrict__ cperm, const int32_t* __restrict__ crow, long N, int NH,
-                                                     float scale, float* __restrict__ dk, float* __restrict__ dv) {
+                                                     float scale, float sd, float* __restrict__ dk, float* __restrict__ dv) {
   constexpr int H = 4 * LPR;
   const long j = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
@@ -208,7 +241,11 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
         heads(ds_in, (size_t)en, dsn), heads(a_in, (size_t)en, awn);
       }
       if (t + 2 < t1) in = crow[t + 2], en = cperm[t + 2];
-      const float qr[4] = {qv.x, qv.y, qv.z, qv.w}, gr[4] = {gv.x, gv.y, gv.z, gv.w};
+      float qr[4] = {qv.x, qv.y, qv.z, qv.w}, gr[4] = {gv.x, gv.y, gv.z, gv.w};
+      if (B16) {  // the query the scores were formed from (float(bf16(q / sd)) * sd) and the bf16 dy
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qr[r] = bf16r(qr[r] / sd) * sd, gr[r] = bf16r(gr[r]);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         ak[r] += dsv[r] * qr[r];
@@ -225,7 +262,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
 
 // attention weights per edge and head (return_attention=True, layers.py:543-559): a[e,h] = exp(score[e,h] - lse[i_e,h]),
 // written at out_pos[e] (the edge's position in the caller's edge_index; NULL: the row-sorted position itself)
-template <int LPR>
+template <int LPR, bool B16_UNUSED>
 __global__ void __launch_bounds__(256) k_attn_weights(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ lse,
                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                      const int32_t* __restrict__ out_pos, long N, int NH, float scale, float* __restrict__ a_out) {
@@ -257,41 +294,84 @@ static int attn_args_ok(int64_t N, int H, int NH) {
   return 1;
 }
 
-#define ATTN_DISPATCH(KERNEL, ...)                                                                               \
+#define ATTN_DISPATCH(KERNEL, B16, ...)                                                                              \
   do {                                                                                                           \
     const unsigned grid = (unsigned)(((long)N * (H / 4) + 255) / 256);                                           \
     switch (H) {                                                                                                 \
-      case 128: hipLaunchKernelGGL((KERNEL<32>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;               \
-      case 64: hipLaunchKernelGGL((KERNEL<16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                \
-      case 32: hipLaunchKernelGGL((KERNEL<8>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                 \
-      default: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                 \
+      case 128: hipLaunchKernelGGL((KERNEL<32, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;               \
+      case 64: hipLaunchKernelGGL((KERNEL<16, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                \
+      case 32: hipLaunchKernelGGL((KERNEL<8, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                 \
+      default: hipLaunchKernelGGL((KERNEL<4, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                 \
     }                                                                                                            \
   } while (0)
 
-extern "C" int mgn_sparse_attn_fwd(const float* q, const float* k, const float* v, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
-                                   int num_heads, float* y, float* lse, void* stream) {
-  if (!attn_args_ok(N, H, num_heads)) return afail(1, "mgn_sparse_attn_fwd: hidden must be 16/32/64/128 and num_heads 1/2/4/8/16 dividing it");
+static int attn_fwd_any(bool b16, const float* q, const void* k, const void* v, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
+                        int num_heads, float* y, float* lse, float* y_raw, void* stream, const char* who) {
+  if (!attn_args_ok(N, H, num_heads)) {
+    snprintf(g_aerr, sizeof(g_aerr), "%s: hidden must be 16/32/64/128 and num_heads 1/2/4/8/16 dividing it", who);
+    return 1;
+  }
   if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const float scale = 1.0f / sqrtf((float)(H / num_heads));
-  ATTN_DISPATCH(k_attn_fwd, q, k, v, rowptr, col, (long)N, num_heads, scale, y, lse);
-  return acheck("mgn_sparse_attn_fwd");
+  const float sd = sqrtf((float)(H / num_heads)), scale = 1.0f / sd;
+  if (b16)
+    ATTN_DISPATCH(k_attn_fwd, true, q, k, v, rowptr, col, (long)N, num_heads, scale, sd, y, lse, y_raw);
+  else
+    ATTN_DISPATCH(k_attn_fwd, false, q, k, v, rowptr, col, (long)N, num_heads, scale, sd, y, lse, y_raw);
+  return acheck(who);
+}
+
+static int attn_bwd_any(bool b16, const float* q, const void* k, const void* v, const float* y, const float* lse, const float* dy,
+                        const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm, const int32_t* crow, int64_t N,
+                        int64_t E, int H, int num_heads, float* dq, float* dk, float* dv, float* ws, size_t ws_bytes, void* stream,
+                        const char* who) {
+  if (!attn_args_ok(N, H, num_heads) || E < 0) {
+    snprintf(g_aerr, sizeof(g_aerr), "%s: bad arguments", who);
+    return 1;
+  }
+  if (ws_bytes < (size_t)2 * E * num_heads * sizeof(float)) {
+    snprintf(g_aerr, sizeof(g_aerr), "%s: workspace too small (2 * E * num_heads floats)", who);
+    return 1;
+  }
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const float sd = sqrtf((float)(H / num_heads)), scale = 1.0f / sd;
+  float* a_e = ws;
+  float* ds_e = ws + (size_t)E * num_heads;
+  if (b16) {
+    ATTN_DISPATCH(k_attn_bwd_row, true, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e);
+    ATTN_DISPATCH(k_attn_bwd_col, true, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv);
+  } else {
+    ATTN_DISPATCH(k_attn_bwd_row, false, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e);
+    ATTN_DISPATCH(k_attn_bwd_col, false, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv);
+  }
+  return acheck(who);
+}
+
+extern "C" int mgn_sparse_attn_fwd(const float* q, const float* k, const float* v, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
+                                   int num_heads, float* y, float* lse, void* stream) {
+  return attn_fwd_any(false, q, k, v, rowptr, col, N, H, num_heads, y, lse, nullptr, stream, "mgn_sparse_attn_fwd");
 }
 
 extern "C" int mgn_sparse_attn_bwd(const float* q, const float* k, const float* v, const float* y, const float* lse, const float* dy,
                                    const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
                                    const int32_t* crow, int64_t N, int64_t E, int H, int num_heads, float* dq, float* dk, float* dv,
                                    float* ws, size_t ws_bytes, void* stream) {
-  if (!attn_args_ok(N, H, num_heads) || E < 0) return afail(1, "mgn_sparse_attn_bwd: bad arguments");
-  if (ws_bytes < (size_t)2 * E * num_heads * sizeof(float)) return afail(1, "mgn_sparse_attn_bwd: workspace too small (2 * E * num_heads floats)");
-  if (N == 0) return 0;
-  hipStream_t s = (hipStream_t)stream;
-  const float scale = 1.0f / sqrtf((float)(H / num_heads));
-  float* a_e = ws;
-  float* ds_e = ws + (size_t)E * num_heads;
-  ATTN_DISPATCH(k_attn_bwd_row, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, dq, a_e, ds_e);
-  ATTN_DISPATCH(k_attn_bwd_col, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, dk, dv);
-  return acheck("mgn_sparse_attn_bwd");
+  return attn_bwd_any(false, q, k, v, y, lse, dy, rowptr, col, cptr, cperm, crow, N, E, H, num_heads, dq, dk, dv, ws, ws_bytes, stream,
+                      "mgn_sparse_attn_bwd");
+}
+
+extern "C" int mgn_sparse_attn_fwd_b16(const float* q, const uint16_t* k16, const uint16_t* v16, const int32_t* rowptr, const int32_t* col,
+                                       int64_t N, int H, int num_heads, float* y, float* lse, float* y_raw, void* stream) {
+  return attn_fwd_any(true, q, k16, v16, rowptr, col, N, H, num_heads, y, lse, y_raw, stream, "mgn_sparse_attn_fwd_b16");
+}
+
+extern "C" int mgn_sparse_attn_bwd_b16(const float* q, const uint16_t* k16, const uint16_t* v16, const float* y, const float* lse,
+                                       const float* dy, const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
+                                       const int32_t* crow, int64_t N, int64_t E, int H, int num_heads, float* dq, float* dk, float* dv,
+                                       float* ws, size_t ws_bytes, void* stream) {
+  return attn_bwd_any(true, q, k16, v16, y, lse, dy, rowptr, col, cptr, cperm, crow, N, E, H, num_heads, dq, dk, dv, ws, ws_bytes, stream,
+                      "mgn_sparse_attn_bwd_b16");
 }
 
 extern "C" int mgn_sparse_attn_weights(const float* q, const float* k, const float* lse, const int32_t* rowptr, const int32_t* col,
@@ -300,6 +380,6 @@ extern "C" int mgn_sparse_attn_weights(const float* q, const float* k, const flo
   if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const float scale = 1.0f / sqrtf((float)(H / num_heads));
-  ATTN_DISPATCH(k_attn_weights, q, k, lse, rowptr, col, out_pos, (long)N, num_heads, scale, attn);
+  ATTN_DISPATCH(k_attn_weights, false, q, k, lse, rowptr, col, out_pos, (long)N, num_heads, scale, attn);
   return acheck("mgn_sparse_attn_weights");
 }

@@ -56,21 +56,31 @@ def get_attn_topology(edge_index: torch.Tensor, num_nodes: int) -> AttnTopology:
 
 
 class SparseAttentionFn(torch.autograd.Function):
-    """y = softmax_rows(mask . q k^T / sqrt(D)) v on the HIP kernels (mgn_sparse_attn_fwd / _bwd)."""
+    """y = softmax_rows(mask . q k^T / sqrt(D)) v on the HIP kernels (mgn_sparse_attn_fwd / _bwd).
+    ``b16`` (bf16 matrix mode, k / v straight out of bf16-mode projections): the *_b16 entry points -- k / v are gathered (and
+    saved for the backward) as bf16 rows, the roundings of the scaled query, y, dy and dq happen inside the kernels."""
 
     @staticmethod
-    def forward(ctx, q, k, v, topo: AttnTopology, num_heads: int):
+    def forward(ctx, q, k, v, topo: AttnTopology, num_heads: int, b16: bool = False):
         ops._require_device(q, k, v)
-        q, k, v = (t.float().contiguous() for t in (q, k, v))
+        q = q.float().contiguous()
+        k, v = ((t.contiguous().to(torch.bfloat16) if b16 else t.float().contiguous()) for t in (k, v))
         N, H = q.shape
         y = torch.empty_like(q)
         lse = torch.empty_like(q)
+        need_raw = b16 and any(ctx.needs_input_grad[:3])
+        y_raw = torch.empty_like(q) if need_raw else None     # the unrounded rows: the backward's y
         with torch.cuda.device(q.device):
-            rc = _capi.lib().mgn_sparse_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), topo.rowptr.data_ptr(), topo.col.data_ptr(),
-                                                 N, H, num_heads, y.data_ptr(), lse.data_ptr(), ops._stream(q.device))
+            if b16:
+                rc = _capi.lib().mgn_sparse_attn_fwd_b16(q.data_ptr(), k.data_ptr(), v.data_ptr(), topo.rowptr.data_ptr(), topo.col.data_ptr(),
+                                                         N, H, num_heads, y.data_ptr(), lse.data_ptr(),
+                                                         y_raw.data_ptr() if need_raw else None, ops._stream(q.device))
+            else:
+                rc = _capi.lib().mgn_sparse_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), topo.rowptr.data_ptr(), topo.col.data_ptr(),
+                                                     N, H, num_heads, y.data_ptr(), lse.data_ptr(), ops._stream(q.device))
         _capi.check(rc, "mgn_sparse_attn_fwd", attn=True)
-        ctx.save_for_backward(q, k, v, y, lse)
-        ctx.topo, ctx.num_heads = topo, num_heads
+        ctx.save_for_backward(q, k, v, y_raw if need_raw else y, lse)
+        ctx.topo, ctx.num_heads, ctx.b16 = topo, num_heads, b16
         ctx.mark_non_differentiable(lse)
         return y, lse
 
@@ -82,19 +92,22 @@ class SparseAttentionFn(torch.autograd.Function):
         N, H = q.shape
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         ws = torch.empty(max(2 * topo.E * nh, 1), dtype=torch.float32, device=q.device)
+        fn = _capi.lib().mgn_sparse_attn_bwd_b16 if ctx.b16 else _capi.lib().mgn_sparse_attn_bwd
         with torch.cuda.device(q.device):
-            rc = _capi.lib().mgn_sparse_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(), lse.data_ptr(), dy.data_ptr(),
-                                                 topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.cptr.data_ptr(), topo.cperm.data_ptr(),
-                                                 topo.crow.data_ptr(), N, topo.E, H, nh, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-                                                 ws.data_ptr(), ws.numel() * 4, ops._stream(q.device))
+            rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(), lse.data_ptr(), dy.data_ptr(),
+                    topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.cptr.data_ptr(), topo.cperm.data_ptr(),
+                    topo.crow.data_ptr(), N, topo.E, H, nh, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                    ws.data_ptr(), ws.numel() * 4, ops._stream(q.device))
         _capi.check(rc, "mgn_sparse_attn_bwd", attn=True)
-        return dq, dk, dv, None, None
+        return dq, dk, dv, None, None, None
 
 
-def sparse_attention(q, k, v, topo: AttnTopology, num_heads: int, return_attention: bool = False):
+def sparse_attention(q, k, v, topo: AttnTopology, num_heads: int, return_attention: bool = False, b16: bool = False):
     """``return_attention``: also the per-edge attention weights [E, num_heads] in the order of the caller's edge_index
     (the values of the reference's softmax-ed sparse matrix, layers.py:543-559); no gradient flows through them."""
-    y, lse = SparseAttentionFn.apply(q, k, v, topo, num_heads)
+    if b16 and return_attention:
+        raise ValueError("sparse_attention: b16 and return_attention do not combine (the weights kernel reads fp32 q / k)")
+    y, lse = SparseAttentionFn.apply(q, k, v, topo, num_heads, b16)
     if not return_attention:
         return y
     qd, kd = q.detach().float().contiguous(), k.detach().float().contiguous()
@@ -176,20 +189,24 @@ class Attention(nn.Module):
         topo = adj if isinstance(adj, AttnTopology) else get_attn_topology(adj, N)
         lin = lambda m: dense(x, m.weight, m.bias, norm_scale=_norm_scale)  # noqa: E731
         q, k, v = lin(self.q_proj), lin(self.k_proj), lin(self.v_proj)
-        if self.use_rope_embeddings and self.rope_inv_freq.numel() > 0:
+        rope = self.use_rope_embeddings and self.rope_inv_freq.numel() > 0
+        if rope:
             q3, k3 = _apply_rope_with_inv(q.reshape(N, self.head_dim, self.num_heads), k.reshape(N, self.head_dim, self.num_heads),
                                           pos, self.rope_inv_freq)
             q, k = q3.reshape(N, -1), k3.reshape(N, -1)
         bf16 = ops.get_matrix_precision() == "bf16"
-        if bf16:  # the scaled query is a bf16 tensor in the reference (q / sqrt(d) on the bf16 projection, layers.py:509-510)
+        # bf16 mode, k / v straight out of the (bf16-rounding) projections: the *_b16 kernels gather bf16 rows and do the
+        # roundings below themselves (no elementwise launches around the attention)
+        fused16 = bf16 and not rope and not return_attention
+        if bf16 and not fused16:  # the scaled query is a bf16 tensor in the reference (q / sqrt(d), layers.py:509-510)
             s_ = math.sqrt(self.head_dim)
             q = (q / s_).bfloat16().float() * s_
         attn = None
         if return_attention:   # (out, attn): attn [E, num_heads] lines up with edge_index (layers.py:688-697)
             y, attn = sparse_attention(q, k, v, topo, self.num_heads, return_attention=True)
         else:
-            y = sparse_attention(q, k, v, topo, self.num_heads)
-        if bf16:  # scores / softmax / AV ran in fp32 (the reference's shims, layers.py:49-70); y returns in v's dtype
+            y = sparse_attention(q, k, v, topo, self.num_heads, b16=fused16)
+        if bf16 and not fused16:  # scores / softmax / AV ran in fp32 (layers.py:49-70); y returns in v's dtype
             y = y.bfloat16().float()
         if self.use_gated_attention and self.gate_proj is not None:
             y = SigmoidGateFn.apply(y, lin(self.gate_proj))   # same flat layout as reshape(N, head_dim, num_heads)

@@ -533,6 +533,19 @@ int mgn_sparse_attn_bwd(const float* q, const float* k, const float* v, const fl
                         const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
                         const int32_t* crow, int64_t N, int64_t E, int H, int num_heads,
                         float* dq, float* dk, float* dv, float* ws, size_t ws_bytes, void* stream);
+/* bf16 matrix mode of the same pair ([r4]; the reference under torch.autocast(bfloat16): q / k / v are bf16 tensors,
+ * the scaled query q / sqrt(D) is a bf16 tensor (layers.py:509-510), scores / softmax / AV run in fp32 (the shims at
+ * layers.py:49-70) and y returns in v's dtype).  k16 / v16 are the key / value rows STORED as bf16 ([N, H] uint16, half the
+ * gather bytes; exact when k, v came out of bf16-mode projections); q is the fp32 projection, rounded in the kernel as
+ * bf16(q / sqrt(D)); y is rounded to bf16 values (fp32 storage) and y_raw (optional) receives the unrounded rows, which is
+ * what the backward takes as its y (D = sum_d dy y is the fp32 softmax's own); the backward rounds dy on load and returns dq
+ * through the two casts (bf16(dq_scaled * sqrt(D)) / sqrt(D)); dk, dv are fp32.  Same CSR arguments, ws and determinism. */
+int mgn_sparse_attn_fwd_b16(const float* q, const uint16_t* k16, const uint16_t* v16, const int32_t* rowptr, const int32_t* col,
+                            int64_t N, int H, int num_heads, float* y, float* lse, float* y_raw, void* stream);
+int mgn_sparse_attn_bwd_b16(const float* q, const uint16_t* k16, const uint16_t* v16, const float* y, const float* lse,
+                            const float* dy, const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
+                            const int32_t* crow, int64_t N, int64_t E, int H, int num_heads,
+                            float* dq, float* dk, float* dv, float* ws, size_t ws_bytes, void* stream);
 /* The attention weights themselves (Attention.forward(..., return_attention=True), layers.py:543-559,688-697: the values of
  * the softmax-ed sparse matrix): attn[out_pos[e], h] = exp(score[e,h] - lse[i_e,h]) for the row-sorted edge e; out_pos
  * (optional) = the position of that edge in the caller's edge_index (the CSR build's perm), so attn [E, num_heads] lines up

@@ -106,6 +106,43 @@ def test_sparse_attention_kernels_vs_oracle(dev, H, nh):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,nh", [(64, 4), (128, 4), (128, 8), (32, 2), (16, 1), (64, 16)])
+def test_sparse_attention_b16_entry_points_equal_the_fp32_kernels_around_explicit_roundings(dev, H, nh):
+    """mgn_sparse_attn_fwd_b16 / _bwd_b16 (bf16 matrix mode: bf16-stored k / v rows, the roundings of the scaled query, y, dy and
+    dq inside the kernels) against the fp32 entry points with those roundings spelled out as tensor ops around them (what the
+    module did before [r4], layers.py:509-510 and the shims at layers.py:49-70).  Head widths whose sqrt is a power of two
+    reproduce bit for bit; the others differ by the rounding of q / sqrt(D) against q * (1 / sqrt(D))."""
+    import math
+    from graph_physics_amd import transformer as T
+
+    N, E, seed = 500, 4000, 31 + H + nh
+    ei = R.random_graph(N, E, seed)
+    q = R.randn((N, H), seed + 1)
+    k, v = (R.randn((N, H), seed + i).bfloat16().float() for i in (2, 3))     # outputs of bf16-mode projections
+    cot = R.randn((N, H), seed + 4)
+    topo = T.AttnTopology(ei.to(dev), N)
+    s_ = math.sqrt(H // nh)
+    qa, ka, va = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    ya = T.sparse_attention((qa / s_).bfloat16().float() * s_, ka, va, topo, nh).bfloat16().float()
+    (ya * cot.to(dev)).sum().backward()
+    qb, kb, vb = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    yb = T.sparse_attention(qb, kb, vb, topo, nh, b16=True)
+    (yb * cot.to(dev)).sum().backward()
+    exact = float(s_).is_integer() and (int(s_) & (int(s_) - 1)) == 0
+    if exact:
+        assert torch.equal(ya, yb)
+        for a, b, what in ((qa.grad, qb.grad, "dq"), (ka.grad, kb.grad, "dk"), (va.grad, vb.grad, "dv")):
+            assert torch.equal(a, b), what
+    else:
+        assert rel_err(yb, ya) < 4e-3      # a bf16 ulp where a rounding decision moved
+        for a, b, what in ((qa.grad, qb.grad, "dq"), (ka.grad, kb.grad, "dk"), (va.grad, vb.grad, "dv")):
+            assert rel_err(b, a) < 4e-3, what
+    assert torch.equal(yb, yb.bfloat16().float())
+    with pytest.raises(ValueError):
+        T.sparse_attention(qb, kb, vb, topo, nh, return_attention=True, b16=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", list(R.TRANSFORMER_CASES))
 def test_transformer_models_vs_reference_golden(dev, name):
     import graph_physics_amd as gp
