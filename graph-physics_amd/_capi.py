@@ -234,6 +234,9 @@ SYMBOLS = {
     "mgn_sparse_attn_bwd": (C.c_int, [C.c_void_p] * 11 + [C.c_int64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]),
     "mgn_sparse_attn_fwd_b16": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 4),
     "mgn_sparse_attn_bwd_b16": (C.c_int, [C.c_void_p] * 11 + [C.c_int64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]),
+    "mgn_sparse_attn_fwd_s": (C.c_int, [C.c_void_p, C.c_int64] * 3 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "mgn_sparse_attn_bwd_s": (C.c_int, [C.c_void_p, C.c_int64] * 3 + [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int64, C.c_int, C.c_int]
+                              + [C.c_void_p, C.c_int64] * 3 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_sparse_attn_weights": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mgn_attn_last_error": (C.c_char_p, []),
     "mgn_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),

@@ -70,7 +70,7 @@ __device__ __forceinline__ float bf16r(float x) {
   return __builtin_bit_cast(float, u);
 }
 template <bool B16>
-__device__ __forceinline__ float4 ldkv(const void* p, size_t row, int H, int l) {
+__device__ __forceinline__ float4 ldkv(const void* p, size_t row, int H, int l) {   // H = the row pitch in elements here
   if constexpr (B16) {
     const uint2 t = *(const uint2*)((const uint16_t*)p + row * H + 4 * l);
     return make_float4(__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xffff0000u),
@@ -82,25 +82,31 @@ __device__ __forceinline__ float4 ldkv(const void* p, size_t row, int H, int l) 
 template <bool B16>
 __device__ __forceinline__ float qscaled(float q, float scale, float sd) { return B16 ? bf16r(q / sd) : q * scale; }
 
+// Row pitches (in elements) of the strided operands: q / k / v may be column slabs of one [N, 3H] projection output and
+// dq / dk / dv slabs of its gradient (the *_s entry points); y, lse, dy are dense [N, H].
+struct AttnLd {
+  int q, k, v, dq, dk, dv;
+};
+
 // y[i] and lse[i] (per feature: log-sum-exp of its head's scores) for every row i
 template <int LPR, bool B16>
 __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
                                                  const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
-                                                 float scale, float sd, float* __restrict__ y, float* __restrict__ lse, float* __restrict__ y_raw) {
+                                                 float scale, float sd, float* __restrict__ y, float* __restrict__ lse, float* __restrict__ y_raw, AttnLd ld) {
   constexpr int H = 4 * LPR;
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
   if (i >= N) return;
-  const float4 qv = *(const float4*)(q + (size_t)i * H + 4 * l);
+  const float4 qv = *(const float4*)(q + (size_t)i * ld.q + 4 * l);
   const float qq[4] = {qscaled<B16>(qv.x, scale, sd), qscaled<B16>(qv.y, scale, sd), qscaled<B16>(qv.z, scale, sd), qscaled<B16>(qv.w, scale, sd)};
   float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int e0 = rowptr[i], e1 = rowptr[i + 1];
   if (e0 < e1) {
-    float4 kv = ldkv<B16>(k, (size_t)col[e0], H, l), vv = ldkv<B16>(v, (size_t)col[e0], H, l);
+    float4 kv = ldkv<B16>(k, (size_t)col[e0], ld.k, l), vv = ldkv<B16>(v, (size_t)col[e0], ld.v, l);
     int jn = (e0 + 1 < e1) ? col[e0 + 1] : 0;
     for (int e = e0; e < e1; ++e) {
       float4 kn = kv, vn = vv;
-      if (e + 1 < e1) kn = ldkv<B16>(k, (size_t)jn, H, l), vn = ldkv<B16>(v, (size_t)jn, H, l);
+      if (e + 1 < e1) kn = ldkv<B16>(k, (size_t)jn, ld.k, l), vn = ldkv<B16>(v, (size_t)jn, ld.v, l);
       if (e + 2 < e1) jn = col[e + 2];
       float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
       head_reduce<LPR>(p, NH);
@@ -145,13 +151,13 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
                                                      const float* __restrict__ y, const float* __restrict__ lse, const float* __restrict__ dy,
                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
                                                      float scale, float sd, float* __restrict__ dq, float* __restrict__ a_out,
-                                                     float* __restrict__ ds_out) {
+                                                     float* __restrict__ ds_out, AttnLd ld) {
   constexpr int H = 4 * LPR;
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
   if (i >= N) return;
   const size_t ro = (size_t)i * H + 4 * l;
-  const float4 qv = *(const float4*)(q + ro), yv = *(const float4*)(y + ro), lv = *(const float4*)(lse + ro);
+  const float4 qv = *(const float4*)(q + (size_t)i * ld.q + 4 * l), yv = *(const float4*)(y + ro), lv = *(const float4*)(lse + ro);
   float4 gv = *(const float4*)(dy + ro);
   if (B16) gv = make_float4(bf16r(gv.x), bf16r(gv.y), bf16r(gv.z), bf16r(gv.w));
   const float qq[4] = {qscaled<B16>(qv.x, scale, sd), qscaled<B16>(qv.y, scale, sd), qscaled<B16>(qv.z, scale, sd), qscaled<B16>(qv.w, scale, sd)};
@@ -163,11 +169,11 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
   const int nr = (NH >= 4) ? 4 : NH;
   const int e0 = rowptr[i], e1 = rowptr[i + 1];
   if (e0 < e1) {
-    float4 kv = ldkv<B16>(k, (size_t)col[e0], H, l), vv = ldkv<B16>(v, (size_t)col[e0], H, l);
+    float4 kv = ldkv<B16>(k, (size_t)col[e0], ld.k, l), vv = ldkv<B16>(v, (size_t)col[e0], ld.v, l);
     int jn = (e0 + 1 < e1) ? col[e0 + 1] : 0;
     for (int e = e0; e < e1; ++e) {
       float4 kn = kv, vn = vv;
-      if (e + 1 < e1) kn = ldkv<B16>(k, (size_t)jn, H, l), vn = ldkv<B16>(v, (size_t)jn, H, l);
+      if (e + 1 < e1) kn = ldkv<B16>(k, (size_t)jn, ld.k, l), vn = ldkv<B16>(v, (size_t)jn, ld.v, l);
       if (e + 2 < e1) jn = col[e + 2];
       const float kr[4] = {kv.x, kv.y, kv.z, kv.w};
       float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
@@ -201,7 +207,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = bf16r(acc[r] * scale * sd) / (sd * scale);
   }
-  *(float4*)(dq + ro) = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
+  *(float4*)(dq + (size_t)i * ld.dq + 4 * l) = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
 }
 
 // backward, pass B (by column j through the column-grouped order of the same edges: the t-th edge of that order is the
@@ -211,7 +217,7 @@ template <int LPR, bool B16>
 __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ q, const float* __restrict__ dy, const float* __restrict__ a_in,
                                                      const float* __restrict__ ds_in, const int32_t* __restrict__ cptr,
                                                      const int32_t* __restrict__ cperm, const int32_t* __restrict__ crow, long N, int NH,
-                                                     float scale, float sd, float* __restrict__ dk, float* __restrict__ dv) {
+                                                     float scale, float sd, float* __restrict__ dk, float* __restrict__ dv, AttnLd ld) {
   constexpr int H = 4 * LPR;
   const long j = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
     }
   };
   if (t0 < t1) {
-    float4 qv = ldrow(q, (size_t)crow[t0], H, l), gv = ldrow(dy, (size_t)crow[t0], H, l);
+    float4 qv = ldrow(q, (size_t)crow[t0], ld.q, l), gv = ldrow(dy, (size_t)crow[t0], H, l);
     float dsv[4], aw[4];
     heads(ds_in, (size_t)cperm[t0], dsv), heads(a_in, (size_t)cperm[t0], aw);
     int in = 0, en = 0;
@@ -237,7 +243,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
       float4 qn = qv, gn = gv;
       float dsn[4] = {0.f, 0.f, 0.f, 0.f}, awn[4] = {0.f, 0.f, 0.f, 0.f};
       if (t + 1 < t1) {
-        qn = ldrow(q, (size_t)in, H, l), gn = ldrow(dy, (size_t)in, H, l);
+        qn = ldrow(q, (size_t)in, ld.q, l), gn = ldrow(dy, (size_t)in, H, l);
         heads(ds_in, (size_t)en, dsn), heads(a_in, (size_t)en, awn);
       }
       if (t + 2 < t1) in = crow[t + 2], en = cperm[t + 2];
@@ -256,8 +262,8 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
       for (int r = 0; r < 4; ++r) dsv[r] = dsn[r], aw[r] = awn[r];
     }
   }
-  *(float4*)(dk + (size_t)j * H + 4 * l) = make_float4(ak[0] * scale, ak[1] * scale, ak[2] * scale, ak[3] * scale);
-  *(float4*)(dv + (size_t)j * H + 4 * l) = make_float4(av[0], av[1], av[2], av[3]);
+  *(float4*)(dk + (size_t)j * ld.dk + 4 * l) = make_float4(ak[0] * scale, ak[1] * scale, ak[2] * scale, ak[3] * scale);
+  *(float4*)(dv + (size_t)j * ld.dv + 4 * l) = make_float4(av[0], av[1], av[2], av[3]);
 }
 
 // attention weights per edge and head (return_attention=True, layers.py:543-559): a[e,h] = exp(score[e,h] - lse[i_e,h]),
@@ -305,25 +311,37 @@ static int attn_args_ok(int64_t N, int H, int NH) {
     }                                                                                                            \
   } while (0)
 
+static int attn_ld_ok(const AttnLd& ld, int H, bool grads) {
+  const int p[6] = {ld.q, ld.k, ld.v, ld.dq, ld.dk, ld.dv};
+  for (int i = 0; i < (grads ? 6 : 3); ++i)
+    if (p[i] < H || p[i] % 4 != 0) return 0;
+  return 1;
+}
+static AttnLd attn_dense_ld(int H) { return AttnLd{H, H, H, H, H, H}; }
+
 static int attn_fwd_any(bool b16, const float* q, const void* k, const void* v, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
-                        int num_heads, float* y, float* lse, float* y_raw, void* stream, const char* who) {
+                        int num_heads, float* y, float* lse, float* y_raw, AttnLd ld, void* stream, const char* who) {
   if (!attn_args_ok(N, H, num_heads)) {
     snprintf(g_aerr, sizeof(g_aerr), "%s: hidden must be 16/32/64/128 and num_heads 1/2/4/8/16 dividing it", who);
+    return 1;
+  }
+  if (!attn_ld_ok(ld, H, false)) {
+    snprintf(g_aerr, sizeof(g_aerr), "%s: row pitches must be multiples of 4 elements and >= hidden", who);
     return 1;
   }
   if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const float sd = sqrtf((float)(H / num_heads)), scale = 1.0f / sd;
   if (b16)
-    ATTN_DISPATCH(k_attn_fwd, true, q, k, v, rowptr, col, (long)N, num_heads, scale, sd, y, lse, y_raw);
+    ATTN_DISPATCH(k_attn_fwd, true, q, k, v, rowptr, col, (long)N, num_heads, scale, sd, y, lse, y_raw, ld);
   else
-    ATTN_DISPATCH(k_attn_fwd, false, q, k, v, rowptr, col, (long)N, num_heads, scale, sd, y, lse, y_raw);
+    ATTN_DISPATCH(k_attn_fwd, false, q, k, v, rowptr, col, (long)N, num_heads, scale, sd, y, lse, y_raw, ld);
   return acheck(who);
 }
 
 static int attn_bwd_any(bool b16, const float* q, const void* k, const void* v, const float* y, const float* lse, const float* dy,
                         const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm, const int32_t* crow, int64_t N,
-                        int64_t E, int H, int num_heads, float* dq, float* dk, float* dv, float* ws, size_t ws_bytes, void* stream,
+                        int64_t E, int H, int num_heads, float* dq, float* dk, float* dv, float* ws, size_t ws_bytes, AttnLd ld, void* stream,
                         const char* who) {
   if (!attn_args_ok(N, H, num_heads) || E < 0) {
     snprintf(g_aerr, sizeof(g_aerr), "%s: bad arguments", who);
@@ -333,45 +351,68 @@ static int attn_bwd_any(bool b16, const float* q, const void* k, const void* v, 
     snprintf(g_aerr, sizeof(g_aerr), "%s: workspace too small (2 * E * num_heads floats)", who);
     return 1;
   }
+  if (!attn_ld_ok(ld, H, true)) {
+    snprintf(g_aerr, sizeof(g_aerr), "%s: row pitches must be multiples of 4 elements and >= hidden", who);
+    return 1;
+  }
   if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const float sd = sqrtf((float)(H / num_heads)), scale = 1.0f / sd;
   float* a_e = ws;
   float* ds_e = ws + (size_t)E * num_heads;
   if (b16) {
-    ATTN_DISPATCH(k_attn_bwd_row, true, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e);
-    ATTN_DISPATCH(k_attn_bwd_col, true, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv);
+    ATTN_DISPATCH(k_attn_bwd_row, true, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e, ld);
+    ATTN_DISPATCH(k_attn_bwd_col, true, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv, ld);
   } else {
-    ATTN_DISPATCH(k_attn_bwd_row, false, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e);
-    ATTN_DISPATCH(k_attn_bwd_col, false, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv);
+    ATTN_DISPATCH(k_attn_bwd_row, false, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e, ld);
+    ATTN_DISPATCH(k_attn_bwd_col, false, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv, ld);
   }
   return acheck(who);
 }
 
 extern "C" int mgn_sparse_attn_fwd(const float* q, const float* k, const float* v, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
                                    int num_heads, float* y, float* lse, void* stream) {
-  return attn_fwd_any(false, q, k, v, rowptr, col, N, H, num_heads, y, lse, nullptr, stream, "mgn_sparse_attn_fwd");
+  return attn_fwd_any(false, q, k, v, rowptr, col, N, H, num_heads, y, lse, nullptr, attn_dense_ld(H), stream, "mgn_sparse_attn_fwd");
 }
 
 extern "C" int mgn_sparse_attn_bwd(const float* q, const float* k, const float* v, const float* y, const float* lse, const float* dy,
                                    const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
                                    const int32_t* crow, int64_t N, int64_t E, int H, int num_heads, float* dq, float* dk, float* dv,
                                    float* ws, size_t ws_bytes, void* stream) {
-  return attn_bwd_any(false, q, k, v, y, lse, dy, rowptr, col, cptr, cperm, crow, N, E, H, num_heads, dq, dk, dv, ws, ws_bytes, stream,
+  return attn_bwd_any(false, q, k, v, y, lse, dy, rowptr, col, cptr, cperm, crow, N, E, H, num_heads, dq, dk, dv, ws, ws_bytes, attn_dense_ld(H), stream,
                       "mgn_sparse_attn_bwd");
 }
 
 extern "C" int mgn_sparse_attn_fwd_b16(const float* q, const uint16_t* k16, const uint16_t* v16, const int32_t* rowptr, const int32_t* col,
                                        int64_t N, int H, int num_heads, float* y, float* lse, float* y_raw, void* stream) {
-  return attn_fwd_any(true, q, k16, v16, rowptr, col, N, H, num_heads, y, lse, y_raw, stream, "mgn_sparse_attn_fwd_b16");
+  return attn_fwd_any(true, q, k16, v16, rowptr, col, N, H, num_heads, y, lse, y_raw, attn_dense_ld(H), stream, "mgn_sparse_attn_fwd_b16");
 }
 
 extern "C" int mgn_sparse_attn_bwd_b16(const float* q, const uint16_t* k16, const uint16_t* v16, const float* y, const float* lse,
                                        const float* dy, const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
                                        const int32_t* crow, int64_t N, int64_t E, int H, int num_heads, float* dq, float* dk, float* dv,
                                        float* ws, size_t ws_bytes, void* stream) {
-  return attn_bwd_any(true, q, k16, v16, y, lse, dy, rowptr, col, cptr, cperm, crow, N, E, H, num_heads, dq, dk, dv, ws, ws_bytes, stream,
+  return attn_bwd_any(true, q, k16, v16, y, lse, dy, rowptr, col, cptr, cperm, crow, N, E, H, num_heads, dq, dk, dv, ws, ws_bytes, attn_dense_ld(H), stream,
                       "mgn_sparse_attn_bwd_b16");
+}
+
+// Strided forms: q / k / v as column slabs of one projection output (ldq / ldk / ldv = row pitches in elements; kv_bf16: k / v are
+// bf16 rows and the bf16-mode roundings apply, as in the *_b16 pair), dq / dk / dv as slabs of its gradient.
+extern "C" int mgn_sparse_attn_fwd_s(const float* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int kv_bf16,
+                                     const int32_t* rowptr, const int32_t* col, int64_t N, int H, int num_heads, float* y, float* lse,
+                                     float* y_raw, void* stream) {
+  const AttnLd ld{(int)ldq, (int)ldk, (int)ldv, H, H, H};
+  return attn_fwd_any(kv_bf16 != 0, q, k, v, rowptr, col, N, H, num_heads, y, lse, y_raw, ld, stream, "mgn_sparse_attn_fwd_s");
+}
+
+extern "C" int mgn_sparse_attn_bwd_s(const float* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int kv_bf16,
+                                     const float* y, const float* lse, const float* dy, const int32_t* rowptr, const int32_t* col,
+                                     const int32_t* cptr, const int32_t* cperm, const int32_t* crow, int64_t N, int64_t E, int H,
+                                     int num_heads, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* ws,
+                                     size_t ws_bytes, void* stream) {
+  const AttnLd ld{(int)ldq, (int)ldk, (int)ldv, (int)lddq, (int)lddk, (int)lddv};
+  return attn_bwd_any(kv_bf16 != 0, q, k, v, y, lse, dy, rowptr, col, cptr, cperm, crow, N, E, H, num_heads, dq, dk, dv, ws, ws_bytes, ld,
+                      stream, "mgn_sparse_attn_bwd_s");
 }
 
 extern "C" int mgn_sparse_attn_weights(const float* q, const float* k, const float* lse, const int32_t* rowptr, const int32_t* col,

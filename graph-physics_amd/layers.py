@@ -158,6 +158,10 @@ class GraphNetBlock(nn.Module):
         self.use_gated_mlp = use_gated_mlp
         if use_gated_mlp:
             from .gated import build_gated_mlp
+            if hidden_size not in (16, 32, 64, 128):
+                # the gated blocks run on mgn_linear_fwd / _bwd: phases of 16/32/64/128 columns, outputs up to 384 (include/mgn_hip.h,
+                # "Dense row work"); say so here instead of a C-layer error at the first forward
+                raise NotImplementedError(f"use_gated_mlp needs hidden_size in (16, 32, 64, 128) on the HIP dense kernels, got {hidden_size}")
             self.edge_block = build_gated_mlp(3 * hidden_size, hidden_size, hidden_size)
             self.node_block = build_gated_mlp(2 * hidden_size, hidden_size, hidden_size)
         else:

@@ -102,6 +102,69 @@ class SparseAttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+class _StackRows(torch.autograd.Function):
+    """[W_1; W_2; ...] (and the biases alike) of Linears that read the same rows, as ONE matrix for one launch: a multi-tensor copy
+    of the parameters (a few KB) into a fresh buffer; the backward hands each parameter its row slab of the stacked gradient."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        rows = [int(w.shape[0]) for w in ws]
+        out = torch.empty((sum(rows),) + tuple(ws[0].shape[1:]), dtype=torch.float32, device=ws[0].device)
+        torch._foreach_copy_(list(out.split(rows, dim=0)), [w.detach() for w in ws])
+        ctx.rows = rows
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return tuple(d.split(ctx.rows, dim=0))
+
+
+class PackedAttentionFn(torch.autograd.Function):
+    """Sparse attention over q | k | v held as column slabs of ONE [N, 3H] projection output (mgn_sparse_attn_fwd_s / _bwd_s): no
+    copies out of it, and dq | dk | dv written as slabs of its gradient.  ``b16``: bf16 matrix mode (k | v narrowed to bf16 rows in one
+    pass, the roundings inside the kernels -- the *_b16 semantic)."""
+
+    @staticmethod
+    def forward(ctx, qkv, topo: AttnTopology, num_heads: int, b16: bool):
+        ops._require_device(qkv)
+        qkv = ops._f32c(qkv)
+        N, H3 = qkv.shape
+        H = H3 // 3
+        kv = qkv[:, H:].to(torch.bfloat16) if b16 else qkv[:, H:]         # [N, 2H]: k | v
+        es, ekv = qkv.element_size(), kv.element_size()
+        y, lse = torch.empty(N, H, dtype=torch.float32, device=qkv.device), torch.empty(N, H, dtype=torch.float32, device=qkv.device)
+        need_raw = b16 and ctx.needs_input_grad[0]
+        y_raw = torch.empty_like(y) if need_raw else None
+        with torch.cuda.device(qkv.device):
+            rc = _capi.lib().mgn_sparse_attn_fwd_s(qkv.data_ptr(), H3, kv.data_ptr(), int(kv.stride(0)), kv.data_ptr() + H * ekv, int(kv.stride(0)),
+                                                   int(b16), topo.rowptr.data_ptr(), topo.col.data_ptr(), N, H, num_heads, y.data_ptr(),
+                                                   lse.data_ptr(), y_raw.data_ptr() if need_raw else None, ops._stream(qkv.device))
+        _capi.check(rc, "mgn_sparse_attn_fwd_s", attn=True)
+        ctx.save_for_backward(qkv, kv if b16 else qkv.new_empty(0), y_raw if need_raw else y, lse)
+        ctx.topo, ctx.num_heads, ctx.b16 = topo, num_heads, b16
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        qkv, kv16, y, lse = ctx.saved_tensors
+        topo, nh, b16 = ctx.topo, ctx.num_heads, ctx.b16
+        dy = ops._f32c(dy)
+        N, H3 = qkv.shape
+        H = H3 // 3
+        kv = kv16 if b16 else qkv[:, H:]
+        ekv = kv.element_size()
+        d = torch.empty_like(qkv)
+        ws = torch.empty(max(2 * topo.E * nh, 1), dtype=torch.float32, device=qkv.device)
+        with torch.cuda.device(qkv.device):
+            rc = _capi.lib().mgn_sparse_attn_bwd_s(qkv.data_ptr(), H3, kv.data_ptr(), int(kv.stride(0)), kv.data_ptr() + H * ekv, int(kv.stride(0)),
+                                                   int(b16), y.data_ptr(), lse.data_ptr(), dy.data_ptr(), topo.rowptr.data_ptr(),
+                                                   topo.col.data_ptr(), topo.cptr.data_ptr(), topo.cperm.data_ptr(), topo.crow.data_ptr(),
+                                                   N, topo.E, H, nh, d.data_ptr(), H3, d.data_ptr() + 4 * H, H3, d.data_ptr() + 8 * H, H3,
+                                                   ws.data_ptr(), ws.numel() * 4, ops._stream(qkv.device))
+        _capi.check(rc, "mgn_sparse_attn_bwd_s", attn=True)
+        return d, None, None, None
+
+
 def sparse_attention(q, k, v, topo: AttnTopology, num_heads: int, return_attention: bool = False, b16: bool = False):
     """``return_attention``: also the per-edge attention weights [E, num_heads] in the order of the caller's edge_index
     (the values of the reference's softmax-ed sparse matrix, layers.py:543-559); no gradient flows through them."""
@@ -188,13 +251,23 @@ class Attention(nn.Module):
         N = x.size(0)
         topo = adj if isinstance(adj, AttnTopology) else get_attn_topology(adj, N)
         lin = lambda m: dense(x, m.weight, m.bias, norm_scale=_norm_scale)  # noqa: E731
-        q, k, v = lin(self.q_proj), lin(self.k_proj), lin(self.v_proj)
         rope = self.use_rope_embeddings and self.rope_inv_freq.numel() > 0
+        bf16 = ops.get_matrix_precision() == "bf16"
+        if not rope and not return_attention and 3 * self.hidden_size <= 384:
+            # the three projections as ONE launch over [W_q; W_k; W_v] (the norm prologue runs once, x is read once), attention
+            # straight on the column slabs of its output ([r4])
+            projs = (self.q_proj, self.k_proj, self.v_proj)
+            Wc = _StackRows.apply(*(m.weight for m in projs))
+            bc = _StackRows.apply(*(m.bias for m in projs)) if self.q_proj.bias is not None else None
+            y = PackedAttentionFn.apply(dense(x, Wc, bc, norm_scale=_norm_scale), topo, self.num_heads, bf16)
+            if self.use_gated_attention and self.gate_proj is not None:
+                y = SigmoidGateFn.apply(y, lin(self.gate_proj))
+            return dense(y, self.proj.weight, self.proj.bias, resid=_resid)
+        q, k, v = lin(self.q_proj), lin(self.k_proj), lin(self.v_proj)
         if rope:
             q3, k3 = _apply_rope_with_inv(q.reshape(N, self.head_dim, self.num_heads), k.reshape(N, self.head_dim, self.num_heads),
                                           pos, self.rope_inv_freq)
             q, k = q3.reshape(N, -1), k3.reshape(N, -1)
-        bf16 = ops.get_matrix_precision() == "bf16"
         # bf16 mode, k / v straight out of the (bf16-rounding) projections: the *_b16 kernels gather bf16 rows and do the
         # roundings below themselves (no elementwise launches around the attention)
         fused16 = bf16 and not rope and not return_attention

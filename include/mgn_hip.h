@@ -546,6 +546,18 @@ int mgn_sparse_attn_bwd_b16(const float* q, const uint16_t* k16, const uint16_t*
                             const float* dy, const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm,
                             const int32_t* crow, int64_t N, int64_t E, int H, int num_heads,
                             float* dq, float* dk, float* dv, float* ws, size_t ws_bytes, void* stream);
+/* Strided forms of both pairs ([r4]): q / k / v are column slabs of ONE [N, 3H] projection output (Attention's three Linears,
+ * layers.py:606-616,668-671, issued as a single launch over the concatenated weights) -- ldq / ldk / ldv are the row pitches in
+ * elements (multiples of 4, >= H; of the uint16 rows when kv_bf16) -- and dq / dk / dv slabs of that output's gradient, so neither
+ * side needs a copy or a concatenation.  kv_bf16 != 0: the *_b16 semantic (k, v bf16 rows; y_raw as there).  y, lse, dy dense. */
+int mgn_sparse_attn_fwd_s(const float* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int kv_bf16,
+                          const int32_t* rowptr, const int32_t* col, int64_t N, int H, int num_heads, float* y, float* lse,
+                          float* y_raw, void* stream);
+int mgn_sparse_attn_bwd_s(const float* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int kv_bf16,
+                          const float* y, const float* lse, const float* dy, const int32_t* rowptr, const int32_t* col,
+                          const int32_t* cptr, const int32_t* cperm, const int32_t* crow, int64_t N, int64_t E, int H,
+                          int num_heads, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* ws,
+                          size_t ws_bytes, void* stream);
 /* The attention weights themselves (Attention.forward(..., return_attention=True), layers.py:543-559,688-697: the values of
  * the softmax-ed sparse matrix): attn[out_pos[e], h] = exp(score[e,h] - lse[i_e,h]) for the row-sorted edge e; out_pos
  * (optional) = the position of that edge in the caller's edge_index (the CSR build's perm), so attn [E, num_heads] lines up

@@ -61,6 +61,8 @@ def test_block_variants_construct_with_reference_state_dict_keys():
     assert {"gate_pos", "gate_proj.weight", "gate_proj.bias"} <= keys and "_rope_inv_freq" not in keys
     assert b._rope_inv_freq.numel() == 32 // 4 and abs(float(b._rope_inv_freq[1]) - 10000.0 ** (-1 / 8)) < 1e-7
     g = gp.GraphNetBlock(32, use_gated_mlp=True)
+    with pytest.raises(NotImplementedError, match="hidden_size in"):     # widths off the dense kernels: said at construction
+        gp.GraphNetBlock(256, use_gated_mlp=True)
     assert {"edge_block.0.scale", "edge_block.1.linear1.weight", "edge_block.1.linear2.bias", "edge_block.2.weight"} <= set(g.state_dict())
     assert g.edge_block[1].linear1.weight.shape == (96, 96) and g.node_block[2].weight.shape == (32, 96)
     b3 = gp.GraphNetBlock(32, nb_of_layers=3, layer_norm=False)
