@@ -37,15 +37,43 @@ static int acheck(const char* what) {
 // per-feature partial products p[r] into the full per-HEAD sums, delivered to every lane for the heads of
 // its own four features: butterfly over the lanes that share the same heads (stride >= NH/4), then a fold
 // inside the lane when NH < 4.  LPR = lanes per row (hidden / 4), a power of two <= 32.
-template <int LPR>
+// p + (p of lane l ^ M) inside groups of LPR lanes, on the DPP network (no LDS round trip): quad permutes for M = 1, 2; rotations
+// of the 16-lane DPP row for M = 8 and, when the group IS that row, for M = 4 (the operand already has period 8 there, so the
+// rotation reads the same value as the exchange would -- bit-identical sums); 8-lane groups take M = 4 as two bank-masked
+// rotations; M = 16 (128-wide rows) stays a shuffle.
+template <int M, int LPR>
+__device__ __forceinline__ float xor_add(float x) {
+  const int xi = __builtin_bit_cast(int, x);
+  int t;
+  if constexpr (M == 1) {
+    t = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xf, 0xf, false);          // quad_perm [1,0,3,2]
+  } else if constexpr (M == 2) {
+    t = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xf, 0xf, false);          // quad_perm [2,3,0,1]
+  } else if constexpr (M == 4 && LPR >= 16) {
+    t = __builtin_amdgcn_update_dpp(0, xi, 0x124, 0xf, 0xf, false);         // row_ror:4 (after the M = 8 step)
+  } else if constexpr (M == 4) {
+    t = __builtin_amdgcn_update_dpp(0, xi, 0x12C, 0xf, 0x5, false);         // row_ror:12 (lane l reads l + 4) into lanes 0-3, 8-11
+    t = __builtin_amdgcn_update_dpp(t, xi, 0x124, 0xf, 0xa, false);         // row_ror:4 (lane l reads l - 4) into lanes 4-7, 12-15
+  } else if constexpr (M == 8) {
+    t = __builtin_amdgcn_update_dpp(0, xi, 0x128, 0xf, 0xf, false);         // row_ror:8 == l ^ 8
+  } else {
+    return x + __shfl_xor(x, M, LPR);
+  }
+  return x + __builtin_bit_cast(float, t);
+}
+
+// GS = lanes of a row group that hold one copy of every head between them (max(NH / 4, 1)): the butterfly runs over the strides
+// >= GS, top down (M = 8 before M = 4: what the rotation form of M = 4 relies on).
+template <int LPR, int GS>
 __device__ __forceinline__ void head_reduce(float (&p)[4], int NH) {
-  const int gs = (NH >= 4) ? (NH >> 2) : 1;
+  static_assert(LPR <= 32 && GS >= 1, "row groups of at most 32 lanes");
 #pragma unroll
-  for (int m = LPR >> 1; m >= 1; m >>= 1) {
-    if (m >= gs) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) p[r] += __shfl_xor(p[r], m, LPR);
-    }
+  for (int r = 0; r < 4; ++r) {
+    if constexpr (LPR >= 32 && GS <= 16) p[r] = xor_add<16, LPR>(p[r]);
+    if constexpr (LPR >= 16 && GS <= 8) p[r] = xor_add<8, LPR>(p[r]);
+    if constexpr (LPR >= 8 && GS <= 4) p[r] = xor_add<4, LPR>(p[r]);
+    if constexpr (LPR >= 4 && GS <= 2) p[r] = xor_add<2, LPR>(p[r]);
+    if constexpr (LPR >= 2 && GS <= 1) p[r] = xor_add<1, LPR>(p[r]);
   }
   if (NH == 2) {
     const float a = p[0] + p[2], b = p[1] + p[3];
@@ -89,7 +117,7 @@ struct AttnLd {
 };
 
 // y[i] and lse[i] (per feature: log-sum-exp of its head's scores) for every row i
-template <int LPR, bool B16>
+template <int LPR, int GS, bool B16>
 __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
                                                  const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
                                                  float scale, float sd, float* __restrict__ y, float* __restrict__ lse, float* __restrict__ y_raw, AttnLd ld) {
@@ -109,7 +137,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
       if (e + 1 < e1) kn = ldkv<B16>(k, (size_t)jn, ld.k, l), vn = ldkv<B16>(v, (size_t)jn, ld.v, l);
       if (e + 2 < e1) jn = col[e + 2];
       float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
-      head_reduce<LPR>(p, NH);
+      head_reduce<LPR, GS>(p, NH);
       const float vr[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -146,7 +174,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
 // backward, pass A (by row): dq[i]; per edge and head the attention weight a and the score gradient ds
 //   D[h] = sum_d dy[i,d,h] y[i,d,h];  a = exp(score - lse);  dA = sum_d dy[i,d,h] v[j,d,h];  ds = a (dA - D)
 //   dq[i,f] = scale * sum_e ds[e,h(f)] k[j_e,f]
-template <int LPR, bool B16>
+template <int LPR, int GS, bool B16>
 __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
                                                      const float* __restrict__ y, const float* __restrict__ lse, const float* __restrict__ dy,
                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
@@ -163,7 +191,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
   const float qq[4] = {qscaled<B16>(qv.x, scale, sd), qscaled<B16>(qv.y, scale, sd), qscaled<B16>(qv.z, scale, sd), qscaled<B16>(qv.w, scale, sd)};
   const float g[4] = {gv.x, gv.y, gv.z, gv.w}, ls[4] = {lv.x, lv.y, lv.z, lv.w};
   float D[4] = {gv.x * yv.x, gv.y * yv.y, gv.z * yv.z, gv.w * yv.w};
-  head_reduce<LPR>(D, NH);
+  head_reduce<LPR, GS>(D, NH);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int gs = (NH >= 4) ? (NH >> 2) : 1;     // lanes 0 .. gs-1 hold one copy of every head between them
   const int nr = (NH >= 4) ? 4 : NH;
@@ -178,8 +206,8 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
       const float kr[4] = {kv.x, kv.y, kv.z, kv.w};
       float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
       float dA[4] = {g[0] * vv.x, g[1] * vv.y, g[2] * vv.z, g[3] * vv.w};
-      head_reduce<LPR>(p, NH);
-      head_reduce<LPR>(dA, NH);
+      head_reduce<LPR, GS>(p, NH);
+      head_reduce<LPR, GS>(dA, NH);
       float a4[4], d4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -213,7 +241,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
 // backward, pass B (by column j through the column-grouped order of the same edges: the t-th edge of that order is the
 // row-sorted edge cperm[t], whose row is crow[t]):
 //   dk[j,f] = scale * sum_e ds[e,h(f)] q[i_e,f];   dv[j,f] = sum_e a[e,h(f)] dy[i_e,f]
-template <int LPR, bool B16>
+template <int LPR, int GS, bool B16>
 __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ q, const float* __restrict__ dy, const float* __restrict__ a_in,
                                                      const float* __restrict__ ds_in, const int32_t* __restrict__ cptr,
                                                      const int32_t* __restrict__ cperm, const int32_t* __restrict__ crow, long N, int NH,
@@ -268,7 +296,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
 
 // attention weights per edge and head (return_attention=True, layers.py:543-559): a[e,h] = exp(score[e,h] - lse[i_e,h]),
 // written at out_pos[e] (the edge's position in the caller's edge_index; NULL: the row-sorted position itself)
-template <int LPR, bool B16_UNUSED>
+template <int LPR, int GS, bool B16_UNUSED>
 __global__ void __launch_bounds__(256) k_attn_weights(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ lse,
                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                      const int32_t* __restrict__ out_pos, long N, int NH, float scale, float* __restrict__ a_out) {
@@ -285,7 +313,7 @@ __global__ void __launch_bounds__(256) k_attn_weights(const float* __restrict__ 
     const size_t j = (size_t)col[e];
     const float4 kv = *(const float4*)(k + j * H + 4 * l);
     float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
-    head_reduce<LPR>(p, NH);
+    head_reduce<LPR, GS>(p, NH);
     const size_t o = (size_t)(out_pos != nullptr ? out_pos[e] : e) * NH;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -300,15 +328,25 @@ static int attn_args_ok(int64_t N, int H, int NH) {
   return 1;
 }
 
-#define ATTN_DISPATCH(KERNEL, B16, ...)                                                                              \
+#define ATTN_DISPATCH_GS(KERNEL, GS_, B16, ...)                                                                        \
   do {                                                                                                           \
     const unsigned grid = (unsigned)(((long)N * (H / 4) + 255) / 256);                                           \
     switch (H) {                                                                                                 \
-      case 128: hipLaunchKernelGGL((KERNEL<32, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;               \
-      case 64: hipLaunchKernelGGL((KERNEL<16, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                \
-      case 32: hipLaunchKernelGGL((KERNEL<8, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                 \
-      default: hipLaunchKernelGGL((KERNEL<4, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;                 \
+      case 128: hipLaunchKernelGGL((KERNEL<32, GS_, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;     \
+      case 64: hipLaunchKernelGGL((KERNEL<16, GS_, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;      \
+      case 32: hipLaunchKernelGGL((KERNEL<8, GS_, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;       \
+      default: hipLaunchKernelGGL((KERNEL<4, GS_, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;       \
     }                                                                                                            \
+  } while (0)
+// the reduction stride is a template argument: 1 (up to 4 heads), 2 (8 heads), 4 (16 heads)
+#define ATTN_DISPATCH(KERNEL, B16, ...)                                    \
+  do {                                                                     \
+    if (num_heads <= 4)                                                    \
+      ATTN_DISPATCH_GS(KERNEL, 1, B16, __VA_ARGS__);                       \
+    else if (num_heads == 8)                                               \
+      ATTN_DISPATCH_GS(KERNEL, 2, B16, __VA_ARGS__);                       \
+    else                                                                   \
+      ATTN_DISPATCH_GS(KERNEL, 4, B16, __VA_ARGS__);                       \
   } while (0)
 
 static int attn_ld_ok(const AttnLd& ld, int H, bool grads) {
