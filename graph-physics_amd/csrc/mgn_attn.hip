@@ -46,20 +46,47 @@ __device__ __forceinline__ float xor_add(float x) {
   const int xi = __builtin_bit_cast(int, x);
   int t;
   if constexpr (M == 1) {
-    t = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xf, 0xf, false);          // quad_perm [1,0,3,2]
+    t = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xf, 0xf, true);           // quad_perm [1,0,3,2]
   } else if constexpr (M == 2) {
-    t = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xf, 0xf, false);          // quad_perm [2,3,0,1]
+    t = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xf, 0xf, true);           // quad_perm [2,3,0,1]
   } else if constexpr (M == 4 && LPR >= 16) {
-    t = __builtin_amdgcn_update_dpp(0, xi, 0x124, 0xf, 0xf, false);         // row_ror:4 (after the M = 8 step)
+    t = __builtin_amdgcn_update_dpp(0, xi, 0x124, 0xf, 0xf, true);          // row_ror:4 (after the M = 8 step)
   } else if constexpr (M == 4) {
     t = __builtin_amdgcn_update_dpp(0, xi, 0x12C, 0xf, 0x5, false);         // row_ror:12 (lane l reads l + 4) into lanes 0-3, 8-11
     t = __builtin_amdgcn_update_dpp(t, xi, 0x124, 0xf, 0xa, false);         // row_ror:4 (lane l reads l - 4) into lanes 4-7, 12-15
   } else if constexpr (M == 8) {
-    t = __builtin_amdgcn_update_dpp(0, xi, 0x128, 0xf, 0xf, false);         // row_ror:8 == l ^ 8
+    t = __builtin_amdgcn_update_dpp(0, xi, 0x128, 0xf, 0xf, true);          // row_ror:8 == l ^ 8
   } else {
     return x + __shfl_xor(x, M, LPR);
   }
   return x + __builtin_bit_cast(float, t);
+}
+
+// The same step for the four partial products of a lane at once, as v_add_f32_dpp (operand 0 through the DPP network, one
+// instruction per value: hipcc keeps update_dpp as a v_mov_b32_dpp + zero fill + add, three).  The leading s_nop covers the
+// VALU-write -> DPP-read hazard the assembler does not see inside an asm block; within and between the blocks a register is
+// read four instructions after it was written.
+#define ATTN_DPP4(CTRL)                                                             \
+  asm("s_nop 1\n\t"                                                                 \
+      "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+      "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+      "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+      "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"       \
+      : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]))
+template <int M, int LPR>
+__device__ __forceinline__ void xor_add4(float (&p)[4]) {
+  if constexpr (M == 1) {
+    ATTN_DPP4("quad_perm:[1,0,3,2]");
+  } else if constexpr (M == 2) {
+    ATTN_DPP4("quad_perm:[2,3,0,1]");
+  } else if constexpr (M == 4 && LPR >= 16) {
+    ATTN_DPP4("row_ror:4");
+  } else if constexpr (M == 8) {
+    ATTN_DPP4("row_ror:8");
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = xor_add<M, LPR>(p[r]);
+  }
 }
 
 // GS = lanes of a row group that hold one copy of every head between them (max(NH / 4, 1)): the butterfly runs over the strides
@@ -67,14 +94,11 @@ __device__ __forceinline__ float xor_add(float x) {
 template <int LPR, int GS>
 __device__ __forceinline__ void head_reduce(float (&p)[4], int NH) {
   static_assert(LPR <= 32 && GS >= 1, "row groups of at most 32 lanes");
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if constexpr (LPR >= 32 && GS <= 16) p[r] = xor_add<16, LPR>(p[r]);
-    if constexpr (LPR >= 16 && GS <= 8) p[r] = xor_add<8, LPR>(p[r]);
-    if constexpr (LPR >= 8 && GS <= 4) p[r] = xor_add<4, LPR>(p[r]);
-    if constexpr (LPR >= 4 && GS <= 2) p[r] = xor_add<2, LPR>(p[r]);
-    if constexpr (LPR >= 2 && GS <= 1) p[r] = xor_add<1, LPR>(p[r]);
-  }
+  if constexpr (LPR >= 32 && GS <= 16) xor_add4<16, LPR>(p);
+  if constexpr (LPR >= 16 && GS <= 8) xor_add4<8, LPR>(p);
+  if constexpr (LPR >= 8 && GS <= 4) xor_add4<4, LPR>(p);
+  if constexpr (LPR >= 4 && GS <= 2) xor_add4<2, LPR>(p);
+  if constexpr (LPR >= 2 && GS <= 1) xor_add4<1, LPR>(p);
   if (NH == 2) {
     const float a = p[0] + p[2], b = p[1] + p[3];
     p[0] = p[2] = a, p[1] = p[3] = b;
@@ -97,6 +121,24 @@ __device__ __forceinline__ float bf16r(float x) {
   u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
   return __builtin_bit_cast(float, u);
 }
+// exp(x) for the softmax terms (x <= 0 up to rounding; a very negative FINITE x gives 0): expf's own evaluation -- t = fl(x log2 e),
+// the part of x log2 e that t lost (the product's rounding and log2 e's tail) carried in r, v_exp_f32 on the REDUCED argument
+// (t - round(t)) + r in [-0.5, 0.5], then ldexp -- without its range checks (9 instructions instead of 14).  Skipping the reduction
+// (v_exp_f32 on t itself, corrected to first order in r: 6 instructions) was measured 4x noisier on the cancelling key-bias
+// gradient and is not used.  These kernels are bound by vector-instruction issue, not by bytes ([r4]).
+__device__ __forceinline__ float exp_sm(float x) {
+#ifdef ATTN_EXPF
+  return expf(x);
+#endif
+  constexpr float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f;
+  const float t = x * L2E_HI;
+  const float r = __builtin_fmaf(x, L2E_LO, __builtin_fmaf(x, L2E_HI, -t));
+  const float n = __builtin_rintf(t);
+  const float e = __builtin_amdgcn_exp2f((t - n) + r);
+  return __builtin_amdgcn_ldexpf(e, (int)n);
+}
+constexpr float ATTN_M0 = -1e37f;   // the running maximum before the first edge: finite, so exp_sm(-(p - M0)) is an exact 0, no NaN
+
 template <bool B16>
 __device__ __forceinline__ float4 ldkv(const void* p, size_t row, int H, int l) {   // H = the row pitch in elements here
   if constexpr (B16) {
@@ -127,7 +169,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
   if (i >= N) return;
   const float4 qv = *(const float4*)(q + (size_t)i * ld.q + 4 * l);
   const float qq[4] = {qscaled<B16>(qv.x, scale, sd), qscaled<B16>(qv.y, scale, sd), qscaled<B16>(qv.z, scale, sd), qscaled<B16>(qv.w, scale, sd)};
-  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float m[4] = {ATTN_M0, ATTN_M0, ATTN_M0, ATTN_M0}, s[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int e0 = rowptr[i], e1 = rowptr[i + 1];
   if (e0 < e1) {
     float4 kv = ldkv<B16>(k, (size_t)col[e0], ld.k, l), vv = ldkv<B16>(v, (size_t)col[e0], ld.v, l);
@@ -146,7 +188,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
         // two-exponential form; same value, other rounding (outputs move by <= 1e-6 of the scale; the three parity readings of the
         // 10-block model for both forms on three seeds: profiles/r03_attn_one_exp_readings.txt)
         const bool up = p[r] > m[r];
-        const float t = expf(-fabsf(p[r] - m[r]));        // first edge: exp(-inf) = 0
+        const float t = exp_sm(-fabsf(p[r] - m[r]));      // first edge: exp(-1e37) = 0
         s[r] = up ? __builtin_fmaf(s[r], t, 1.f) : s[r] + t;
         acc[r] = up ? __builtin_fmaf(acc[r], t, vr[r]) : __builtin_fmaf(t, vr[r], acc[r]);
         m[r] = up ? p[r] : m[r];
@@ -211,7 +253,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
       float a4[4], d4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        a4[r] = expf(p[r] - ls[r]);
+        a4[r] = exp_sm(p[r] - ls[r]);
         d4[r] = a4[r] * (dA[r] - D[r]);
         acc[r] += d4[r] * kr[r];
       }
@@ -251,6 +293,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
   const int l = threadIdx.x % LPR;
   if (j >= N) return;
   float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool sd_pow2 = (__builtin_bit_cast(unsigned, sd) & 0x7fffffu) == 0u;   // then scale = 1 / sd is exact as well
   const int t0 = cptr[j], t1 = cptr[j + 1];
   auto heads = [&](const float* __restrict__ src, size_t e, float (&o)[4]) {
     if (NH == 4) {
@@ -262,32 +305,42 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
     }
   };
   if (t0 < t1) {
-    float4 qv = ldrow(q, (size_t)crow[t0], ld.q, l), gv = ldrow(dy, (size_t)crow[t0], H, l);
-    float dsv[4], aw[4];
-    heads(ds_in, (size_t)cperm[t0], dsv), heads(a_in, (size_t)cperm[t0], aw);
-    int in = 0, en = 0;
-    if (t0 + 1 < t1) in = crow[t0 + 1], en = cperm[t0 + 1];
+    // two edges in flight behind the one being summed, their indices one further ahead: nothing but latency bounds this pass
+    // (no reductions, four adds per edge), so the depth of the request queue is its speed ([r4]: 251 -> ~200 us at depth 2)
+    struct Row {
+      float4 q, g;
+      float ds[4], aw[4];
+    };
+    auto fetch = [&](int i_, int e_) -> Row {
+      Row r;
+      r.q = ldrow(q, (size_t)i_, ld.q, l), r.g = ldrow(dy, (size_t)i_, H, l);
+      heads(ds_in, (size_t)e_, r.ds), heads(a_in, (size_t)e_, r.aw);
+      return r;
+    };
+    Row cur = fetch(crow[t0], cperm[t0]), nx1 = cur;
+    int i2 = 0, e2 = 0;
+    if (t0 + 1 < t1) nx1 = fetch(crow[t0 + 1], cperm[t0 + 1]);
+    if (t0 + 2 < t1) i2 = crow[t0 + 2], e2 = cperm[t0 + 2];
     for (int t = t0; t < t1; ++t) {
-      float4 qn = qv, gn = gv;
-      float dsn[4] = {0.f, 0.f, 0.f, 0.f}, awn[4] = {0.f, 0.f, 0.f, 0.f};
-      if (t + 1 < t1) {
-        qn = ldrow(q, (size_t)in, ld.q, l), gn = ldrow(dy, (size_t)in, H, l);
-        heads(ds_in, (size_t)en, dsn), heads(a_in, (size_t)en, awn);
-      }
-      if (t + 2 < t1) in = crow[t + 2], en = cperm[t + 2];
-      float qr[4] = {qv.x, qv.y, qv.z, qv.w}, gr[4] = {gv.x, gv.y, gv.z, gv.w};
+      Row nx2 = nx1;
+      if (t + 2 < t1) nx2 = fetch(i2, e2);
+      if (t + 3 < t1) i2 = crow[t + 3], e2 = cperm[t + 3];
+      float qr[4] = {cur.q.x, cur.q.y, cur.q.z, cur.q.w}, gr[4] = {cur.g.x, cur.g.y, cur.g.z, cur.g.w};
       if (B16) {  // the query the scores were formed from (float(bf16(q / sd)) * sd) and the bf16 dy
+        if (sd_pow2) {  // a power-of-two sqrt(D) (head widths 4, 16, 64): q * (1 / sd) IS q / sd, without four divisions per edge
 #pragma unroll
-        for (int r = 0; r < 4; ++r) qr[r] = bf16r(qr[r] / sd) * sd, gr[r] = bf16r(gr[r]);
+          for (int r = 0; r < 4; ++r) qr[r] = bf16r(qr[r] * scale) * sd, gr[r] = bf16r(gr[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) qr[r] = bf16r(qr[r] / sd) * sd, gr[r] = bf16r(gr[r]);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        ak[r] += dsv[r] * qr[r];
-        av[r] += aw[r] * gr[r];
+        ak[r] += cur.ds[r] * qr[r];
+        av[r] += cur.aw[r] * gr[r];
       }
-      qv = qn, gv = gn;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dsv[r] = dsn[r], aw[r] = awn[r];
+      cur = nx1, nx1 = nx2;
     }
   }
   *(float4*)(dk + (size_t)j * ld.dk + 4 * l) = make_float4(ak[0] * scale, ak[1] * scale, ak[2] * scale, ak[3] * scale);
@@ -317,7 +370,7 @@ __global__ void __launch_bounds__(256) k_attn_weights(const float* __restrict__ 
     const size_t o = (size_t)(out_pos != nullptr ? out_pos[e] : e) * NH;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (l < gs && r < nr) a_out[o + 4 * l + r] = expf(p[r] - ls[r]);
+      if (l < gs && r < nr) a_out[o + 4 * l + r] = exp_sm(p[r] - ls[r]);
   }
 }
 
