@@ -306,6 +306,9 @@ class HipBackend:
     def block(self, block, x, e, ctx, pos=None, phi=None):
         from . import ops
         from .layers import _block_params
+        if block.use_gated_mlp:   # gated-MLP blocks run on the dense kernels (gated.py), on the same dst-sorted edge rows
+            from .gated import gated_block_forward
+            return gated_block_forward(block, x, e, ctx, pos if block.use_rope else None, phi if block.use_gate else None)
         return ops.processor_apply(x, e, ctx, 1, *_block_params(block), spec=block.spec,
                                    pos=pos if block.use_rope else None, phi=phi if block.use_gate else None,
                                    rope_inv_freq=block._rope_inv_freq if block.use_rope else None)

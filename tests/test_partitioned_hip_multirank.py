@@ -54,6 +54,25 @@ def _case(world):
     return pos_all[perm], inv[ei_all], part[perm.numpy()]
 
 
+def _collect(q, procs, world, timeout):
+    """one result per rank; a rank that died (its peers then wait in a collective) fails the test at once, not after the timeout"""
+    import queue
+    import time
+
+    res, t_end = [], time.time() + timeout
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > t_end:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError(f"rank process(es) died with exit codes {dead}" if dead else "timed out waiting for the ranks")
+    return res
+
+
 def _inputs(n, e):
     x_in, e_in = R.randn((n, 11), 1), R.randn((e, 3), 2)
     tgt = R.randn((n, 2), 3)
@@ -113,7 +132,7 @@ def test_partitioned_hip_ranks_equal_unpartitioned_oracle(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=900) for _ in range(world)]
+    res = _collect(q, procs, world, 900)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -145,20 +164,25 @@ def test_partitioned_hip_ranks_equal_unpartitioned_oracle(world):
 
 
 ROPE_VARIANT = {"use_gate": True, "use_rope": True, "rope_axes": 2, "rope_base": 100.0}
+GATED_VARIANT = {"use_gated_mlp": True, "use_gate": True}
+VARIANTS = {"rope": ROPE_VARIANT, "gated_mlp": GATED_VARIANT}
 
 
-def _rope_net(gp, act_silu=True):
+def _rope_net(gp, act_silu=True, kind="rope"):
     from graph_physics_amd import layers
     layers.set_use_silu_activation(act_silu)
     try:
-        net = gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=H, use_rope_embeddings=True, rope_pos_dimension=2, rope_base=100.0,
-                                     use_gated_attention=True)
+        if kind == "rope":
+            net = gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=H, use_rope_embeddings=True, rope_pos_dimension=2, rope_base=100.0,
+                                         use_gated_attention=True)
+        else:   # gated-MLP blocks (layers.py:213-278,932-942) with the sigmoid gate on the aggregate
+            net = gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=H, use_gated_mlp=True, use_gated_attention=True)
     finally:
         layers.set_use_silu_activation(False)
     return net
 
 
-def _worker_rope(rank, world, port, q):
+def _worker_rope(rank, world, port, q, kind="rope"):
     """RoPE + sigmoid gate (graph.phi) on the partitioned mesh with the HIP engine's per-block path: ghost positions exchanged once,
     ghost latents before every block"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -170,14 +194,15 @@ def _worker_rope(rank, world, port, q):
     dev = torch.device("cuda:0")
     pos, ei, part = _case(world)
     N = pos.shape[0]
-    net = _rope_net(gp)
+    net = _rope_net(gp, kind=kind)
     net.load_state_dict(R.variant_params(net.state_dict(), SEED + 20))
     net = net.to(dev)
     x_in, e_in, tgt, nt = _inputs(N, ei.shape[1])
     phi = R.randn((N,), 44)
     plan = P.build_rank_plan(ei, part, rank, world, pos=pos.numpy())
     pm = D.PartitionedEPD(net, plan)
-    out = pm(x_in[plan.owned].to(dev), e_in[plan.edge_ids].to(dev), phi_own=phi[plan.owned].to(dev), pos_own=pos[plan.owned].to(dev))
+    out = pm(x_in[plan.owned].to(dev), e_in[plan.edge_ids].to(dev), phi_own=phi[plan.owned].to(dev),
+             pos_own=pos[plan.owned].to(dev) if kind == "rope" else None)
     assert pm._halo is None   # the per-block path, not the fused processor node
     loss = D.partitioned_loss(out, tgt[plan.owned].to(dev), nt[plan.owned].to(dev))
     loss.backward()
@@ -188,15 +213,18 @@ def _worker_rope(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_partitioned_rope_gate_phi_hip_world4_equals_unpartitioned_oracle():
+@pytest.mark.parametrize("kind", ["rope", "gated_mlp"])
+def test_partitioned_rope_gate_phi_hip_world4_equals_unpartitioned_oracle(kind):
+    """the per-block partitioned path for the block variants -- relative RoPE (ghost positions), the sigmoid gate with graph.phi, and
+    [r4] gated-MLP blocks -- at world 4 on one device against the UN-partitioned oracle, forward and every gradient"""
     world = 4
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_rope, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_rope, args=(r, world, port, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=900) for _ in range(world)]
+    res = _collect(q, procs, world, 900)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -204,11 +232,11 @@ def test_partitioned_rope_gate_phi_hip_world4_equals_unpartitioned_oracle():
 
     pos, ei, part = _case(world)
     N = pos.shape[0]
-    net = _rope_net(gp)
+    net = _rope_net(gp, kind=kind)
     params = {k: v.clone().requires_grad_(True) for k, v in R.variant_params(net.state_dict(), SEED + 20).items()}
     x_in, e_in, tgt, nt = _inputs(N, ei.shape[1])
     phi = R.randn((N,), 44)
-    ref = O.epd_forward(x_in, e_in, ei, params, 2, act="silu", variant=ROPE_VARIANT, pos=pos, phi=phi)
+    ref = O.epd_forward(x_in, e_in, ei, params, 2, act="silu", variant=VARIANTS[kind], pos=pos if kind == "rope" else None, phi=phi)
     ref_loss = O.l2_loss(ref, tgt, nt)
     ref_loss.backward()
     full = torch.zeros_like(ref)
@@ -285,7 +313,7 @@ def test_overlapped_gradient_all_reduce_equals_the_flat_one(world):
     procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in range(world)]
+    res = _collect(q, procs, world, 600)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
