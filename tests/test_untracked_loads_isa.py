@@ -10,10 +10,13 @@ HIPCC = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/
 
 @pytest.mark.skipif(HIPCC is None, reason="hipcc not available")
 def test_no_instruction_touches_an_untracked_load_before_its_drain(tmp_path):
+    sys.path.insert(0, ROOT)
+    from graph_physics_amd import _capi   # the code-generation flags of the shipped build (no packed-fp32 instructions)
+
     asm = tmp_path / "mgn.s"
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-S",
-                        "--cuda-device-only", "-o", str(asm), os.path.join(ROOT, "graph-physics_amd", "csrc", "mgn_kernels.hip")],
-                       capture_output=True, text=True)
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17"] + list(_capi.DEVICE_FLAGS) +
+                       ["-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", str(asm),
+                        os.path.join(ROOT, "graph-physics_amd", "csrc", "mgn_kernels.hip")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     c = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_untracked_loads.py"), str(asm)], capture_output=True, text=True)
     assert c.returncode == 0, c.stdout[-3000:]
