@@ -2044,16 +2044,20 @@ static int fwd_static_shape(const mgn_mlp_fwd_args& a) {
 
 // The ping-pong edge update (mgn_pp.inc) takes a ShEdge launch when it is fp32-grade, its four units lie back to back,
 // the messages are not written (fused aggregation only), the saves are all there or all absent, and every CU gets at
-// least two 128-row tiles (on a one-tile launch the alternation only doubles the tile's latency).  MGN_PP=0: off.
+// least two 128-row tiles (on a one-tile launch the alternation only doubles the tile's latency).
+// MGN_PP unset: INFERENCE-mode launches only (no saves: measured 127-130 us against 132-145 us at the bench size; the
+// training-mode instance is slower than the x6 kernel); 0: off; 1: both modes; 2: both modes at any size (tests).
 static bool fwd_pp_ok(const mgn_mlp_fwd_args& a) {
   const char* env = getenv("MGN_PP");
-  if (env == nullptr || atoi(env) == 0) return false;  // opt-in while the kernel is being tuned
-  const int64_t min_rows = (env != nullptr && atoi(env) == 2) ? 1 : 2 * 128 * 256;  // MGN_PP=2: any size (tests)
+  const int mode = (env == nullptr) ? -1 : atoi(env);
+  if (mode == 0) return false;
+  const int64_t min_rows = (mode == 2) ? 1 : 2 * 128 * 256;
   if (a.precision != 0 || a.y_out != nullptr || a.M < min_rows || a.M * 512 >= (int64_t)1 << 32) return false;  // (32-bit row offsets)
   for (int u = 1; u < 4; ++u)
     if ((const char*)a.wpk[u] != (const char*)a.wpk[0] + (size_t)u * MGN_WPACK_BYTES) return false;
   const bool all = a.saveU && a.saveR && a.saveH[0] && a.saveH[1] && a.saveH[2] && a.saveM[0] && a.saveM[1] && a.saveM[2];
   const bool none = !a.saveU && !a.saveR && !a.saveH[0] && !a.saveH[1] && !a.saveH[2] && !a.saveM[0] && !a.saveM[1] && !a.saveM[2];
+  if (mode < 0 && !none) return false;
   // rows past M are computed as copies of row M - 1 and stored there again: the outputs must alias no input
   return (all || none) && a.resid != nullptr && a.scale != nullptr && a.out != a.resid && a.out != a.src[0];
 }

@@ -1,4 +1,4 @@
-"""GPU: the ping-pong generation of the edge update (csrc/mgn_pp.inc; opt-in, MGN_PP) through the C ABI (mgn_mlp_fwd):
+"""GPU: the ping-pong generation of the edge update (csrc/mgn_pp.inc; MGN_PP: default = inference-mode launches from 65 536 rows) through the C ABI (mgn_mlp_fwd):
 every output of the launch -- e', the fused aggregation, the saved activations with their sign bits, U, rms -- against an fp64
 evaluation of the reference's edge update (layers.py:1044-1060, 163-210, 104-129) on ragged row counts (tile tails, one row,
 rows past the last tile) in inference and training mode, and against the x6 static-shape kernel it replaces."""
