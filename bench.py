@@ -274,8 +274,10 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
                               + ("6..7 node jobs; the E-row jobs run inside the fused edge backward)" if tm.ms("edge_bwd_fused") else "4 edge + 6..7 node jobs)"),
                               tm.ms("wgrad"), b_wg, traffic.get("wgrad_bytes"), {"launches_per_step": per_step("wgrad")}))
     if tm.ms("edge_inf"):
-        others.append(hbm_obj(f"k_mlp_fwd_{t} (edge update, inference mode = the rollout's dominant kernel: nothing saved, "
-                              "aggregation fused)", tm.ms("edge_inf"), b_inf, None,
+        # the ping-pong instance takes fp32-grade inference-mode launches from 65 536 rows unless MGN_PP=0 (mgn_kernels.hip: fwd_pp_ok)
+        pp = x6 and nterm == 6 and E >= 65536 and os.environ.get("MGN_PP", "") != "0"
+        others.append(hbm_obj(("k_edge_fwd_pp<false>" if pp else f"k_mlp_fwd_{t}") + " (edge update, inference mode = the rollout's "
+                              "dominant kernel: nothing saved, aggregation fused)", tm.ms("edge_inf"), b_inf, None,
                               dict(mfma(tm.ms("edge_inf"), nterm if x6 else 1), launches_per_rollout_step=tm.count("edge_inf") // 2)))
     if tm.ms("segsum"):
         roof_seg = hbm_obj("k_segsum2<8> (CSR segment sums = the scatter-add of the backward pass onto destination and source nodes; "
