@@ -1446,110 +1446,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WgradLaunch L) {
   }
 }
 
-// Row-vector variant for jobs up to 64 x 64 (the 64 x 64 block jobs dense.py cuts the Transformer's / gated MLP's weight gradients
-// into): a lane fetches FOUR consecutive features of a row in one 16-byte load -- 16 lanes cover the 256 bytes of a 64-wide row, a
-// wave instruction four whole rows -- where the generic kernel above spends sixteen 4-byte loads per tile on A alone and fetches A
-// once per wave.  The feature a lane holds in component q is 4c + q, so MFMA block q multiplies the STRIDED feature set
-// {q, 4 + q, ..}: a permutation of the rows / columns of dW that the store undoes.  Every wave owns whole tiles (16 rows, no operand
-// is loaded twice) and a full 64 x 64 accumulator; the four waves are summed through LDS, the workgroup writes one partial in the
-// layout k_wgrad_red reads.  Needs lda % 4 == ldb % 4 == kw % 4 == 0 and 16-byte aligned operands (wgrad_job_row64).
-__global__ void __launch_bounds__(256, 2) k_wgrad_row64(const WgradLaunch L) {
-  constexpr int H = 64;
-  __shared__ float red[3][H * H + H];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c = lane & 15, g = lane >> 4;
-  int j = 0;
-  while (j + 1 < L.njobs && (int)blockIdx.x >= L.wg0[j + 1]) ++j;
-  const mgn_wgrad_job J = L.job[j];
-  const int nwg = L.wg0[j + 1] - L.wg0[j];
-  const int wg = blockIdx.x - L.wg0[j];
-  const long ntiles = (J.M + 15) >> 4;
-  const long t0 = ntiles * wg / nwg, t1 = ntiles * (wg + 1) / nwg;
-  const bool a_on = 4 * c < 16 * J.nja, b_on = 4 * c < J.kw;
-
-  f32x4 acc[4][4];  // [qa][qb]
-#pragma unroll
-  for (int qa = 0; qa < 4; ++qa)
-#pragma unroll
-    for (int qb = 0; qb < 4; ++qb) acc[qa][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 cs = {0.f, 0.f, 0.f, 0.f};  // column sums of A over this lane's rows (bias gradient)
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 av[2][4], bv[2][4];
-  auto load_tile = [&](long tile, f32x4 (&a)[4], f32x4 (&b)[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long row = tile * 16 + 4 * g + r;
-      const bool ok = row < J.M;
-      a[r] = (ok && a_on) ? ld4(J.A + row * J.lda + 4 * c) : zero;
-      b[r] = (ok && b_on) ? ld4(J.B + row * J.ldb + 4 * c) : zero;
-    }
-  };
-  auto mac_tile = [&](const f32x4 (&a)[4], const f32x4 (&b)[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int qa = 0; qa < 4; ++qa)
-#pragma unroll
-        for (int qb = 0; qb < 4; ++qb) acc[qa][qb] = MFMA16(a[r][qa], b[r][qb], acc[qa][qb]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) cs += a[r];
-  };
-  long tile = t0 + wv;
-  if (tile < t1) {
-    load_tile(tile, av[0], bv[0]);
-    for (; tile + 8 < t1; tile += 8) {  // two tiles per trip keeps buffer indices static
-      load_tile(tile + 4, av[1], bv[1]);
-      mac_tile(av[0], bv[0]);
-      load_tile(tile + 8, av[0], bv[0]);
-      mac_tile(av[1], bv[1]);
-    }
-    if (tile + 4 < t1) {
-      load_tile(tile + 4, av[1], bv[1]);
-      mac_tile(av[0], bv[0]);
-      mac_tile(av[1], bv[1]);
-    } else {
-      mac_tile(av[0], bv[0]);
-    }
-  }
-  // lane (c,g), block (qa,qb), reg v  ->  dW[16g + 4v + qa][4c + qb]; components qb are consecutive columns: one 16-byte value
-#pragma unroll
-  for (int q = 0; q < 4; ++q) cs[q] = rowsum4(cs[q]);  // all g hold the sum over the wave's rows of features 4c..4c+3
-  auto put = [&](float* dst) {
-#pragma unroll
-    for (int qa = 0; qa < 4; ++qa)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const f32x4 o = {acc[qa][0][v], acc[qa][1][v], acc[qa][2][v], acc[qa][3][v]};
-        *(f32x4*)(dst + (16 * g + 4 * v + qa) * H + 4 * c) = o;
-      }
-    if (g == 0) *(f32x4*)(dst + H * H + 4 * c) = cs;
-  };
-  if (wv > 0) put(red[wv - 1]);
-  __syncthreads();
-  if (wv == 0) {
-#pragma unroll
-    for (int w = 0; w < 3; ++w) {
-#pragma unroll
-      for (int qa = 0; qa < 4; ++qa)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const f32x4 o = *(const f32x4*)(red[w] + (16 * g + 4 * v + qa) * H + 4 * c);
-#pragma unroll
-          for (int qb = 0; qb < 4; ++qb) acc[qa][qb][v] += o[qb];
-        }
-      cs += *(const f32x4*)(red[w] + H * H + 4 * c);
-    }
-    float* P = L.partial + (size_t)blockIdx.x * (H * H + H);
-#pragma unroll
-    for (int qa = 0; qa < 4; ++qa)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const f32x4 o = {acc[qa][0][v], acc[qa][1][v], acc[qa][2][v], acc[qa][3][v]};
-        st4(P + (16 * g + 4 * v + qa) * H + 4 * c, o);
-      }
-    if (g == 0 && J.db != nullptr) st4(P + H * H + 4 * c, cs);
-  }
-}
+// (k_wgrad_row64, the row-vector variant for jobs up to 64 x 64, follows the mgn_x6.inc include: its bf16 form uses the bf16 MFMA helpers)
 
 // LDS-staged variant for full 128 x 128 jobs (lda = ldb = 128): the workgroup streams
 // 32-row tiles of A (= dZ) and B (= X) through LDS by DMA, double buffered; every element is
@@ -1686,6 +1583,134 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
 #include "mgn_x6.inc"
 #include "mgn_pp.inc"
 #include "mgn_fused.inc"
+
+// Row-vector variant for jobs up to 64 x 64 (the 64 x 64 block jobs dense.py cuts the Transformer's / gated MLP's weight gradients
+// into): a lane fetches FOUR consecutive features of a row in one 16-byte load -- 16 lanes cover the 256 bytes of a 64-wide row, a
+// wave instruction four whole rows -- where the generic kernel above spends sixteen 4-byte loads per tile on A alone and fetches A
+// once per wave.  The feature a lane holds in component q is 4c + q, so MFMA block q multiplies the STRIDED feature set
+// {q, 4 + q, ..}: a permutation of the rows / columns of dW that the store undoes.  Every wave owns whole tiles (16 rows, no operand
+// is loaded twice) and a full 64 x 64 accumulator; the four waves are summed through LDS, the workgroup writes one partial in the
+// layout k_wgrad_red reads.  Needs lda % 4 == ldb % 4 == kw % 4 == 0 and 16-byte aligned operands (wgrad_job_row64).
+// [r4] BF (bf16 matrix mode): the same loads and the same double buffering, but a tile is ONE K = 16 step of v_mfma_f32_16x16x16_bf16 --
+// a lane's four rows (4g + r) are its four K values, the same assignment on both operands -- with the operands rounded to bf16 as
+// the reference's autocast Linear backward sees them: 16 matrix instructions per tile instead of 64 exact-fp32 ones.  (A K = 32 form
+// over pairs of tiles needs a second raw pair in flight to hide the loads: 664 bytes of scratch per lane, or 4 % slower without it.)
+template <bool BF>
+__global__ void __launch_bounds__(256, 2) k_wgrad_row64(const WgradLaunch L) {
+  constexpr int H = 64;
+  __shared__ float red[3][H * H + H];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  int j = 0;
+  while (j + 1 < L.njobs && (int)blockIdx.x >= L.wg0[j + 1]) ++j;
+  const mgn_wgrad_job J = L.job[j];
+  const int nwg = L.wg0[j + 1] - L.wg0[j];
+  const int wg = blockIdx.x - L.wg0[j];
+  const long ntiles = (J.M + 15) >> 4;
+  const long t0 = ntiles * wg / nwg, t1 = ntiles * (wg + 1) / nwg;
+  const bool a_on = 4 * c < 16 * J.nja, b_on = 4 * c < J.kw;
+
+  f32x4 acc[4][4];  // [qa][qb]
+#pragma unroll
+  for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) acc[qa][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};  // column sums of A over this lane's rows (bias gradient)
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 av[2][4], bv[2][4];
+  auto load_tile = [&](long tile, f32x4 (&a)[4], f32x4 (&b)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = tile * 16 + 4 * g + r;
+      const bool ok = row < J.M;
+      a[r] = (ok && a_on) ? ld4(J.A + row * J.lda + 4 * c) : zero;
+      b[r] = (ok && b_on) ? ld4(J.B + row * J.ldb + 4 * c) : zero;
+    }
+  };
+  auto mac_tile = [&](const f32x4 (&a)[4], const f32x4 (&b)[4]) {
+    if constexpr (BF) {   // the lane's four rows are the four K values of a K = 16 bf16 MFMA (v_mfma_f32_16x16x16_bf16), same on both operands
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      typedef u32 u32x2_ __attribute__((ext_vector_type(2)));
+      s16x4 pa[4], pb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pa[q] = __builtin_bit_cast(s16x4, u32x2_{pk_bf16(a[0][q], a[1][q]), pk_bf16(a[2][q], a[3][q])});
+        pb[q] = __builtin_bit_cast(s16x4, u32x2_{pk_bf16(b[0][q], b[1][q]), pk_bf16(b[2][q], b[3][q])});
+      }
+#pragma unroll
+      for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) acc[qa][qb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[qa], pb[qb], acc[qa][qb], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs += a[r];
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) acc[qa][qb] = MFMA16(a[r][qa], b[r][qb], acc[qa][qb]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs += a[r];
+  };
+  long tile = t0 + wv;
+  if (tile < t1) {
+    load_tile(tile, av[0], bv[0]);
+    for (; tile + 8 < t1; tile += 8) {  // two tiles per trip keeps buffer indices static
+      load_tile(tile + 4, av[1], bv[1]);
+      mac_tile(av[0], bv[0]);
+      load_tile(tile + 8, av[0], bv[0]);
+      mac_tile(av[1], bv[1]);
+    }
+    if (tile + 4 < t1) {
+      load_tile(tile + 4, av[1], bv[1]);
+      mac_tile(av[0], bv[0]);
+      mac_tile(av[1], bv[1]);
+    } else {
+      mac_tile(av[0], bv[0]);
+    }
+  }
+  // lane (c,g), block (qa,qb), reg v  ->  dW[16g + 4v + qa][4c + qb]; components qb are consecutive columns: one 16-byte value
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cs[q] = rowsum4(cs[q]);  // all g hold the sum over the wave's rows of features 4c..4c+3
+  auto put = [&](float* dst) {
+#pragma unroll
+    for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 o = {acc[qa][0][v], acc[qa][1][v], acc[qa][2][v], acc[qa][3][v]};
+        *(f32x4*)(dst + (16 * g + 4 * v + qa) * H + 4 * c) = o;
+      }
+    if (g == 0) *(f32x4*)(dst + H * H + 4 * c) = cs;
+  };
+  if (wv > 0) put(red[wv - 1]);
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+      for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const f32x4 o = *(const f32x4*)(red[w] + (16 * g + 4 * v + qa) * H + 4 * c);
+#pragma unroll
+          for (int qb = 0; qb < 4; ++qb) acc[qa][qb][v] += o[qb];
+        }
+      cs += *(const f32x4*)(red[w] + H * H + 4 * c);
+    }
+    float* P = L.partial + (size_t)blockIdx.x * (H * H + H);
+#pragma unroll
+    for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 o = {acc[qa][0][v], acc[qa][1][v], acc[qa][2][v], acc[qa][3][v]};
+        st4(P + (16 * g + 4 * v + qa) * H + 4 * c, o);
+      }
+    if (g == 0 && J.db != nullptr) st4(P + H * H + 4 * c, cs);
+  }
+}
+
 
 // dW[r,k] = sum over the job's workgroup partials.  64 outputs x 4 partial-lanes per block:
 // consecutive threads read consecutive addresses of one partial (coalesced), four lanes walk
@@ -2725,7 +2750,10 @@ int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes,
         hipLaunchKernelGGL(k_wgrad_lds, dim3(total), dim3(256), smem, s, L);
       }
     } else if (row64) {
-      hipLaunchKernelGGL(k_wgrad_row64, dim3(total), dim3(256), 0, s, L);
+      if (precision == 1)
+        hipLaunchKernelGGL(k_wgrad_row64<true>, dim3(total), dim3(256), 0, s, L);
+      else
+        hipLaunchKernelGGL(k_wgrad_row64<false>, dim3(total), dim3(256), 0, s, L);
     } else {
       switch (HB) {
         case 8: hipLaunchKernelGGL(k_wgrad<8>, dim3(total), dim3(256), 0, s, L); break;
