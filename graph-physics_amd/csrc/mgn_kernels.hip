@@ -2140,32 +2140,32 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
       if (g6 > 512u) g6 = 512u;
       hipLaunchKernelGGL((k_mlp_fwd_x6<6, 6, 0, ShEdge>), dim3(g6), dim3(384), X6_FWD_LDS_BYTES(6), s, a);
     } else if (shape == 1) {
-      if (a.precision == 1)
+      if (a.precision >= 1)
         hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 0, ShEdge>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
       else
         hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShEdge>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
     } else if (shape == 2) {
-      if (a.precision == 1)
+      if (a.precision >= 1)
         hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 0, ShNode<2>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
       else
         hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShNode<2>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
     } else if (shape == 3) {
-      if (a.precision == 1)
+      if (a.precision >= 1)
         hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 0, ShNode<0>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
       else
         hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0, ShNode<0>>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
     } else if (silu) {
-      if (a.precision == 1)
+      if (a.precision >= 1)
         hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 1>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
       else
         hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 1>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
     } else if (nw == 8) {
-      if (a.precision == 1)
+      if (a.precision >= 1)
         hipLaunchKernelGGL((k_mlp_fwd_x6<1, 8, 0>), dim3(grid), dim3(512), X6_FWD_LDS_BYTES(8), s, a);
       else
         hipLaunchKernelGGL((k_mlp_fwd_x6<6, 8, 0>), dim3(grid), dim3(512), X6_FWD_LDS_BYTES(8), s, a);
     } else {
-      if (a.precision == 1)
+      if (a.precision >= 1)
         hipLaunchKernelGGL((k_mlp_fwd_x6<1, 4, 0>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
       else
         hipLaunchKernelGGL((k_mlp_fwd_x6<6, 4, 0>), dim3(grid), dim3(256), X6_FWD_LDS_BYTES(4), s, a);
@@ -2506,7 +2506,9 @@ static int check_mlp_common(int H, int NL, int out_w, const char* who) {
 int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream) {
   const mgn_mlp_fwd_args& a = *args;
   if (int rc = check_mlp_common(a.H, a.NL, a.out_w, "mgn_mlp_fwd")) return rc;
-  if (a.precision != 0 && a.precision != 1) return fail(1, "mgn_mlp_fwd: precision must be 0 (fp32-grade) or 1 (bf16)");
+  if (a.precision < 0 || a.precision > 2) return fail(1, "mgn_mlp_fwd: precision must be 0 (fp32-grade), 1 (bf16) or 2 (bf16, two-byte saves)");
+  if (a.precision == 2 && (!fwd_x6(a) || !plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false, a.act).lds || a.act != MGN_ACT_RELU))
+    return fail(1, "mgn_mlp_fwd: precision 2 (two-byte saves) needs the packed split-bf16 path (H = 128, wpk[]) and ReLU");
   if (a.seg_out != nullptr && !(plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && fwd_x6(a)))
     return fail(1, "mgn_mlp_fwd: the fused segment sum needs the packed split-bf16 path (and seg_key / seg_rowptr / seg_part, no post-products)");
   if (a.out_relu && (a.scale != nullptr || a.resid != nullptr || a.wpk[0] != nullptr ||
@@ -2517,7 +2519,7 @@ int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream) {
     return fail(1, "mgn_mlp_fwd: GELU runs on the generic kernels only (no packed weights / gathers / post-products)");
   if (a.act == MGN_ACT_SILU && plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && !fwd_x6(a) && a.NL > 1)
     return fail(1, "mgn_mlp_fwd: SiLU is not available on the exact-fp32 LDS generation (pass packed weights)");
-  if (a.precision == 1 && plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && !fwd_x6(a))
+  if (a.precision >= 1 && plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && !fwd_x6(a))
     return fail(1, "mgn_mlp_fwd: at H = 128 with full widths the bf16 matrix mode needs the packed split-bf16 path (wpk); other shapes run it on the generic kernels");
   if (a.nphase < 1 || a.nphase > MGN_MAX_PHASES) return fail(1, "mgn_mlp_fwd: nphase out of range");
   for (int p = 0; p < a.nphase; ++p)
@@ -2690,7 +2692,8 @@ size_t mgn_wgrad_workspace_bytes(int njobs, const mgn_wgrad_job* jobs) {
 }
 
 static bool wgrad_job_full(const mgn_wgrad_job& j) {
-  return j.nja == 8 && j.nkb == 8 && j.lda == 128 && j.ldb == 128 && j.kw == 128 && j.M >= 1 && getenv("MGN_NO_LDS") == nullptr;
+  // (ldb == -128: B holds the forward's two-byte saves, split-bf16 kernel in the bf16 matrix mode only -- checked by mgn_wgrad_p)
+  return j.nja == 8 && j.nkb == 8 && j.lda == 128 && (j.ldb == 128 || j.ldb == -128) && j.kw == 128 && j.M >= 1 && getenv("MGN_NO_LDS") == nullptr;
 }
 
 int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, void* stream) {
@@ -2700,6 +2703,12 @@ int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, v
 int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, int precision, void* stream) {
   if (precision != 0 && precision != 1) return fail(1, "mgn_wgrad: precision must be 0 (fp32-grade) or 1 (bf16)");
   if (njobs < 1 || njobs > MGN_MAX_WGRAD_JOBS) return fail(1, "mgn_wgrad: njobs out of range");
+  for (int j = 0; j < njobs; ++j) {   // two-byte operands: only what k_wgrad_x6<1> reads
+    if (jobs[j].lda < 0 || jobs[j].ldb < 0) {
+      if (precision != 1 || !wgrad_job_full(jobs[j]) || getenv("MGN_FP32_MFMA") != nullptr)
+        return fail(1, "mgn_wgrad: a negative leading dimension (bf16 rows) needs precision 1 and a full 128 x 128 job with ld = -128");
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
   // two launches at most: full 128x128 jobs on the LDS-staged kernel, the others generic
   size_t ws_off = 0;

@@ -1016,6 +1016,11 @@ class ProcessorFunction(torch.autograd.Function):
         hubs = topo.begin_use()   # (a fresh lazily-built topology is hub-free for its first pass: Topology docstring)
         fuse_agg = x6 and _os.environ.get("MGN_NO_FUSED_AGG") is None and not hubs
         relu_bits = x6 and act == 0
+        # [r4] bf16 matrix mode on the packed path: the saved edge activations H1..H_{NL-1} are bf16 tensors in the reference (autocast
+        # Linear -> ReLU) and only the weight gradients read them back, so they are STORED as bf16 rows (precision 2 of mgn_mlp_fwd,
+        # ldb = -128 of mgn_wgrad): half the bytes of those saves on both sides, bit-identical gradients.  MGN_SAVE16=0: fp32 saves.
+        save16 = (relu_bits and prec == 1 and (split or spec.rope) and _os.environ.get("MGN_SAVE16", "1") != "0"
+                  and _os.environ.get("MGN_FUSED_BWD", "0") != "1")
         # ---- packed units of all rounds, one launch.  Per round:
         #   edge  [We0|e (, We0|x_dst, We0|x_src with RoPE), We1 .. We_{NL-1}]
         #   node  [Wn0|x, Wn0|agg, Wn1 .. Wn_{NL-1}, NEXT round's We0|x_dst, We0|x_src (split)]
@@ -1069,7 +1074,7 @@ class ProcessorFunction(torch.autograd.Function):
             He = Hn = Me = Mn = Ze = Zn = None
             Ue = Re = Un = Rn = None
             if save:
-                He = [torch.empty(E, H, **f) for _ in range(NL - 1)]
+                He = [torch.empty(E, H, dtype=torch.bfloat16 if save16 else torch.float32, device=dev) for _ in range(NL - 1)]
                 Hn = [torch.empty(Nn, H, **f) for _ in range(NL - 1)]
                 if spec.layer_norm:
                     Ue, Re = torch.empty(E, H, **f), torch.empty(E, **f)
@@ -1096,7 +1101,7 @@ class ProcessorFunction(torch.autograd.Function):
                     part = torch.empty((M + 15) // 16, 2, H, **f)
                     seg = (topo.dst_s[sl], rowptr, agg, part)
                 y = m[sl] if m is not None else None
-                common = dict(saveM=sv(Me), saveZ=sv(Ze), act=act, precision=prec, seg=seg)
+                common = dict(saveM=sv(Me), saveZ=sv(Ze), act=act, precision=2 if (save16 and He is not None) else prec, seg=seg)
                 if spec.rope:
                     mlp_fwd(M, H, [(e[sl], None, H), (x, topo.dst_s[sl], H), (xj[sl], None, H)], We, be, se, H, e[sl], e_new[sl], y,
                             sv(He), Ue[sl] if Ue is not None else None, Re[sl] if Re is not None else None,
@@ -1182,6 +1187,7 @@ class ProcessorFunction(torch.autograd.Function):
         ctx.rerun = (run_round, project, pk if x6 else None) if recompute else None
         ctx.topo, ctx.L, ctx.saved_acts, ctx.prec, ctx.spec, ctx.halo = topo, L, (saved if need else None), prec, spec, halo
         ctx.aux = (pos, phi, rope_inv_freq, x6, split)
+        ctx.save16 = save16
         ctx.save_for_backward(*P)  # version-checked by autograd (an optimiser step in between is an error)
         return x, e
 
@@ -1401,7 +1407,7 @@ class ProcessorFunction(torch.autograd.Function):
                 njobs.append((Ss[:Nn], H, nb, x, H, nb, H, gWe[0], 2 * H, 3 * H))
             for l in range(1, NL):
                 njobs.append((dZn[l], H, nb, Hn[l - 1], H, nb, H, gWn[l], 0, H, gbn[l]))
-                ejobs.append((dZe[l], H, nb, He[l - 1], H, nb, H, gWe[l], 0, H, gbe[l]))
+                ejobs.append((dZe[l], H, nb, He[l - 1], -H if He[l - 1].dtype == torch.bfloat16 else H, nb, H, gWe[l], 0, H, gbe[l]))
             if spec.gate:
                 gWg, gbg, gpos = g[2 * k_], g[2 * k_ + 1], g[2 * k_ + 2]
                 njobs.append((dG, H, nb, x, H, nb, H, gWg, 0, H, gbg))

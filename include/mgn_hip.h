@@ -148,7 +148,11 @@ typedef struct {
    * and every stored tensor stay fp32) -- the semantic of the reference under bf16-mixed
    * autocast (train.py:74-78,268-293), BASELINE configs[2].  [r4] Off the packed path (H != 128, ragged widths: the generic
    * kernels) precision = 1 rounds the row operands and every layer's result to bf16 in the kernel; the caller passes W[] / b[]
-   * already rounded (mgn_mlp_bwd: WT[] / WT0[] likewise, and every dZ it writes is a bf16 value). */
+   * already rounded (mgn_mlp_bwd: WT[] / WT0[] likewise, and every dZ it writes is a bf16 value).
+   * [r4] precision = 2 (packed path only): as 1, and saveH[l] receives TWO-BYTE rows -- the activation as the bf16 tensor the
+   * reference's autocast holds, bit for bit what precision 1 would round at its next use -- 128 bf16 values per row in the
+   * kernel's operand order (K-slice p at element 32 p; inside it, for g = 0..3: features 32p + 4g .. + 3, then
+   * 32p + 16 + 4g .. + 3).  Only mgn_wgrad_p reads them back (ldb = -128). */
   int precision;
   /* out = act(z) instead of z (generic ragged-input kernel only; no norm / residual): lets an
    * encoder run its narrow first layer stand-alone and the three full layers on the packed path
@@ -261,7 +265,9 @@ int mgn_colred_batch(int n, const mgn_colred_job* jobs, void* stream);
  * (B columns >= kw read as zero).  A is [M,lda], B is [M,ldb], dW is [16*nja, ldw].
  * db (optional, [16*nja]): db[j] = sum_m A[m, j] -- the bias gradient of the same Linear,
  * a by-product of reading A (= dZ) here.
- * ws: device scratch of mgn_wgrad_workspace_bytes(njobs, jobs) bytes. */
+ * ws: device scratch of mgn_wgrad_workspace_bytes(njobs, jobs) bytes.
+ * [r4] ldb == -128 (mgn_wgrad_p with precision 1, full 128 x 128 jobs only): B points to the TWO-BYTE saves a forward launch with
+ * precision == 2 wrote (rows of 128 bf16 values in that launch's packed feature order, see mgn_mlp_fwd_args.precision). */
 typedef struct {
   const float* A; const float* B; float* dW;
   int64_t M;

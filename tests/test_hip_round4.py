@@ -1,0 +1,55 @@
+"""GPU: round-4 additions on the packed path's bf16 matrix mode -- two-byte saved activations / gradients rows (precision 2 of
+mgn_mlp_fwd / mgn_mlp_bwd, negative leading dimensions of mgn_wgrad) against the fp32-stored form of the same mode."""
+import os
+
+import pytest
+import torch
+
+import recipe as R
+import graph_physics_amd as gp
+from graph_physics_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dev, save16, variant):
+    old = os.environ.get("MGN_SAVE16")
+    os.environ["MGN_SAVE16"] = "1" if save16 else "0"
+    ops.set_matrix_precision("bf16")
+    try:
+        g = gp.cylinder_batch(5, 1885, 3).to(dev)            # E ~ 56 k rows: several tiles per workgroup, ragged tails
+        L, H = 3, 128
+        kw = dict(use_rope_embeddings=True, rope_pos_dimension=2) if variant == "rope" else {}
+        net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H, **kw).to(dev)
+        net.load_state_dict(R.variant_params(net.state_dict(), 77))
+        x_in, e_in = R.randn((g.x.shape[0], 11), 5).to(dev), R.randn((g.edge_index.shape[1], 3), 6).to(dev)
+        out = net(gp.Graph(x=x_in, edge_attr=e_in, edge_index=g.edge_index, pos=g.pos))
+        (out * R.randn(tuple(out.shape), 8).to(dev)).sum().backward()
+        return {"out": out.detach().clone(), **{k: p.grad.clone() for k, p in net.named_parameters()}}
+    finally:
+        ops.set_matrix_precision("fp32")
+        if old is None:
+            os.environ.pop("MGN_SAVE16", None)
+        else:
+            os.environ["MGN_SAVE16"] = old
+
+
+@pytest.mark.parametrize("variant", ["default", "rope"])
+def test_two_byte_saves_reproduce_the_fp32_stored_bf16_mode(dev, variant):
+    """bf16 matrix mode: what is saved for the backward pass are bf16 tensors in the reference (autocast Linear -> ReLU outputs, the
+    gradients of bf16 Linear outputs; train.py:74-78), and the engine's weight-gradient kernel rounds them to bf16 at its load anyway
+    -- storing them in two bytes must not change the forward and changes the gradients only where a value is now rounded BEFORE a
+    sum that used to see it unrounded (bias gradients, the scatter of dZ0)."""
+    a, b = _run(dev, False, variant), _run(dev, True, variant)
+    assert torch.equal(a["out"], b["out"])
+    worst = 0.0
+    for k in a:
+        if k == "out":
+            continue
+        assert torch.isfinite(b[k]).all(), k
+        err = float((a[k] - b[k]).abs().max() / a[k].abs().max().clamp_min(1e-30))
+        worst = max(worst, err)
+        if k.endswith("weight") and ("edge_block" in k) and not k.endswith("0.weight"):
+            pass
+        assert err < 4e-3, (k, err)     # a bf16 ulp (2^-8) where a rounded value enters a sum
+    print(f"two-byte saves vs fp32 saves ({variant}): worst relative gradient difference {worst:.2e}")
