@@ -2247,18 +2247,18 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
                          a.n_din == 1 && a.din_resid[0] != nullptr && a.scale != nullptr && a.R != nullptr && a.U != nullptr &&
                          a.dOut2 != nullptr && a.idx2 != nullptr;
     if (sb_edge) {
-      if (a.precision == 1)
+      if (a.precision >= 1)
         hipLaunchKernelGGL((k_mlp_bwd_x6<1, false, 0, false, SbEdge>), dim3(p.grid), dim3(256), lds, s, a);
       else
         hipLaunchKernelGGL((k_mlp_bwd_x6<6, false, 0, false, SbEdge>), dim3(p.grid), dim3(256), lds, s, a);
     } else if (a.seg_out != nullptr) {
       hipLaunchKernelGGL((k_mlp_bwd_x6<6, false, 0, true>), dim3(p.grid), dim3(256), lds, s, a);
     } else if (a.act == MGN_ACT_SILU) {
-      if (a.precision == 1)
+      if (a.precision >= 1)
         hipLaunchKernelGGL((k_mlp_bwd_x6<1, false, 1>), dim3(p.grid), dim3(256), lds, s, a);
       else
         hipLaunchKernelGGL((k_mlp_bwd_x6<6, false, 1>), dim3(p.grid), dim3(256), lds, s, a);
-    } else if (a.precision == 1) {
+    } else if (a.precision >= 1) {
       if (front)
         hipLaunchKernelGGL((k_mlp_bwd_x6<1, true, 0>), dim3(p.grid), dim3(256), lds, s, a);
       else
@@ -2553,7 +2553,9 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   if (int rc = check_mlp_common(a.H, a.NL, a.out_w, "mgn_mlp_bwd")) return rc;
   if (a.n_din < 0 || a.n_din > MGN_MAX_PHASES) return fail(1, "mgn_mlp_bwd: n_din out of range");
   if (a.n_din > 1 && a.dZ[0] == nullptr) return fail(1, "mgn_mlp_bwd: n_din > 1 needs dZ[0]");
-  if (a.precision != 0 && a.precision != 1) return fail(1, "mgn_mlp_bwd: precision must be 0 (fp32-grade) or 1 (bf16)");
+  if (a.precision < 0 || a.precision > 2) return fail(1, "mgn_mlp_bwd: precision must be 0 (fp32-grade), 1 (bf16) or 2 (bf16, two-byte dZ[1..])");
+  if (a.precision == 2 && (!bwd_x6(a) || !plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds || a.act != MGN_ACT_RELU || a.n_front != 0))
+    return fail(1, "mgn_mlp_bwd: precision 2 (two-byte dZ rows) needs the packed split-bf16 path (H = 128, wpk, Ms), ReLU and no front stage");
   if (a.act != MGN_ACT_RELU && a.act != MGN_ACT_SILU && a.act != MGN_ACT_GELU) return fail(1, "mgn_mlp_bwd: act must be MGN_ACT_RELU, _SILU or _GELU");
   if (a.act == MGN_ACT_GELU && (a.wpk[0] != nullptr || a.precision != 0 || a.seg_out != nullptr || a.n_front != 0))
     return fail(1, "mgn_mlp_bwd: GELU runs on the generic kernels only");
@@ -2567,7 +2569,7 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   }
   if (a.n_front != 0 && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
     return fail(1, "mgn_mlp_bwd: the front stage needs the packed split-bf16 path (H = 128, full widths, wpk, Ms, no dOut2)");
-  if (a.precision == 1 && plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && !bwd_x6(a))
+  if (a.precision >= 1 && plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && !bwd_x6(a))
     return fail(1, "mgn_mlp_bwd: at H = 128 with full widths the bf16 matrix mode needs the packed split-bf16 path (wpk, Ms); other shapes run it on the generic kernels");
   if (a.seg_out != nullptr && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
     return fail(1, "mgn_mlp_bwd: the fused segment sum of dZ[0] needs the packed split-bf16 path (fp32-grade, ReLU, dZ[0], no front stage)");
@@ -2693,7 +2695,7 @@ size_t mgn_wgrad_workspace_bytes(int njobs, const mgn_wgrad_job* jobs) {
 
 static bool wgrad_job_full(const mgn_wgrad_job& j) {
   // (ldb == -128: B holds the forward's two-byte saves, split-bf16 kernel in the bf16 matrix mode only -- checked by mgn_wgrad_p)
-  return j.nja == 8 && j.nkb == 8 && j.lda == 128 && (j.ldb == 128 || j.ldb == -128) && j.kw == 128 && j.M >= 1 && getenv("MGN_NO_LDS") == nullptr;
+  return j.nja == 8 && j.nkb == 8 && (j.lda == 128 || j.lda == -128) && (j.ldb == 128 || j.ldb == -128) && j.kw == 128 && j.M >= 1 && getenv("MGN_NO_LDS") == nullptr;
 }
 
 int mgn_wgrad(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes, void* stream) {

@@ -1215,7 +1215,9 @@ class ProcessorFunction(torch.autograd.Function):
         empty = (E == 0 or Nn == 0)  # some launches return early at M == 0 and would leave their outputs unwritten
         mk = torch.zeros if empty else torch.empty
         dZn = [mk(Nn, H, **f) for _ in range(NL)]
-        dZe = [mk(E, H, **f) for _ in range(NL)]
+        d16 = bool(getattr(ctx, "save16", False)) and x6
+        # (two-byte rows of dZe[1..]: written by the chain with precision 2, read by the weight gradients with lda = -128)
+        dZe = [mk(E, H, **f)] + [mk(E, H, dtype=torch.bfloat16, device=dev) if d16 else mk(E, H, **f) for _ in range(1, NL)]
         dAgg, Sd, Ss = mk(Nn, H, **f), mk(N, H, **f), mk(N, H, **f)
         # Weight gradients on a SIDE STREAM (MGN_WGRAD_STREAM=1): dW of round i depends on nothing the rest of
         # the backward pass waits for, so its launch can fill the bubbles of the main stream (launch gaps, the
@@ -1226,7 +1228,7 @@ class ProcessorFunction(torch.autograd.Function):
         # while its weight-gradient launch may still read them on the side stream)
         if _os.environ.get("MGN_WGRAD_STREAM") is not None and halo is None and not empty and not spec.gate and ctx.rerun is None:
             side = _side_stream(dev)
-            wsets = [(dZn, dZe, Sd, Ss), ([mk(Nn, H, **f) for _ in range(NL)], [mk(E, H, **f) for _ in range(NL)], mk(N, H, **f), mk(N, H, **f))]
+            wsets = [(dZn, dZe, Sd, Ss), ([mk(Nn, H, **f) for _ in range(NL)], [torch.empty_like(t) for t in dZe], mk(N, H, **f), mk(N, H, **f))]
             wdone = [None, None]
             main = torch.cuda.current_stream(dev)
         dx_buf, de_buf = [mk(Nn, H, **f), mk(Nn, H, **f)], [mk(E, H, **f), mk(E, H, **f)]
@@ -1366,7 +1368,7 @@ class ProcessorFunction(torch.autograd.Function):
                     part_b = torch.empty((E + 15) // 16, 2, H, **f)
                     seg = (topo.dst_s, topo.rowptr_dst, Sd, part_b)
                 mlp_bwd(E, H, NL, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
-                        [None] * NL, gse, wpk=ke, Ms=S["Me"], Zs=S["Ze"], act=act, precision=prec, defer=deferred, seg=seg)
+                        [None] * NL, gse, wpk=ke, Ms=S["Me"], Zs=S["Ze"], act=act, precision=2 if d16 else prec, defer=deferred, seg=seg)
                 if fuse_sd:
                     seg_fix(topo.rowptr_dst, part_b, Sd)
             else:
@@ -1407,7 +1409,8 @@ class ProcessorFunction(torch.autograd.Function):
                 njobs.append((Ss[:Nn], H, nb, x, H, nb, H, gWe[0], 2 * H, 3 * H))
             for l in range(1, NL):
                 njobs.append((dZn[l], H, nb, Hn[l - 1], H, nb, H, gWn[l], 0, H, gbn[l]))
-                ejobs.append((dZe[l], H, nb, He[l - 1], -H if He[l - 1].dtype == torch.bfloat16 else H, nb, H, gWe[l], 0, H, gbe[l]))
+                ejobs.append((dZe[l], -H if dZe[l].dtype == torch.bfloat16 else H, nb, He[l - 1], -H if He[l - 1].dtype == torch.bfloat16 else H, nb, H,
+                              gWe[l], 0, H, gbe[l]))
             if spec.gate:
                 gWg, gbg, gpos = g[2 * k_], g[2 * k_ + 1], g[2 * k_ + 2]
                 njobs.append((dG, H, nb, x, H, nb, H, gWg, 0, H, gbg))

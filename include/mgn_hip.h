@@ -220,7 +220,8 @@ typedef struct {
   /* Ms[l-1] = saveM[l-1] of the forward launch (ReLU masks as bits).  Required by the split-bf16
    * kernel (it does not read Hs); ignored by the fp32 kernels. */
   const uint32_t* Ms[MGN_MAX_LAYERS];
-  int precision;                    /* as in mgn_mlp_fwd_args */
+  int precision;                    /* as in mgn_mlp_fwd_args; [r4] 2: as 1, and dZ[l] for l >= 1 are written as TWO-BYTE rows in the
+                                     * forward's packed feature order (dZ[0] stays fp32); packed path, ReLU, no front stage */
   /* Optional front stage (split-bf16 kernel only; dOut / dOut2 are then ignored):
    *   dY[m] = (front_resid ? front_resid[m] : 0) + sum_{p < n_front} Wf_p . front_src[p][m]
    * with Wf_p = wpk[p] (packed, [H,H]); dY is stored to front_out (if not NULL) and feeds the
@@ -266,8 +267,9 @@ int mgn_colred_batch(int n, const mgn_colred_job* jobs, void* stream);
  * db (optional, [16*nja]): db[j] = sum_m A[m, j] -- the bias gradient of the same Linear,
  * a by-product of reading A (= dZ) here.
  * ws: device scratch of mgn_wgrad_workspace_bytes(njobs, jobs) bytes.
- * [r4] ldb == -128 (mgn_wgrad_p with precision 1, full 128 x 128 jobs only): B points to the TWO-BYTE saves a forward launch with
- * precision == 2 wrote (rows of 128 bf16 values in that launch's packed feature order, see mgn_mlp_fwd_args.precision). */
+ * [r4] ldb == -128 / lda == -128 (mgn_wgrad_p with precision 1, full 128 x 128 jobs only): B / A points to TWO-BYTE rows -- the
+ * saves a forward launch with precision == 2 wrote, the dZ[1..] rows of a backward launch with precision == 2 (rows of 128 bf16
+ * values in those launches' packed feature order, see mgn_mlp_fwd_args.precision). */
 typedef struct {
   const float* A; const float* B; float* dW;
   int64_t M;
