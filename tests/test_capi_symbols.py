@@ -68,3 +68,24 @@ def test_host_side_queries_need_no_gpu():
     a.M, a.H, a.NL, a.nphase, a.out_w = 0, 100, 4, 1, 100
     assert lib.mgn_mlp_fwd(ctypes.byref(a), None) == 1
     assert b"H must be" in lib.mgn_last_error()
+
+
+def test_two_byte_operands_are_refused_outside_the_bf16_packed_path():
+    """[r4] negative leading dimensions of mgn_wgrad_job (two-byte rows) and precision 2 of mgn_mlp_fwd are taken only where a kernel
+    reads / writes that form: validated before any launch, so this runs without a GPU."""
+    from graph_physics_amd import _capi
+
+    lib = _capi.lib()
+    job = (_capi.WgradJob * 1)()
+    job[0].M, job[0].lda, job[0].ldb, job[0].ldw, job[0].nja, job[0].nkb, job[0].kw = 1000, -128, 128, 128, 8, 8, 128
+    assert lib.mgn_wgrad_p(1, job, None, 0, 0, None) == 1           # fp32-grade precision: no two-byte operand
+    assert b"negative leading dimension" in lib.mgn_last_error()
+    job[0].lda, job[0].nja = -64, 4                                   # not a full 128 x 128 job
+    assert lib.mgn_wgrad_p(1, job, None, 0, 1, None) == 1
+    a = _capi.MlpFwdArgs()
+    a.M, a.H, a.NL, a.nphase, a.out_w, a.precision = 100, 128, 4, 1, 128, 2   # no packed weights: not the split-bf16 path
+    a.kw[0] = 128
+    assert lib.mgn_mlp_fwd(ctypes.byref(a), None) == 1
+    assert b"precision 2" in lib.mgn_last_error()
+    a.precision = 3
+    assert lib.mgn_mlp_fwd(ctypes.byref(a), None) == 1
