@@ -183,6 +183,7 @@ SYMBOLS = {
     "mgn_segsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "mgn_seg_fix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mgn_segsum2": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_void_p]),
+    "mgn_segsum2_b16": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_void_p]),
     "mgn_mlp_fwd": (C.c_int, [C.POINTER(MlpFwdArgs), C.c_void_p]),
     "mgn_mlp_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "mgn_mlp_bwd": (C.c_int, [C.POINTER(MlpBwdArgs), C.c_void_p]),

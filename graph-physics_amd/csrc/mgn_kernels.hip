@@ -1800,7 +1800,7 @@ __global__ void __launch_bounds__(256) k_segsum(const float* __restrict__ src, c
 
 // Two segment sums of the SAME source in one launch (the backward scatter of the first-layer
 // gradients onto destination and source nodes): workgroups [0, half) run job 0, the rest job 1.
-template <int HB>
+template <int HB, bool SRC16 = false>
 __global__ void __launch_bounds__(256) k_segsum2(const float* __restrict__ src, const int32_t* __restrict__ rowptr0,
                                                  const int32_t* __restrict__ perm0, float* __restrict__ out0,
                                                  const int32_t* __restrict__ rowptr1, const int32_t* __restrict__ perm1,
@@ -1824,7 +1824,14 @@ __global__ void __launch_bounds__(256) k_segsum2(const float* __restrict__ src, 
       const int kk = k + u;
       if (kk < end) {
         const long row = perm ? (long)perm[kk] : (long)kk;
-        v[u] = ld4(base + row * H);
+        if constexpr (SRC16) {   // two-byte rows in the packed feature order of the chain kernels (mgn_mlp_fwd_args.precision): features
+                                 // 4l .. 4l + 3 are the four bf16 values at element 32 (l >> 3) + 8 (l & 3) + 4 ((l >> 2) & 1)
+          const uint2 t = *(const uint2*)((const uint16_t*)src + row * H + 32 * (l >> 3) + 8 * (l & 3) + 4 * ((l >> 2) & 1));
+          v[u] = f32x4{__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xffff0000u),
+                       __builtin_bit_cast(float, t.y << 16), __builtin_bit_cast(float, t.y & 0xffff0000u)};
+        } else {
+          v[u] = ld4(base + row * H);
+        }
       } else {
         v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -2494,6 +2501,17 @@ int mgn_segsum2(const float* src, const int32_t* rowptr0, const int32_t* perm0, 
   return check_launch("mgn_segsum2");
 }
 
+int mgn_segsum2_b16(const uint16_t* src, const int32_t* rowptr0, const int32_t* perm0, float* out0, const int32_t* rowptr1,
+                    const int32_t* perm1, float* out1, int64_t N, int H, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) return 0;
+  if (H != 128) return fail(1, "mgn_segsum2_b16: H must be 128");
+  const unsigned half = (unsigned)((N * (H / 4) + 255) / 256);
+  hipLaunchKernelGGL((k_segsum2<8, true>), dim3(2 * half), dim3(256), 0, s, (const float*)src, rowptr0, perm0, out0, rowptr1, perm1, out1,
+                     (long)N, half);
+  return check_launch("mgn_segsum2_b16");
+}
+
 static int check_mlp_common(int H, int NL, int out_w, const char* who) {
   if (!(H == 16 || H == 32 || H == 64 || H == 128)) return fail(1, "H must be 16, 32, 64 or 128");
   if (NL < 1 || NL > MGN_MAX_LAYERS) return fail(1, "NL out of range");
@@ -2553,8 +2571,8 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   if (int rc = check_mlp_common(a.H, a.NL, a.out_w, "mgn_mlp_bwd")) return rc;
   if (a.n_din < 0 || a.n_din > MGN_MAX_PHASES) return fail(1, "mgn_mlp_bwd: n_din out of range");
   if (a.n_din > 1 && a.dZ[0] == nullptr) return fail(1, "mgn_mlp_bwd: n_din > 1 needs dZ[0]");
-  if (a.precision < 0 || a.precision > 2) return fail(1, "mgn_mlp_bwd: precision must be 0 (fp32-grade), 1 (bf16) or 2 (bf16, two-byte dZ[1..])");
-  if (a.precision == 2 && (!bwd_x6(a) || !plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds || a.act != MGN_ACT_RELU || a.n_front != 0))
+  if (a.precision < 0 || a.precision > 3) return fail(1, "mgn_mlp_bwd: precision must be 0 (fp32-grade), 1 (bf16), 2 (bf16, two-byte dZ[1..]) or 3 (dZ[0] too)");
+  if (a.precision >= 2 && (!bwd_x6(a) || !plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds || a.act != MGN_ACT_RELU || a.n_front != 0))
     return fail(1, "mgn_mlp_bwd: precision 2 (two-byte dZ rows) needs the packed split-bf16 path (H = 128, wpk, Ms), ReLU and no front stage");
   if (a.act != MGN_ACT_RELU && a.act != MGN_ACT_SILU && a.act != MGN_ACT_GELU) return fail(1, "mgn_mlp_bwd: act must be MGN_ACT_RELU, _SILU or _GELU");
   if (a.act == MGN_ACT_GELU && (a.wpk[0] != nullptr || a.precision != 0 || a.seg_out != nullptr || a.n_front != 0))

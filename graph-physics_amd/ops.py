@@ -373,8 +373,9 @@ def seg_fix(rowptr: torch.Tensor, part: torch.Tensor, out: torch.Tensor):
 def segsum2(src: torch.Tensor, rowptr0, perm0, out0, rowptr1, perm1, out1):
     """two segment sums of the same source rows in one launch (H = 128)"""
     n = rowptr0.numel() - 1
+    fn = _capi.lib().mgn_segsum2_b16 if src.dtype == torch.bfloat16 else _capi.lib().mgn_segsum2   # (two-byte rows: dZ[0] of precision 3)
     with torch.cuda.device(src.device):
-        rc = _capi.lib().mgn_segsum2(_ptr(src), _ptr(rowptr0), _ptr(perm0), _ptr(out0), _ptr(rowptr1), _ptr(perm1), _ptr(out1),
+        rc = fn(_ptr(src), _ptr(rowptr0), _ptr(perm0), _ptr(out0), _ptr(rowptr1), _ptr(perm1), _ptr(out1),
                                      n, src.shape[1], _stream(src.device))
     _capi.check(rc, "mgn_segsum2")
 
@@ -1217,7 +1218,10 @@ class ProcessorFunction(torch.autograd.Function):
         dZn = [mk(Nn, H, **f) for _ in range(NL)]
         d16 = bool(getattr(ctx, "save16", False)) and x6
         # (two-byte rows of dZe[1..]: written by the chain with precision 2, read by the weight gradients with lda = -128)
-        dZe = [mk(E, H, **f)] + [mk(E, H, dtype=torch.bfloat16, device=dev) if d16 else mk(E, H, **f) for _ in range(1, NL)]
+        # dZe[0] too where its only other reader is the two-segment-sum launch (default blocks, no hubs, no fused destination scatter)
+        z16 = (d16 and not spec.rope and H == 128 and not topo.has_hubs and _os.environ.get("MGN_FUSED_SD") is None
+               and _os.environ.get("MGN_SAVE16", "1") != "2")
+        dZe = [mk(E, H, dtype=torch.bfloat16, device=dev) if (d16 and (l > 0 or z16)) else mk(E, H, **f) for l in range(NL)]
         dAgg, Sd, Ss = mk(Nn, H, **f), mk(N, H, **f), mk(N, H, **f)
         # Weight gradients on a SIDE STREAM (MGN_WGRAD_STREAM=1): dW of round i depends on nothing the rest of
         # the backward pass waits for, so its launch can fill the bubbles of the main stream (launch gaps, the
@@ -1368,7 +1372,7 @@ class ProcessorFunction(torch.autograd.Function):
                     part_b = torch.empty((E + 15) // 16, 2, H, **f)
                     seg = (topo.dst_s, topo.rowptr_dst, Sd, part_b)
                 mlp_bwd(E, H, NL, de, dAgg, topo.dst_s, H, Ue, Re, se, He, WTe, dZe, [(WT0e_e, de, de_new)],
-                        [None] * NL, gse, wpk=ke, Ms=S["Me"], Zs=S["Ze"], act=act, precision=2 if d16 else prec, defer=deferred, seg=seg)
+                        [None] * NL, gse, wpk=ke, Ms=S["Me"], Zs=S["Ze"], act=act, precision=(3 if z16 else 2) if d16 else prec, defer=deferred, seg=seg)
                 if fuse_sd:
                     seg_fix(topo.rowptr_dst, part_b, Sd)
             else:
@@ -1397,7 +1401,7 @@ class ProcessorFunction(torch.autograd.Function):
                 back = halo.start_backward(Ss)
             # weight gradients: dW = dZ^T X
             # (A = dZ, B = layer input, dW slab[, db = bias gradient as a by-product])
-            ejobs = [(dZe[0], H, nb, e, H, nb, H, gWe[0], 0, 3 * H, gbe[0])]
+            ejobs = [(dZe[0], -H if dZe[0].dtype == torch.bfloat16 else H, nb, e, H, nb, H, gWe[0], 0, 3 * H, gbe[0])]
             if spec.rope:
                 ejobs.append((dZe[0], H, nb, S["xj"], H, nb, H, gWe[0], 2 * H, 3 * H))
             njobs = [

@@ -88,6 +88,10 @@ int mgn_seg_fix(const int32_t* rowptr, const float* part, float* out, int64_t N,
  * over (rowptr1, perm1) -- the backward scatter onto destination and source nodes. */
 int mgn_segsum2(const float* src, const int32_t* rowptr0, const int32_t* perm0, float* out0,
                 const int32_t* rowptr1, const int32_t* perm1, float* out1, int64_t N, int H, void* stream);
+/* [r4] the same over TWO-BYTE source rows: dZ[0] of a backward launch with precision == 3 (128 bf16 values per row in the chain
+ * kernels' packed feature order, mgn_mlp_fwd_args.precision); outputs fp32 in the true feature order. */
+int mgn_segsum2_b16(const uint16_t* src, const int32_t* rowptr0, const int32_t* perm0, float* out0,
+                    const int32_t* rowptr1, const int32_t* perm1, float* out1, int64_t N, int H, void* stream);
 
 /* ------------------------------------------------------------ fused MLP forward
  * For each row m in [0,M):
@@ -221,7 +225,8 @@ typedef struct {
    * kernel (it does not read Hs); ignored by the fp32 kernels. */
   const uint32_t* Ms[MGN_MAX_LAYERS];
   int precision;                    /* as in mgn_mlp_fwd_args; [r4] 2: as 1, and dZ[l] for l >= 1 are written as TWO-BYTE rows in the
-                                     * forward's packed feature order (dZ[0] stays fp32); packed path, ReLU, no front stage */
+                                     * forward's packed feature order (dZ[0] stays fp32); 3: dZ[0] too (for mgn_segsum2_b16 / lda = -128); packed path, ReLU,
+                                     * no front stage */
   /* Optional front stage (split-bf16 kernel only; dOut / dOut2 are then ignored):
    *   dY[m] = (front_resid ? front_resid[m] : 0) + sum_{p < n_front} Wf_p . front_src[p][m]
    * with Wf_p = wpk[p] (packed, [H,H]); dY is stored to front_out (if not NULL) and feeds the

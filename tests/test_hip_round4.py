@@ -49,7 +49,8 @@ def test_two_byte_saves_reproduce_the_fp32_stored_bf16_mode(dev, variant):
         assert torch.isfinite(b[k]).all(), k
         err = float((a[k] - b[k]).abs().max() / a[k].abs().max().clamp_min(1e-30))
         worst = max(worst, err)
-        if k.endswith("weight") and ("edge_block" in k) and not k.endswith("0.weight"):
-            pass
-        assert err < 4e-3, (k, err)     # a bf16 ulp (2^-8) where a rounded value enters a sum
+        # a few bf16 ulps (2^-8) where a value is now rounded before it enters a sum: bias gradients (column sums of dZ), and -- with dZ0
+        # in two bytes as well -- everything downstream of the node scatter.  Both sides are the SAME bf16-mixed semantic up to where
+        # the reference's own bf16 gradient tensors are rounded; the oracle-side bars are tests/test_hip_configs.py (plate, bf16).
+        assert err < 1e-2, (k, err)
     print(f"two-byte saves vs fp32 saves ({variant}): worst relative gradient difference {worst:.2e}")
