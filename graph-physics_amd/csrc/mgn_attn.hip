@@ -221,7 +221,8 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
                                                      const float* __restrict__ y, const float* __restrict__ lse, const float* __restrict__ dy,
                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
                                                      float scale, float sd, float* __restrict__ dq, float* __restrict__ a_out,
-                                                     float* __restrict__ ds_out, AttnLd ld) {
+                                                     float* __restrict__ ds_out, AttnLd ld, uint16_t* __restrict__ q16,
+                                                     uint16_t* __restrict__ g16) {
   constexpr int H = 4 * LPR;
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
@@ -232,6 +233,11 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
   if (B16) gv = make_float4(bf16r(gv.x), bf16r(gv.y), bf16r(gv.z), bf16r(gv.w));
   const float qq[4] = {qscaled<B16>(qv.x, scale, sd), qscaled<B16>(qv.y, scale, sd), qscaled<B16>(qv.z, scale, sd), qscaled<B16>(qv.w, scale, sd)};
   const float g[4] = {gv.x, gv.y, gv.z, gv.w}, ls[4] = {lv.x, lv.y, lv.z, lv.w};
+  if (B16 && q16 != nullptr) {   // the column pass gathers these rows per edge: hand it the bf16 tensors themselves (both ARE bf16 values)
+    auto pk2 = [](float a_, float b_) { return (__builtin_bit_cast(unsigned, a_) >> 16) | (__builtin_bit_cast(unsigned, b_) & 0xffff0000u); };
+    *(uint2*)(q16 + (size_t)i * H + 4 * l) = make_uint2(pk2(qq[0], qq[1]), pk2(qq[2], qq[3]));
+    *(uint2*)(g16 + (size_t)i * H + 4 * l) = make_uint2(pk2(g[0], g[1]), pk2(g[2], g[3]));
+  }
   float D[4] = {gv.x * yv.x, gv.y * yv.y, gv.z * yv.z, gv.w * yv.w};
   head_reduce<LPR, GS>(D, NH);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -287,7 +293,8 @@ template <int LPR, int GS, bool B16>
 __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ q, const float* __restrict__ dy, const float* __restrict__ a_in,
                                                      const float* __restrict__ ds_in, const int32_t* __restrict__ cptr,
                                                      const int32_t* __restrict__ cperm, const int32_t* __restrict__ crow, long N, int NH,
-                                                     float scale, float sd, float* __restrict__ dk, float* __restrict__ dv, AttnLd ld) {
+                                                     float scale, float sd, float* __restrict__ dk, float* __restrict__ dv, AttnLd ld,
+                                                     const uint16_t* __restrict__ q16, const uint16_t* __restrict__ g16) {
   constexpr int H = 4 * LPR;
   const long j = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
@@ -313,7 +320,11 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
     };
     auto fetch = [&](int i_, int e_) -> Row {
       Row r;
-      r.q = ldrow(q, (size_t)i_, ld.q, l), r.g = ldrow(dy, (size_t)i_, H, l);
+      if (B16 && q16 != nullptr) {   // bf16(q / sd) and bf16(dy) as the row pass stored them: half the gathered bytes
+        r.q = ldkv<true>(q16, (size_t)i_, H, l), r.g = ldkv<true>(g16, (size_t)i_, H, l);
+      } else {
+        r.q = ldrow(q, (size_t)i_, ld.q, l), r.g = ldrow(dy, (size_t)i_, H, l);
+      }
       heads(ds_in, (size_t)e_, r.ds), heads(a_in, (size_t)e_, r.aw);
       return r;
     };
@@ -326,7 +337,10 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
       if (t + 2 < t1) nx2 = fetch(i2, e2);
       if (t + 3 < t1) i2 = crow[t + 3], e2 = cperm[t + 3];
       float qr[4] = {cur.q.x, cur.q.y, cur.q.z, cur.q.w}, gr[4] = {cur.g.x, cur.g.y, cur.g.z, cur.g.w};
-      if (B16) {  // the query the scores were formed from (float(bf16(q / sd)) * sd) and the bf16 dy
+      if (B16 && q16 != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qr[r] *= sd;   // (the stored rows are bf16(q / sd) and bf16(dy) already)
+      } else if (B16) {  // the query the scores were formed from (float(bf16(q / sd)) * sd) and the bf16 dy
         if (sd_pow2) {  // a power-of-two sqrt(D) (head widths 4, 16, 64): q * (1 / sd) IS q / sd, without four divisions per edge
 #pragma unroll
           for (int r = 0; r < 4; ++r) qr[r] = bf16r(qr[r] * scale) * sd, gr[r] = bf16r(gr[r]);
@@ -451,12 +465,21 @@ static int attn_bwd_any(bool b16, const float* q, const void* k, const void* v, 
   const float sd = sqrtf((float)(H / num_heads)), scale = 1.0f / sd;
   float* a_e = ws;
   float* ds_e = ws + (size_t)E * num_heads;
+  // bf16 mode with N * H more floats of workspace: the row pass leaves bf16(q / sd) and bf16(dy) as two-byte rows for the column pass
+  uint16_t* q16 = nullptr;
+  uint16_t* g16 = nullptr;
+  if (b16 && ws_bytes >= ((size_t)2 * E * num_heads + (size_t)N * H) * sizeof(float)) {
+    q16 = (uint16_t*)(ws + (size_t)2 * E * num_heads);
+    g16 = q16 + (size_t)N * H;
+  }
   if (b16) {
-    ATTN_DISPATCH(k_attn_bwd_row, true, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e, ld);
-    ATTN_DISPATCH(k_attn_bwd_col, true, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv, ld);
+    ATTN_DISPATCH(k_attn_bwd_row, true, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e, ld, q16, g16);
+    ATTN_DISPATCH(k_attn_bwd_col, true, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv, ld,
+                  (const uint16_t*)q16, (const uint16_t*)g16);
   } else {
-    ATTN_DISPATCH(k_attn_bwd_row, false, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e, ld);
-    ATTN_DISPATCH(k_attn_bwd_col, false, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv, ld);
+    ATTN_DISPATCH(k_attn_bwd_row, false, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e, ld, q16, g16);
+    ATTN_DISPATCH(k_attn_bwd_col, false, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv, ld,
+                  (const uint16_t*)q16, (const uint16_t*)g16);
   }
   return acheck(who);
 }

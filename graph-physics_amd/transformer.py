@@ -91,7 +91,7 @@ class SparseAttentionFn(torch.autograd.Function):
         dy = dy.float().contiguous()
         N, H = q.shape
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-        ws = torch.empty(max(2 * topo.E * nh, 1), dtype=torch.float32, device=q.device)
+        ws = torch.empty(max(2 * topo.E * nh + (N * H if ctx.b16 else 0), 1), dtype=torch.float32, device=q.device)
         fn = _capi.lib().mgn_sparse_attn_bwd_b16 if ctx.b16 else _capi.lib().mgn_sparse_attn_bwd
         with torch.cuda.device(q.device):
             rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(), lse.data_ptr(), dy.data_ptr(),
@@ -154,7 +154,7 @@ class PackedAttentionFn(torch.autograd.Function):
         kv = kv16 if b16 else qkv[:, H:]
         ekv = kv.element_size()
         d = torch.empty_like(qkv)
-        ws = torch.empty(max(2 * topo.E * nh, 1), dtype=torch.float32, device=qkv.device)
+        ws = torch.empty(max(2 * topo.E * nh + (N * H if b16 else 0), 1), dtype=torch.float32, device=qkv.device)
         with torch.cuda.device(qkv.device):
             rc = _capi.lib().mgn_sparse_attn_bwd_s(qkv.data_ptr(), H3, kv.data_ptr(), int(kv.stride(0)), kv.data_ptr() + H * ekv, int(kv.stride(0)),
                                                    int(b16), y.data_ptr(), lse.data_ptr(), dy.data_ptr(), topo.rowptr.data_ptr(),

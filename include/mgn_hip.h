@@ -552,7 +552,9 @@ int mgn_sparse_attn_bwd(const float* q, const float* k, const float* v, const fl
  * gather bytes; exact when k, v came out of bf16-mode projections); q is the fp32 projection, rounded in the kernel as
  * bf16(q / sqrt(D)); y is rounded to bf16 values (fp32 storage) and y_raw (optional) receives the unrounded rows, which is
  * what the backward takes as its y (D = sum_d dy y is the fp32 softmax's own); the backward rounds dy on load and returns dq
- * through the two casts (bf16(dq_scaled * sqrt(D)) / sqrt(D)); dk, dv are fp32.  Same CSR arguments, ws and determinism. */
+ * through the two casts (bf16(dq_scaled * sqrt(D)) / sqrt(D)); dk, dv are fp32.  Same CSR arguments and determinism; ws as above, and
+ * with N * H more floats of it the row pass hands the column pass bf16(q / sqrt(D)) and bf16(dy) as two-byte rows (half the gathered
+ * bytes of that pass, same results bit for bit). */
 int mgn_sparse_attn_fwd_b16(const float* q, const uint16_t* k16, const uint16_t* v16, const int32_t* rowptr, const int32_t* col,
                             int64_t N, int H, int num_heads, float* y, float* lse, float* y_raw, void* stream);
 int mgn_sparse_attn_bwd_b16(const float* q, const uint16_t* k16, const uint16_t* v16, const float* y, const float* lse,
