@@ -22,7 +22,8 @@ import os as _os
 X6_ENABLED = _os.environ.get("MGN_FP32_MFMA") is None
 
 #: "fp32" (default: bf16x3 operands, 6 product terms, fp32-grade) or "bf16" (operands rounded to
-#: bf16, one term, fp32 accumulate; everything stored stays fp32) -- the processor's GEMMs only.
+#: bf16, one term, fp32 accumulate; the residual streams, RMSNorm and the node-row saves stay fp32, the saved edge activations and
+#: the edge chain's dZ rows travel as two-byte rows [r4]) -- the processor's GEMMs only.
 #: "bf16" mirrors the reference under Lightning ``precision="bf16-mixed"`` (train.py:74-78,268-293).
 _matrix_precision = "fp32"
 
