@@ -131,6 +131,9 @@ __device__ __forceinline__ float exp_sm(float x) {
   return expf(x);
 #endif
   constexpr float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f;
+  // [r5] exp(-150) is an exact 0 after the ldexp; clamping keeps n inside int range and r bounded whatever the score magnitude
+  // (the -1e37 start of the running maximum, or |score| >= 3e29, used to reach fptosi's undefined range); a NaN stays a NaN
+  x = x < -150.f ? -150.f : x;
   const float t = x * L2E_HI;
   const float r = __builtin_fmaf(x, L2E_LO, __builtin_fmaf(x, L2E_HI, -t));
   const float n = __builtin_rintf(t);

@@ -2537,7 +2537,7 @@ int mgn_mlp_fwd(const mgn_mlp_fwd_args* args, void* stream) {
     return fail(1, "mgn_mlp_fwd: GELU runs on the generic kernels only (no packed weights / gathers / post-products)");
   if (a.act == MGN_ACT_SILU && plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && !fwd_x6(a) && a.NL > 1)
     return fail(1, "mgn_mlp_fwd: SiLU is not available on the exact-fp32 LDS generation (pass packed weights)");
-  if (a.precision >= 1 && plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false).lds && !fwd_x6(a))
+  if (a.precision >= 1 && plan_mlp(a.M, a.H, a.NL, fwd_ragged(a), false, a.act).lds && !fwd_x6(a))
     return fail(1, "mgn_mlp_fwd: at H = 128 with full widths the bf16 matrix mode needs the packed split-bf16 path (wpk); other shapes run it on the generic kernels");
   if (a.nphase < 1 || a.nphase > MGN_MAX_PHASES) return fail(1, "mgn_mlp_fwd: nphase out of range");
   for (int p = 0; p < a.nphase; ++p)
@@ -2587,7 +2587,7 @@ int mgn_mlp_bwd(const mgn_mlp_bwd_args* args, void* stream) {
   }
   if (a.n_front != 0 && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
     return fail(1, "mgn_mlp_bwd: the front stage needs the packed split-bf16 path (H = 128, full widths, wpk, Ms, no dOut2)");
-  if (a.precision >= 1 && plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && !bwd_x6(a))
+  if (a.precision >= 1 && plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true, a.act).lds && !bwd_x6(a))
     return fail(1, "mgn_mlp_bwd: at H = 128 with full widths the bf16 matrix mode needs the packed split-bf16 path (wpk, Ms); other shapes run it on the generic kernels");
   if (a.seg_out != nullptr && !(plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true).lds && bwd_x6(a)))
     return fail(1, "mgn_mlp_bwd: the fused segment sum of dZ[0] needs the packed split-bf16 path (fp32-grade, ReLU, dZ[0], no front stage)");
@@ -2650,7 +2650,7 @@ static bool wgrad_job_row64(const mgn_wgrad_job& j) {
   return j.nja <= 4 && j.nkb <= 4 && j.kw <= 64 && (j.kw & 3) == 0 && (j.lda & 3) == 0 && (j.ldb & 3) == 0 &&
          (((uintptr_t)j.A | (uintptr_t)j.B) & 15) == 0;
 }
-static int wgrad_plan(int njobs, const mgn_wgrad_job* jobs, int* wg0, bool lds) {
+static int wgrad_plan(int njobs, const mgn_wgrad_job* jobs, int* wg0, bool lds, int lds_budget = 512) {
   // A fixed budget of workgroups -- at most what is co-resident (512 = 2 per CU for the LDS
   // kernel; the generic one could hold 1024) -- shared out in proportion to the rows of each job.
   // The total must NEVER exceed the budget: four workgroups too many start a second
@@ -2659,7 +2659,7 @@ static int wgrad_plan(int njobs, const mgn_wgrad_job* jobs, int* wg0, bool lds) 
   const int rows = lds ? WG_TILE_ROWS : 16;
   // (generic kernel: 1024 workgroups are co-resident, but half as many leave half the partials to k_wgrad_red -- neutral on the
   //  headline, -3.5 % on the Transformer step whose weight gradients are all small matrices; MGN_WGRAD_GENERIC_BUDGET overrides)
-  int budget = 512;
+  int budget = lds ? lds_budget : 512;
   if (!lds) {
     if (const char* e = getenv("MGN_WGRAD_GENERIC_BUDGET")) {
       const int b = atoi(e);
@@ -2750,12 +2750,27 @@ int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes,
     for (int j = 0; row64 && j < L.njobs; ++j) row64 = wgrad_job_row64(L.job[j]);
     if (row64) HB = 4;
     L.H = 16 * HB;
-    const int total = wgrad_plan(L.njobs, L.job, L.wg0, pass == 0);
+    // [r5] fp32-row full jobs: the producer / consumer kernel (one 512-thread workgroup per CU); MGN_WGRAD_PC=0: k_wgrad_x6<6>
+    bool pc = pass == 0 && precision == 0 && getenv("MGN_FP32_MFMA") == nullptr;
+    if (pc) {
+      const char* e = getenv("MGN_WGRAD_PC");
+      pc = e == nullptr || atoi(e) != 0;
+      for (int j = 0; pc && j < L.njobs; ++j) pc = L.job[j].lda == 128 && L.job[j].ldb == 128;
+    }
+    const int total = wgrad_plan(L.njobs, L.job, L.wg0, pass == 0, pc ? 256 : 512);
     const size_t need = (size_t)total * (L.H * L.H + L.H) * sizeof(float);
     if (ws_bytes < ws_off + need) return fail(1, "mgn_wgrad: workspace too small");
     L.partial = (float*)((char*)ws + ws_off);
     ws_off += need;
-    if (pass == 0) {
+    if (pc) {
+      static thread_local bool attr_pc_done = false;
+      if (!attr_pc_done) {
+        if (hipFuncSetAttribute((const void*)k_wgrad_pc, hipFuncAttributeMaxDynamicSharedMemorySize, WPC_LDS_BYTES) != hipSuccess)
+          return fail(2, "mgn_wgrad: cannot reserve LDS");
+        attr_pc_done = true;
+      }
+      hipLaunchKernelGGL(k_wgrad_pc, dim3(total), dim3(512), WPC_LDS_BYTES, s, L);
+    } else if (pass == 0) {
       const size_t smem = 4 * WG_TILE_BYTES;
       static thread_local bool attr_done = false;
       if (!attr_done) {

@@ -322,24 +322,35 @@ class PartitionedEPD(torch.nn.Module):
     forward(x_in_own[n_own,F_n], edge_attr_loc[E_loc,F_e]) -> out_own[n_own,O]
     """
 
-    def __init__(self, model, plan, group=None, backend=None):
+    def __init__(self, model, plan, group=None, backend=None, cache_positions: bool = False):
         super().__init__()
         self.model, self.plan, self.group = model, plan, group
         self.backend = backend if backend is not None else HipBackend()
         self._ctx = None
         self._halo = None
-        self._pos_full = None   # [n_own + n_ghost, D]: owned positions + the ghosts' (exchanged once per plan)
+        # [n_own + n_ghost, D]: owned positions + the ghosts'.  The ghosts' rows are exchanged on EVERY forward (one small
+        # neighbour exchange beside the one-per-block exchanges of the latents) unless ``cache_positions=True`` -- the caller's
+        # promise that the mesh does not deform and the same sample is evaluated: then they travel once (``invalidate_positions()``
+        # drops them).  The decision must be the same on every rank (the exchange is a collective), so it is a constructor
+        # argument and never inferred from the tensor a rank happens to pass.  Owned rows always come from the current pos_own.
+        self.cache_positions = bool(cache_positions)
+        self._pos_full = None
         # what the un-partitioned forward would apply and this path does not: refuse instead of silently
         # computing another function (processors.py:203-209: the temporal block attends over ALL nodes' previous latents)
         if getattr(model, "use_temporal_block", False) or getattr(model, "temporal_block", None) is not None:
             raise NotImplementedError("PartitionedEPD: use_temporal_block is not supported on a partitioned mesh")
+
+    def invalidate_positions(self) -> None:
+        """drop the cached ghost positions (``cache_positions=True``): the next forward exchanges them again -- call it on
+        EVERY rank (the exchange is a collective)"""
+        self._pos_full = None
 
     def forward(self, x_in_own: torch.Tensor, edge_attr_loc: torch.Tensor, phi_own: Optional[torch.Tensor] = None,
                 pos_own: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``phi_own``: the owned rows of ``graph.phi`` (only read by blocks with the sigmoid gate, layers.py:1091-1098).
         ``pos_own``: the owned rows of ``graph.pos`` -- required with ``use_rope_embeddings`` (layers.py:1020-1026 rotates
         x_src by pos[src] - pos[dst]: a rank needs the positions of its ghost sources; they travel ONCE per plan, by the same
-        neighbour exchange as the latents, and are kept)."""
+        neighbour exchange as the latents, on every call unless the module was built with ``cache_positions=True``)."""
         plan, be, m = self.plan, self.backend, self.model
         dev = x_in_own.device
         if phi_own is not None and phi_own.reshape(-1).shape[0] != plan.n_own:
@@ -350,9 +361,12 @@ class PartitionedEPD(torch.nn.Module):
                 raise ValueError("Graph data must contain `pos` when use_rope_embeddings=True.")   # processors.py:188-191
             if pos_own.shape[0] != plan.n_own:
                 raise ValueError("pos_own must hold one row per owned node")
-            if self._pos_full is None or self._pos_full.device != dev:
-                p_own = pos_own.detach().to(dev, torch.float32).contiguous()
+            p_own = pos_own.detach().to(dev, torch.float32).contiguous()
+            if (not self.cache_positions or self._pos_full is None or self._pos_full.device != dev
+                    or self._pos_full.shape[1] != p_own.shape[1]):
                 self._pos_full = torch.cat([p_own, HaloExchange.apply(p_own, plan, self.group)], dim=0)
+            else:
+                self._pos_full[: plan.n_own].copy_(p_own)
         if self._ctx is None:
             self._ctx = be.prepare(plan.edge_index.to(dev), plan.n_own + plan.n_ghost)
         x_own = be.mlp(m.nodes_encoder, x_in_own)

@@ -715,6 +715,19 @@ def processor_apply(x, e, topo, L, *params, spec: BlockSpec = DEFAULT_SPEC, halo
 #: bucket of rounds while the earlier rounds are still being differentiated (distributed.OverlappedGradAllReduce).  None: no call.
 _grad_ready_hook = None
 
+def _bf16_rounded_many(ts):
+    """bf16-rounded fp32 copies of a list of tensors (bf16 matrix mode off the packed path) in two multi-tensor launches.  Never
+    cached: the fused optimiser writes parameters through raw pointers (no version bump) and a captured training step replays
+    without Python, so a copy kept across calls would silently go stale."""
+    if not ts:
+        return []
+    src = [t.detach() for t in ts]
+    lo = [torch.empty_like(t, dtype=torch.bfloat16) for t in src]
+    out = [torch.empty_like(t) for t in src]
+    torch._foreach_copy_(lo, src)
+    torch._foreach_copy_(out, lo)
+    return out
+
 
 def set_grad_ready_hook(fn) -> None:
     global _grad_ready_hook
@@ -752,13 +765,15 @@ def get_activation_recompute() -> str:
     return _recompute_mode
 
 
-def saved_activation_bytes(E: int, Nn: int, H: int, NL: int, L: int, act: int) -> int:
-    """what ProcessorFunction keeps for the backward pass without recompute"""
+def saved_activation_bytes(E: int, Nn: int, H: int, NL: int, L: int, act: int, save16: bool = False) -> int:
+    """what ProcessorFunction keeps for the backward pass without recompute (``save16``: the edge rows' H1.. are two-byte rows,
+    the bf16 matrix mode's default on the packed path)"""
     per_row = 4 * H * ((NL - 1) * (2 if act == 1 else 1) + 2) + 16 * (NL - 1) + 4   # H1.., [Z1..], U, input | masks | rms
-    return L * (E * per_row + Nn * (per_row + 4 * H))                                  # + agg per node
+    per_edge = per_row - (2 * H * (NL - 1) if save16 else 0)
+    return L * (E * per_edge + Nn * (per_row + 4 * H))                                 # + agg per node
 
 
-def recompute_rounds(E, Nn, H, NL, L, act, dev) -> int:
+def recompute_rounds(E, Nn, H, NL, L, act, dev, save16: bool = False) -> int:
     """how many of the L rounds keep only their inputs and are re-run in the backward pass (the FIRST ones: they are
     differentiated last, when the saved rounds have been released).  "auto": as many rounds are saved as fit in
     MGN_RECOMPUTE_FRACTION (default 0.5) of the free device memory -- 0 recomputed on the bench batch, 6 of 15 on the
@@ -777,7 +792,7 @@ def recompute_rounds(E, Nn, H, NL, L, act, dev) -> int:
     except Exception:  # noqa: BLE001
         return 0
     frac = float(_os.environ.get("MGN_RECOMPUTE_FRACTION", "0.5"))
-    per_round = saved_activation_bytes(E, Nn, H, NL, 1, act)
+    per_round = saved_activation_bytes(E, Nn, H, NL, 1, act, save16)
     fit = int(frac * free // max(per_round, 1))
     return max(0, L - fit)
 
@@ -913,7 +928,9 @@ class MlpFunction(torch.autograd.Function):
             din = [(Wk[0].t().contiguous(), None, dx)] if want_dx else []
             # bias gradients are a by-product of the weight-gradient kernel (it reads dZ anyway)
             mlp_bwd(M, H, NL, dy, None, None, out_w, U, R, scale, saveH, WT, dZ, din, [None] * NL, dscale, act=act, Zs=Zs, precision=prec)
-        ins = [x] + list(saveH)
+        # (bf16 matrix mode: the reference's autocast Linear multiplies the bf16 copy of its input in the weight gradient too; the saved
+        #  layer results are rounded by the kernels already)
+        ins = [x.to(torch.bfloat16).to(torch.float32) if prec else x] + list(saveH)
         in_w = [kin] + [H] * (NL - 1)
         dWs = [mk(widths[l], pad16(in_w[l]), **f) for l in range(NL)]
         jobs = []
@@ -976,6 +993,7 @@ class ProcessorFunction(torch.autograd.Function):
             raise AssertionError("The MLP must have at least 2 layers (input and output)." if NL < 2 else f"at most {_capi.MAX_LAYERS} layers per MLP")
         dev = x.device
         P = [_f32c(p) for p in params]
+        P_params = P   # (P may be re-bound to kernel operands below: bf16 matrix mode off the packed path)
         need = any(ctx.needs_input_grad) and _saving()
         f = dict(dtype=torch.float32, device=dev)
         _require_device(pos if spec.rope else None, phi, rope_inv_freq if spec.rope else None)
@@ -1007,10 +1025,14 @@ class ProcessorFunction(torch.autograd.Function):
             # [r4] bf16 matrix mode off the packed path (any supported width, e.g. the shipped cylinder.json's hidden 32): the
             # generic kernels round the row operands and every layer's result to bf16 (precision = 1); the weights and biases of
             # the Linear layers go in rounded (the RMSNorm scales, gate positions stay fp32: autocast does not touch them)
+            # P_params stays the list of PARAMETERS (what autograd version-checks and what the grad-ready hook reports); the rounded
+            # operands live in their own list (two multi-tensor cast launches per forward pass)
             k_ = spec.mlp_params
-            for i_ in range(L):
-                for j_ in list(range(2 * NL)) + list(range(k_, k_ + 2 * NL)) + ([2 * k_, 2 * k_ + 1] if spec.gate else []):
-                    P[i_ * PB + j_] = P[i_ * PB + j_].to(torch.bfloat16).to(torch.float32)
+            P = list(P)
+            idx_ = [i_ * PB + j_ for i_ in range(L)
+                    for j_ in list(range(2 * NL)) + list(range(k_, k_ + 2 * NL)) + ([2 * k_, 2 * k_ + 1] if spec.gate else [])]
+            for i_, r_ in zip(idx_, _bf16_rounded_many([P_params[i_] for i_ in idx_])):
+                P[i_] = r_
         if halo is not None and not (x6 and split):
             raise NotImplementedError("the partitioned path runs on the packed H = 128 kernels (no RoPE)")
         # (the fused aggregation's second stage walks a node's tile partials serially: hub topologies take the
@@ -1172,7 +1194,7 @@ class ProcessorFunction(torch.autograd.Function):
         # activation recompute (see set_activation_recompute): the forward keeps only every round's INPUTS
         # and runs the inference-mode launches; the backward re-runs a round in training mode right before
         # differentiating it.  2.5 KB per edge and round shrink to 0.5 KB.
-        n_rec = recompute_rounds(E, Nn, H, NL, L, act, dev) if (need and halo is None) else 0
+        n_rec = recompute_rounds(E, Nn, H, NL, L, act, dev, save16) if (need and halo is None) else 0
         recompute = n_rec > 0
         Pd = Ps = None
         pending = None  # halo exchange in flight
@@ -1191,7 +1213,8 @@ class ProcessorFunction(torch.autograd.Function):
         ctx.topo, ctx.L, ctx.saved_acts, ctx.prec, ctx.spec, ctx.halo = topo, L, (saved if need else None), prec, spec, halo
         ctx.aux = (pos, phi, rope_inv_freq, x6, split)
         ctx.save16 = save16
-        ctx.save_for_backward(*P)  # version-checked by autograd (an optimiser step in between is an error)
+        ctx.P_ops = P if P is not P_params else None   # rounded kernel operands of the bf16 mode off the packed path
+        ctx.save_for_backward(*P_params)  # version-checked by autograd (an optimiser step in between is an error)
         return x, e
 
     @staticmethod
@@ -1202,7 +1225,8 @@ class ProcessorFunction(torch.autograd.Function):
             raise RuntimeError("ProcessorFunction: the saved activations were released by an earlier backward pass "
                                "(retain_graph is not supported: ~2.5 KB per edge and round are freed eagerly), "
                                "or the forward ran under no_grad")
-        P = list(ctx.saved_tensors)
+        P_params = list(ctx.saved_tensors)
+        P = ctx.P_ops if ctx.P_ops is not None else P_params   # kernel operands (rounded copies in the bf16 mode off the packed path)
         NL, act, PB = spec.nb_layers, spec.act_id, spec.per_block
         N, E = topo.N, topo.E
         if not topo.resolved:  # lazily built topology: the forward pass is queued, the flags have long arrived
@@ -1483,7 +1507,7 @@ class ProcessorFunction(torch.autograd.Function):
                 # this round's weight / bias gradients are final once their launches are queued (the two RMSNorm scale gradients come
                 # out of the deferred reduction at the very end): a data-parallel wrapper may start reducing them now
                 late = {2 * NL, k_ + 2 * NL} if (spec.layer_norm and deferred is not None) else set()
-                _grad_ready_hook([(P[PB * i + t], g[t]) for t in range(len(g)) if t not in late])
+                _grad_ready_hook([(P_params[PB * i + t], g[t]) for t in range(len(g)) if t not in late])
             dx, de = dx_new, de_new
         if side is not None:
             for ev in wdone:
