@@ -148,11 +148,34 @@ def device_copy_rate(dev):
     return DEVICE_COPY_GBPS
 
 
-def hbm_obj(kernel, t_ms, nbytes, traffic=None, extra=None):
+#: what a streaming kernel sustains on this part as a function of the WRITE share of its traffic (tools/rw_mix_probe.hip, 1 GiB per
+#: stream, far past the Infinity Cache; profiles/r03_rw_mix_probe.txt, mean of the two grid sizes): a read stream reaches 6.4 TB/s,
+#: any mix that carries writes 4.5-5.1 TB/s.  `ceiling_gbps` of a roofline object is this table at the kernel's own read : write ratio.
+RW_MIX_GBPS = [(0.0, 6370.0), (0.25, 5124.0), (1.0 / 3.0, 4890.0), (0.5, 4935.0), (2.0 / 3.0, 4998.0), (0.75, 5077.0), (1.0, 4516.0)]
+
+
+def rw_ceiling_gbps(write_frac):
+    w = min(max(float(write_frac), 0.0), 1.0)
+    for (w0, g0), (w1, g1) in zip(RW_MIX_GBPS, RW_MIX_GBPS[1:]):
+        if w <= w1:
+            return g0 + (g1 - g0) * (w - w0) / (w1 - w0)
+    return RW_MIX_GBPS[-1][1]
+
+
+def hbm_obj(kernel, t_ms, nbytes, traffic=None, extra=None, write_bytes=None, traffic_rw=None):
+    """``write_bytes``: the algorithmic bytes of ``nbytes`` that are stores (the rest are loads); ``traffic_rw``: counted
+    (read, write) bytes per launch of the PMC passes when they exist."""
     ach = nbytes / (t_ms * 1e-3) / 1e9
     d = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM, "unit": "GB/s",
          "frac": round(ach / PEAK_HBM, 4), "traffic": traffic, "launch_ms": round(t_ms, 5),
          "algorithmic_bytes_per_launch": int(nbytes)}
+    if write_bytes is not None:
+        ceil = rw_ceiling_gbps(write_bytes / max(nbytes, 1.0))
+        d.update(read_bytes=int(nbytes - write_bytes), write_bytes=int(write_bytes), ceiling_gbps=round(ceil, 0),
+                 frac_of_ceiling=round(ach / ceil, 4),
+                 ceiling_note="streaming rate at this kernel's read : write ratio (profiles/r03_rw_mix_probe.txt)")
+    if traffic_rw and traffic_rw[0] is not None:
+        d.update(traffic_read_bytes=int(traffic_rw[0]), traffic_write_bytes=int(traffic_rw[1]))
     if DEVICE_COPY_GBPS:
         d["device_copy_gbps"] = DEVICE_COPY_GBPS
         d["frac_of_device_copy"] = round(ach / DEVICE_COPY_GBPS, 4)
@@ -178,6 +201,14 @@ def step_floor(N, E, H, L, terms, ms_per_step):
             "mfma_flops_per_step_bf16_terms": int(flops), "mfma_floor_ms": round(mfma_ms, 3), "step_floor_ms": round(floor, 3),
             "frac_of_floor": round(floor / ms_per_step, 4), "frac_of_floor_at_6300_GBps": round(max(hbm63_ms, mfma_ms) / ms_per_step, 4),
             "what": "step_floor_ms / ms_per_step; bytes = the E-row kernels of the 15 rounds only (a lower bound of the step's traffic)"}
+
+
+def _c4_scatter_traffic(capi, rw=False):
+    """counted HBM bytes of k_segsum<8> at the 1M-node size (profiles/pmc_traffic.json: c4_segsum_*; same build-hash gate)"""
+    t, _ = load_traffic(capi)
+    if rw:
+        return (t.get("c4_segsum_read_bytes"), t.get("c4_segsum_write_bytes"))
+    return t.get("c4_segsum_bytes")
 
 
 def load_traffic(capi):
@@ -248,11 +279,17 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
     b_bwd = row * (7 * E + N) + 52.0 * E + 4.0 * E       # dE', U, dZ0-3 (w), dE (w) | dAgg | rms + masks | dst idx
     b_wg = row * (8 * E + 12 * N)                        # 4 edge jobs (dZ, X) + 6 node jobs, 1 launch per round
     b_seg = 2 * row * (E + N) + 4.0 * E + 8.0 * (N + 1)  # two sums of dZ0: read E rows twice, write 2N rows, perm, 2 rowptr
+    # the store share of each figure (the rest are loads): e', H1-3, U, agg, rms + masks | e', agg | dZ0-3, dE | (partials only) | 2N rows
+    w_fwd, w_inf, w_bwd, w_wg, w_seg = row * (5 * E + N) + 52.0 * E, row * (E + N), row * 5 * E, 0.0, 2 * row * N
+
+    def rw(key):
+        return (traffic.get(key + "_read_bytes"), traffic.get(key + "_write_bytes"))
     t = "x6" if x6 else "lds<1>"
     per_step = lambda tag: tm.count(tag) // steps  # noqa: E731
     roof = hbm_obj(f"k_mlp_fwd_{t} (edge update, training mode: W_e.e + gathered node projections, 3 Linear, RMSNorm, "
                    "residual, saves, fused aggregation)", tm.ms("edge_fwd"), b_fwd, traffic.get("edge_fwd_bytes"),
-                   dict(mfma(tm.ms("edge_fwd"), nterm if x6 else 1), launches_per_step=per_step("edge_fwd"), traffic_source=tnote))
+                   dict(mfma(tm.ms("edge_fwd"), nterm if x6 else 1), launches_per_step=per_step("edge_fwd"), traffic_source=tnote),
+                   write_bytes=w_fwd, traffic_rw=rw("edge_fwd"))
     others = []
     if tm.ms("edge_bwd_fused"):
         # fused edge backward: reads dE', U, e, H1-3 (6 E-row tensors) + gathered dAgg; writes dE, dZ0; masks, rms, idx;
@@ -268,28 +305,33 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
         b_wg = row * (12 * N)                            # the node-row jobs that remain in the weight-gradient launch
     if tm.ms("edge_bwd"):
         others.append(hbm_obj(f"k_mlp_bwd_{t} (edge backward chain: RMSNorm bwd, 3 masked dgrad GEMMs, input grad)", tm.ms("edge_bwd"), b_bwd,
-                              traffic.get("edge_bwd_bytes"), dict(mfma(tm.ms("edge_bwd"), nterm if x6 else 1), launches_per_step=per_step("edge_bwd"))))
+                              traffic.get("edge_bwd_bytes"), dict(mfma(tm.ms("edge_bwd"), nterm if x6 else 1), launches_per_step=per_step("edge_bwd")),
+                              write_bytes=w_bwd, traffic_rw=rw("edge_bwd")))
     if tm.ms("wgrad"):
-        others.append(hbm_obj(f"k_wgrad_{'x6' if x6 else 'lds'} + k_wgrad_red (weight gradients of one round: "
-                              + ("6..7 node jobs; the E-row jobs run inside the fused edge backward)" if tm.ms("edge_bwd_fused") else "4 edge + 6..7 node jobs)"),
-                              tm.ms("wgrad"), b_wg, traffic.get("wgrad_bytes"), {"launches_per_step": per_step("wgrad")}))
+        pc = x6 and nterm == 6 and os.environ.get("MGN_WGRAD_PC", "1") != "0"   # mgn_wgrad_p: fp32-row full jobs on the producer / consumer kernel
+        others.append(hbm_obj(f"k_wgrad_{('pc' if pc else 'x6') if x6 else 'lds'} + k_wgrad_red (weight gradients of one round: "
+                              + ("6..7 node jobs; the E-row jobs run inside the fused edge backward)" if tm.ms("edge_bwd_fused") else "4 edge + 6..7 node jobs)")
+                              + " -- a READ stream: its ceiling is the 6.4 TB/s of a streaming read, not the write-carrying mix",
+                              tm.ms("wgrad"), b_wg, traffic.get("wgrad_bytes"), {"launches_per_step": per_step("wgrad")},
+                              write_bytes=w_wg, traffic_rw=rw("wgrad")))
     if tm.ms("edge_inf"):
         # the ping-pong instance takes fp32-grade inference-mode launches from 65 536 rows unless MGN_PP=0 (mgn_kernels.hip: fwd_pp_ok)
         pp = x6 and nterm == 6 and E >= 65536 and os.environ.get("MGN_PP", "") != "0"
         others.append(hbm_obj(("k_edge_fwd_pp<false>" if pp else f"k_mlp_fwd_{t}") + " (edge update, inference mode = the rollout's "
                               "dominant kernel: nothing saved, aggregation fused)", tm.ms("edge_inf"), b_inf, None,
-                              dict(mfma(tm.ms("edge_inf"), nterm if x6 else 1), launches_per_rollout_step=tm.count("edge_inf") // 2)))
+                              dict(mfma(tm.ms("edge_inf"), nterm if x6 else 1), launches_per_rollout_step=tm.count("edge_inf") // 2),
+                              write_bytes=w_inf))
     if tm.ms("segsum"):
         roof_seg = hbm_obj("k_segsum2<8> (CSR segment sums = the scatter-add of the backward pass onto destination and source nodes; "
                            "the forward aggregation is fused into the edge kernel's epilogue). Working set 217 MB < 256 MiB Infinity "
-                           "Cache: see c4.roofline_scatter for the past-L3 measurement", tm.ms("segsum"), b_seg, traffic.get("segsum_bytes"),
-                           {"launches_per_step": per_step("segsum")})
+                           "Cache: see roofline_scatter_c4 for the past-L3 measurement", tm.ms("segsum"), b_seg, traffic.get("segsum_bytes"),
+                           {"launches_per_step": per_step("segsum")}, write_bytes=w_seg, traffic_rw=rw("segsum"))
     else:  # the destination-side scatter is fused into the backward chain: only the source-side sum is a launch of its own
         b_src = row * (E + N) + 4.0 * E + 4.0 * (N + 1)
         roof_seg = hbm_obj("k_segsum<8> through perm_src (the scatter-add of the backward pass onto SOURCE nodes: gathered 512-byte rows, "
                            "CSR order; the destination-side sums of both passes are fused into the edge kernels). Working set 108 MB < "
-                           "256 MiB Infinity Cache: see c4.roofline_scatter for the past-L3 measurement", tm.ms("segsum_src"), b_src,
-                           traffic.get("segsum_src_bytes"), {"launches_per_step": per_step("segsum_src")})
+                           "256 MiB Infinity Cache: see roofline_scatter_c4 for the past-L3 measurement", tm.ms("segsum_src"), b_src,
+                           traffic.get("segsum_src_bytes"), {"launches_per_step": per_step("segsum_src")}, write_bytes=row * N)
     return roof, roof_seg, others
 
 
@@ -752,6 +794,20 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
             with torch.no_grad():
                 pm(xo, eo)
 
+        def host_time(fn, k=3):
+            """wall time the HOST needs to enqueue one step (Python glue, ctypes launches, c10d enqueue) with the device's queue
+            never empty and never waited for: no synchronisation inside the timed region.  The partitioned step must stay well
+            below the device time of a rank's share, or the 8-GPU step is host-bound whatever the kernels do."""
+            fn()
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                fn()
+            dt = (time.perf_counter() - t0) / k
+            torch.cuda.synchronize()
+            return dt
+
         torch.cuda.reset_peak_memory_stats(dev)
         t_train = timed(train_step, args.c4_steps)
         mem = torch.cuda.max_memory_allocated(dev) / 2**30
@@ -760,6 +816,12 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
              "edge_cut": round(P.edge_cut(g.edge_index, part), 5), "partition_s": round(t_part, 2),
              "train_ms_per_step": round(1e3 * t_train, 2), "rollout_ms_per_step": round(1e3 * t_inf, 2),
              "peak_mem_gib": round(mem, 1)}
+        if world == 1 or dist.get_backend() == "nccl":   # (over gloo the collectives block the host: the figure would mean nothing)
+            r["host_ms_per_step"] = round(1e3 * host_time(train_step), 2)
+            r["host_rollout_ms_per_step"] = round(1e3 * host_time(infer_step), 2)
+            r["host_what"] = ("host wall time to ENQUEUE one step (no synchronisation in the timed region): Python glue + ctypes launches"
+                              + (" + c10d enqueue of the 2 x rounds halo exchanges and the gradient all-reduce" if exchange else "")
+                              + "; must stay below train_ms_per_step for the step to be device-bound")
         if exchange:
             # the step's communication on its own (nothing to overlap with: an upper bound of what it costs inside the step):
             # the 2 x rounds halo exchanges of a step, and the gradient all-reduce
@@ -841,12 +903,15 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
 
     t_seg = ev_time(lambda: ops.segsum(m, topo.rowptr_dst, None, agg))
     b_seg = 4.0 * H * (E + n) + 4.0 * (n + 1)  # 4EH + 4NH + 4(N+1)
+    from graph_physics_amd import _capi as _capi_mod
     rec["roofline_scatter"] = hbm_obj("k_segsum<8> (forward scatter-add agg[i] = sum of the messages of node i's incoming edges, CSR order, "
-                                      "atomics-free; 3.6 GB per launch, past the 256 MiB Infinity Cache)", t_seg, b_seg)
+                                      "atomics-free; 3.6 GB per launch, past the 256 MiB Infinity Cache)", t_seg, b_seg,
+                                      _c4_scatter_traffic(_capi_mod), write_bytes=4.0 * H * n, traffic_rw=_c4_scatter_traffic(_capi_mod, rw=True))
     t_seg2 = ev_time(lambda: ops.segsum2(m, topo.rowptr_dst, None, agg, topo.rowptr_src, topo.perm_src, agg2))
     b_seg2 = 2 * 4.0 * H * (E + n) + 4.0 * E + 8.0 * (n + 1)
     rec["roofline_scatter_backward"] = hbm_obj("k_segsum2<8> (both backward scatters of dZ0 in one launch: onto destinations in CSR order and "
-                                               "onto sources through perm_src = gathered 512-byte rows; engine-renumbered nodes)", t_seg2, b_seg2)
+                                               "onto sources through perm_src = gathered 512-byte rows; engine-renumbered nodes)", t_seg2, b_seg2,
+                                               write_bytes=2 * 4.0 * H * n)
     t_seg2r = ev_time(lambda: ops.segsum2(m, topo_raw.rowptr_dst, None, agg, topo_raw.rowptr_src, topo_raw.perm_src, agg2))
     rec["roofline_scatter_backward_raw_numbering"] = hbm_obj("k_segsum2<8>, nodes in generator order: the source-side rows are random 512-byte "
                                                              "gathers over 3 GB", t_seg2r, b_seg2)
@@ -1105,6 +1170,10 @@ def main():
             wd_done.set()
         if rank == 0:
             out["c4"] = c4
+            # the north-star scatter-add figure (>= 40 % of the HBM roofline past the Infinity Cache) as a top-level key: a reader of
+            # the parsed line need not open the nested record
+            if isinstance(c4, dict) and "roofline_scatter" in c4:
+                out["roofline_scatter_c4"] = c4["roofline_scatter"]
             if c5dp is not None:
                 out["c5"] = c5dp
     if rank == 0:

@@ -1043,8 +1043,9 @@ class ProcessorFunction(torch.autograd.Function):
         # [r4] bf16 matrix mode on the packed path: the saved edge activations H1..H_{NL-1} are bf16 tensors in the reference (autocast
         # Linear -> ReLU) and only the weight gradients read them back, so they are STORED as bf16 rows (precision 2 of mgn_mlp_fwd,
         # ldb = -128 of mgn_wgrad): half the bytes of those saves on both sides, bit-identical gradients.  MGN_SAVE16=0: fp32 saves.
-        # (not on a partitioned mesh: that combination has no test)
-        save16 = (relu_bits and prec == 1 and (split or spec.rope) and halo is None and _os.environ.get("MGN_SAVE16", "1") != "0"
+        # [r5] also on a partitioned mesh (the interior / boundary launches write row ranges of the same two-byte tensors;
+        # tests/test_partitioned_hip_multirank.py::test_partitioned_bf16_two_byte_saves_world4_vs_mixed_oracle)
+        save16 = (relu_bits and prec == 1 and (split or spec.rope) and _os.environ.get("MGN_SAVE16", "1") != "0"
                   and _os.environ.get("MGN_FUSED_BWD", "0") != "1")
         # ---- packed units of all rounds, one launch.  Per round:
         #   edge  [We0|e (, We0|x_dst, We0|x_src with RoPE), We1 .. We_{NL-1}]

@@ -163,6 +163,113 @@ def test_partitioned_hip_ranks_equal_unpartitioned_oracle(world):
         assert max(peers.values()) >= 3                   # a rank with three or more peers
 
 
+def _worker_bf16(rank, world, port, q):
+    """bf16 matrix mode (Lightning bf16-mixed, train.py:74-78) on the partitioned mesh: the packed kernels' two-byte saves of the
+    edge activations and of the backward chain's dZ rows UNDER the halo (interior / boundary launches over row ranges of the same
+    tensors), ReLU network; MGN_SAVE16 from the environment (the parent runs both settings)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import graph_physics_amd as gp
+    from graph_physics_amd import distributed as D
+    from graph_physics_amd import ops
+    from graph_physics_amd import partition as P
+
+    dev = torch.device("cuda:0")
+    pos, ei, part = _case(world)
+    N = pos.shape[0]
+    params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), SEED)
+    x_in, e_in, tgt, nt = _inputs(N, ei.shape[1])
+    plan = P.build_rank_plan(ei, part, rank, world, pos=pos.numpy())
+    net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H).to(dev)
+    net.load_state_dict(params)
+    pm = D.PartitionedEPD(net, plan)
+    ops.set_matrix_precision("bf16")
+    try:
+        runs = []
+        for _ in range(2):
+            net.zero_grad(set_to_none=True)
+            out = pm(x_in[plan.owned].to(dev), e_in[plan.edge_ids].to(dev))
+            loss = D.partitioned_loss(out, tgt[plan.owned].to(dev), nt[plan.owned].to(dev))
+            loss.backward()
+            runs.append({k: v.grad.clone() for k, v in net.named_parameters()})
+    finally:
+        ops.set_matrix_precision("fp32")
+    assert pm._halo is not None and pm._halo.active
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k      # bit-reproducible
+    D.GradAllReduce(average=False)(net.parameters())
+    grads = {k: v.grad.cpu().numpy().copy() for k, v in net.named_parameters()}
+    q.put((rank, plan.owned.numpy().copy(), out.detach().cpu().numpy().copy(), float(loss.detach()), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_bf16_world(world, save16):
+    os.environ["MGN_SAVE16"] = save16
+    try:
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker_bf16, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = _collect(q, procs, world, 900)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        os.environ.pop("MGN_SAVE16", None)
+    return res
+
+
+def test_partitioned_bf16_two_byte_saves_world4_vs_mixed_oracle():
+    """the two-byte saves of the bf16 matrix mode on a partitioned mesh (world 4, all ranks on one device):
+    forward and loss against the UN-partitioned oracle's bf16-mixed evaluation within the suite's bf16 convention (not farther from
+    it than that semantic is from fp32, x1.5), every parameter gradient Frobenius-relative against the mixed oracle's, and -- the
+    sharp check -- gradients and outputs of the two-byte-save run equal to the fp32-save run (MGN_SAVE16=0) of the same partitioned
+    model: the saves only change how H1..H3 / dZ travel, not what they hold (bias gradients sum bf16-rounded dZ rows: 1e-3)."""
+    world = 4
+    res16 = _run_bf16_world(world, "1")
+    res32 = _run_bf16_world(world, "0")
+    pos, ei, part = _case(world)
+    N = pos.shape[0]
+    x_in, e_in, tgt, nt = _inputs(N, ei.shape[1])
+    ref = {}
+    for mixed in (True, False):
+        params = {k: v.clone().requires_grad_(True) for k, v in R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), SEED).items()}
+        if mixed:
+            with O.bf16_mixed():
+                o = O.epd_forward(x_in, e_in, ei, params, L)
+                ls = O.l2_loss(o, tgt, nt)
+        else:
+            o = O.epd_forward(x_in, e_in, ei, params, L)
+            ls = O.l2_loss(o, tgt, nt)
+        ls.backward()
+        ref[mixed] = (o.detach().float(), float(ls), {k: v.grad.clone() for k, v in params.items()})
+    (o16, l16, g16), (o32, l32, g32) = ref[True], ref[False]
+    gap = float((o16 - o32).abs().max() / o32.abs().max())
+    by_rank32 = {r[0]: r for r in res32}
+    full, total, gsum = torch.zeros_like(o32), 0.0, None
+    for rank, owned, out, loss, grads in res16:
+        full[torch.from_numpy(owned)] = torch.from_numpy(out)
+        total += loss
+        _, _, out_b, loss_b, grads_b = by_rank32[rank]
+        assert np.array_equal(out, out_b), rank                                   # the forward does not read the saves
+        for k in grads:
+            a, b = torch.from_numpy(grads[k]).double(), torch.from_numpy(grads_b[k]).double()
+            assert float((a - b).norm() / (b.norm() + 1e-30)) < 2e-3, (rank, k)   # weights: identical operands; biases: rounded dZ rows
+        gsum = grads   # (after the all-reduce every rank holds the same sums)
+    e16 = float((full - o16).abs().max() / o16.abs().max())
+    assert 1e-5 < float((full - o32).abs().max() / o32.abs().max()) < 3e-2        # really the bf16 path
+    assert e16 < 1.5 * gap + 1e-3, (e16, gap)
+    assert abs(total - l16) < 2e-2 * abs(l16)
+    for k, gref in g16.items():
+        a, b, c = torch.from_numpy(gsum[k]).double(), gref.double(), g32[k].double()
+        ggap = float((b - c).norm() / c.norm())
+        err = float((a - b).norm() / b.norm())
+        assert err < max(1.5 * ggap, 0.02), (k, err, ggap)
+
+
 ROPE_VARIANT = {"use_gate": True, "use_rope": True, "rope_axes": 2, "rope_base": 100.0}
 GATED_VARIANT = {"use_gated_mlp": True, "use_gate": True}
 VARIANTS = {"rope": ROPE_VARIANT, "gated_mlp": GATED_VARIANT}

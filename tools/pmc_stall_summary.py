@@ -8,7 +8,7 @@ for f in glob.glob(os.path.join(root, "g*", "**", "*counter_collection.csv"), re
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0]
         if name.startswith("void "): name = name[5:]
-        if not name.startswith(("k_mlp", "k_wgrad_x6", "k_segsum")): continue
+        if not name.startswith(("k_mlp", "k_wgrad", "k_edge", "k_segsum")): continue
         wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
         acc[(name, wgs)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rows = []

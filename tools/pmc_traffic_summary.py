@@ -7,8 +7,10 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fd, wd, tag = sys.argv[1:4]
+# (kernel-name prefix, workgroups or None) -> key.  Prefixes stop before the closing '>' (k_segsum2<8, false> since round 4: the old
+# "k_segsum2<8>" key matched nothing and the bench line carried traffic 0 for the scatter)
 KEYS = {("k_mlp_fwd_x6<6, 4, 0", 512): "edge_fwd", ("k_mlp_bwd_x6<6, false, 0", 512): "edge_bwd", ("k_wgrad_x6", 512): "wgrad",
-        ("k_segsum2<8>", None): "segsum", ("__amd_rocclr_copyBuffer", None): "calibration_copy"}
+        ("k_wgrad_pc", 256): "wgrad", ("k_segsum2<8", None): "segsum", ("__amd_rocclr_copyBuffer", None): "calibration_copy"}
 def collect(d, counter):
     acc = defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -33,6 +35,7 @@ for key in ("calibration_copy", "edge_fwd", "edge_bwd", "wgrad", "segsum"):
     rows.append((key, nf, f, nw, w, int(rb), int(wb), int(rb + wb)))
     if key != "calibration_copy":
         out[key + "_bytes"] = int(rb + wb)
+        out[key + "_read_bytes"], out[key + "_write_bytes"] = int(rb), int(wb)
 PROF = os.environ.get("PROFILES_DIR") or os.path.join(REPO, "profiles")   # on the GPU box: a directory under gpurun_out/ (only that is merged back)
 path = os.path.join(PROF, f"{tag}_pmc_hbm_traffic.csv")
 with open(path, "w") as fh:
@@ -46,5 +49,12 @@ from graph_physics_amd import _capi  # noqa: E402
 out["csrc_hash"] = _capi.source_hash()   # bench.py refuses this file for any other build of csrc/
 out["source"] = f"profiles/{tag}_pmc_hbm_traffic.csv (rocprofv3 PMC passes over real training steps, FETCH_SIZE x{fcorr:.2f} per the calibration copy)"
 out["workload"] = "N=30160, E=180082 (bench default), per launch, averaged over the launches of 3 training steps"
+# the 1M-node scatter-add figures (tools/profile_c4.sh -> <tag>_c4_pmc_hbm_traffic.csv) travel in the same file when they exist
+c4csv = os.environ.get("C4_TRAFFIC_CSV")
+if c4csv and os.path.exists(c4csv):
+    for r in csv.DictReader(l for l in open(c4csv) if not l.startswith("#")):
+        if r.get("kernel", "").startswith("k_segsum<8"):
+            out["c4_segsum_read_bytes"], out["c4_segsum_write_bytes"] = int(float(r["read_bytes_corrected"])), int(float(r["write_bytes"]))
+            out["c4_segsum_bytes"] = out["c4_segsum_read_bytes"] + out["c4_segsum_write_bytes"]
 json.dump(out, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
 print(open(path).read())
