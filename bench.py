@@ -434,33 +434,46 @@ def batch1_record(args, gp, ops, harness, dev):
 
 def shipped_cylinder_record(args, gp, ops, harness, dev):
     """training_config/cylinder.json AS SHIPPED (message_passing_num 5, hidden_size 32 -- what a user who drops the engine in unchanged
-    runs; BASELINE.md's caveat): batch of 16 meshes, training step and rollout step, eager.  Hidden 32 runs on the generic
-    exact-fp32 MFMA kernels (k_mlp_fwd / k_mlp_bwd / k_wgrad at HB = 2), not on the packed split-bf16 path (H = 128 only)."""
+    runs; BASELINE.md's caveat): batch of 16 meshes, training step and rollout step.  Hidden 32 runs on the generic
+    exact-fp32 MFMA kernels (k_mlp_fwd / k_mlp_bwd / k_wgrad at HB = 2), not on the packed split-bf16 path (H = 128 only); a step is
+    ~170 launches of 5-80 us, so the record's figures are hipGraph REPLAY (Engine.capture_train_step; Engine.rollout replays by itself
+    on a static mesh), with the eager figures beside them."""
     cfg = gp.cylinder_config(5, 32)
     eng = harness.Engine(cfg, dev, learning_rate=1e-4, num_steps=10000, warmup=100)
     b = gp.cylinder_batch(args.batch, args.nodes, 0).to(dev)
     n, e = int(b.x.shape[0]), int(b.edge_index.shape[1])
     b.mgn_topology = ops.Topology(b.edge_index, n)
+
+    def timed_loop(fn, k):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k
+
     for _ in range(10):
         eng.train_step(b)
-    torch.cuda.synchronize()
-    k = 50
-    t0 = time.perf_counter()
-    for _ in range(k):
-        eng.train_step(b)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / k
+    dt_eager = timed_loop(lambda: eng.train_step(b), 50)
     frames = [b] * 20
-    eng.rollout(frames[:3])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.rollout(frames)
-    torch.cuda.synchronize()
-    dr = (time.perf_counter() - t0) / len(frames)
+    eng.rollout(frames[:3], graph="off")
+    dr_eager = timed_loop(lambda: eng.rollout(frames, graph="off"), 2) / len(frames)
+    dt, dr, launch = dt_eager, dr_eager, "eager"
+    if args.graph != "off":
+        try:
+            eng.capture_train_step(b, warmup=3)
+            dt = timed_loop(lambda: eng.train_step_graphed(None), 200)
+            eng.rollout(frames)            # graph="auto": captures a step on the first call
+            dr = timed_loop(lambda: eng.rollout(frames), 3) / len(frames)
+            launch = "hipGraph replay (training: Engine.capture_train_step; rollout: Engine.rollout, graph='auto')"
+        except Exception as ex:  # noqa: BLE001
+            print(f"[bench] hipGraph capture of the shipped-config step failed ({type(ex).__name__}: {ex}); eager figures", file=sys.stderr)
     return {"workload": f"training_config/cylinder.json as shipped: 5 MP rounds, latent 32, {args.batch} x {args.nodes}-node meshes per step (N={n}, E={e})",
-            "kernels": "generic exact-fp32 MFMA kernels (k_mlp_fwd<2,..> / k_mlp_bwd<2,..> / k_wgrad<2>, v_mfma_f32_16x16x4_f32); the packed split-bf16 path needs hidden 128",
+            "kernels": "generic exact-fp32 MFMA kernels (k_mlp_fwd<2,..> / k_mlp_bwd<2,..> / k_wgrad_row64, v_mfma_f32_16x16x4_f32); the packed split-bf16 path needs hidden 128",
             "train_steps_per_s": round(1.0 / dt, 1), "train_ms_per_step": round(1e3 * dt, 3),
-            "rollout_ms_per_step": round(1e3 * dr, 3), "rollout_node_steps_per_s": round(n / dr, 1), "launch": "eager"}
+            "rollout_ms_per_step": round(1e3 * dr, 3), "rollout_node_steps_per_s": round(n / dr, 1), "launch": launch,
+            "eager_train_ms_per_step": round(1e3 * dt_eager, 3), "eager_rollout_ms_per_step": round(1e3 * dr_eager, 3)}
 
 
 def plate_bf16_record(args, gp, ops, harness, dev):
@@ -493,7 +506,7 @@ def plate_bf16_record(args, gp, ops, harness, dev):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / k
             frames = [b] * 20
-            roll = eng.rollout
+            roll = lambda fr: eng.rollout(fr, graph="off")  # noqa: E731
             if use_graph:
                 eng.capture_rollout_step(b)
                 roll = eng.rollout_graphed
@@ -1059,7 +1072,7 @@ def main():
 
     # rollout (second half of the metric): one mesh batch advanced autoregressively
     frames = [batch] * args.rollout_steps
-    rollout, rollout_note = eng.rollout, "eager"
+    rollout, rollout_note = (lambda fr: eng.rollout(fr, graph="off")), "eager"
     # single process only: with a live RCCL process group its watchdog thread polls events, which is
     # not allowed while another thread captures; at batch 16 replay and eager rollout time the same
     if args.graph != "off" and world == 1:

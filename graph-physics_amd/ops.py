@@ -736,7 +736,7 @@ def set_grad_ready_hook(fn) -> None:
 
 #: activation recompute of the processor: "off" (save every round's activations: 2.5 KB per edge + 3 KB per
 #: node and round), "on", or "auto" (default): on when the saves would not fit comfortably -- more than
-#: MGN_RECOMPUTE_FRACTION (0.5) of the free device memory.  The 1M-node / 6M-edge mesh needs ~270 GB of
+#: MGN_RECOMPUTE_FRACTION (0.65) of the free device memory.  The 1M-node / 6M-edge mesh needs ~270 GB of
 #: saves for 15 rounds: with recompute it trains on ONE MI355X (~50 GB), at the price of one extra
 #: training-mode forward per round inside the backward pass.
 def _parse_recompute_env(v: str):
@@ -776,7 +776,8 @@ def saved_activation_bytes(E: int, Nn: int, H: int, NL: int, L: int, act: int, s
 def recompute_rounds(E, Nn, H, NL, L, act, dev, save16: bool = False) -> int:
     """how many of the L rounds keep only their inputs and are re-run in the backward pass (the FIRST ones: they are
     differentiated last, when the saved rounds have been released).  "auto": as many rounds are saved as fit in
-    MGN_RECOMPUTE_FRACTION (default 0.5) of the free device memory -- 0 recomputed on the bench batch, 6 of 15 on the
+    MGN_RECOMPUTE_FRACTION (default 0.65; round 5: 0.5 left 65 GiB of the 268 unused on the 1M-node mesh -- tools/c4_recompute_sweep.py:
+    438 / 431 / 424 / 417 ms per step at 7 / 6 / 5 / 4 recomputed rounds, peak 203 / 217 / 231 / 245 GiB) of the free device memory -- 0 recomputed on the bench batch, 5 of 15 on the
     1M-node mesh on one GPU (all 15 before round 3: one extra forward per step where 40 % of one is enough)."""
     if _recompute_mode == "on":
         return L
@@ -791,7 +792,7 @@ def recompute_rounds(E, Nn, H, NL, L, act, dev, save16: bool = False) -> int:
         free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
     except Exception:  # noqa: BLE001
         return 0
-    frac = float(_os.environ.get("MGN_RECOMPUTE_FRACTION", "0.5"))
+    frac = float(_os.environ.get("MGN_RECOMPUTE_FRACTION", "0.65"))
     per_round = saved_activation_bytes(E, Nn, H, NL, 1, act, save16)
     fit = int(frac * free // max(per_round, 1))
     return max(0, L - fit)

@@ -141,6 +141,24 @@ def _worker_partition_rope(rank, world, port, q):
     loss.backward()
     D.GradAllReduce(average=False)(net.parameters())
     grads = {k: v.grad.numpy().copy() for k, v in net.named_parameters()}
+    # [r5, advisor] a deforming mesh: the SAME module called with moved positions must use them -- owned rows and ghosts -- not the
+    # rows of its first call; and cache_positions=True keeps the ghosts until invalidate_positions()
+    pos2 = pos * 1.5 + 0.25
+    with torch.no_grad():
+        moved = pm(x_in[plan.owned], e_in[plan.edge_ids], phi_own=phi[plan.owned], pos_own=pos2[plan.owned])
+        fresh = D.PartitionedEPD(net, plan, backend=OracleBackend())(x_in[plan.owned], e_in[plan.edge_ids], phi_own=phi[plan.owned],
+                                                                     pos_own=pos2[plan.owned])
+        assert torch.equal(moved, fresh)
+        assert torch.equal(pm._pos_full[plan.n_own:], pos2[plan.ghost].float())
+        assert float((moved - out.detach()).abs().max()) > 1e-4     # the positions do matter to this model
+        pc = D.PartitionedEPD(net, plan, backend=OracleBackend(), cache_positions=True)
+        pc(x_in[plan.owned], e_in[plan.edge_ids], phi_own=phi[plan.owned], pos_own=pos[plan.owned])
+        pc(x_in[plan.owned], e_in[plan.edge_ids], phi_own=phi[plan.owned], pos_own=pos2[plan.owned])
+        assert torch.equal(pc._pos_full[plan.n_own:], pos[plan.ghost].float())       # cached ghosts, as promised by the caller
+        assert torch.equal(pc._pos_full[:plan.n_own], pos2[plan.owned].float())      # owned rows always follow the argument
+        pc.invalidate_positions()
+        again = pc(x_in[plan.owned], e_in[plan.edge_ids], phi_own=phi[plan.owned], pos_own=pos2[plan.owned])
+        assert torch.equal(again, fresh)
     q.put((rank, plan.owned.numpy().copy(), out.detach().numpy().copy(), float(loss.detach()), grads))
     dist.barrier()
     dist.destroy_process_group()

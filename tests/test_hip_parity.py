@@ -585,10 +585,26 @@ def test_rollout_graphed_equals_eager(dev):
         f.x[:, :2] += 0.01 * k
         f.y = base.y + 0.02 * k
         frames.append(f)
-    eager = eng.rollout(frames)
+    eager = eng.rollout(frames, graph="off")
     eng.capture_rollout_step(frames[0])
     graphed = eng.rollout_graphed(frames)
     for a, b in zip(eager, graphed):
+        assert torch.equal(a, b)
+    # [r5] rollout(graph="auto"): frames on ONE edge_index tensor replay a captured step, same bits; frames on different tensors
+    # (these clones) run eagerly
+    assert eng._rollout_graph_key(frames) is None
+    shared = []
+    for f in frames:
+        s = gp.Graph(x=f.x, y=f.y, pos=f.pos, edge_attr=f.edge_attr, edge_index=base.edge_index)
+        shared.append(s)
+    assert eng._rollout_graph_key(shared) is not None
+    eng._r_graph = None
+    auto = eng.rollout(shared)
+    assert eng._r_graph is not None                      # it captured
+    for a, b in zip(eager, auto):
+        assert torch.equal(a, b)
+    again = eng.rollout(shared)                          # second trajectory on the same mesh: no new capture
+    for a, b in zip(eager, again):
         assert torch.equal(a, b)
 
 

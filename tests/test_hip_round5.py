@@ -66,3 +66,42 @@ def test_producer_consumer_weight_gradient_is_fp32_grade_on_a_wide_dynamic_range
     A, B, dW = jobs[0][0], jobs[0][3], jobs[0][7]
     bound = A.double().abs().t() @ B.double().abs()
     assert float(((dW.double() - refs[0][0]).abs() / bound).max()) < 3e-7
+
+
+@pytest.mark.gpu
+def test_bf16_mode_off_the_packed_path_reports_parameters_to_the_grad_ready_hook(dev):
+    """advisor r4: at H != 128 the bf16 matrix mode multiplies bf16-rounded COPIES of the weights; what ProcessorFunction saves for
+    autograd's version check and what it reports to the grad-ready hook must still be the PARAMETERS (the overlapped all-reduce
+    looks gradients up by the parameter's storage), and a second forward after an in-place weight update must see the new weights
+    (the rounded copies are never cached: the fused optimiser writes through raw pointers)"""
+    import graph_physics_amd as gp
+    from graph_physics_amd import ops
+    sys_path_golden()
+    import recipe as R
+    L, H, N = 2, 32, 300
+    _, ei, ea = R.delaunay_graph(N, 3)
+    net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H).to(dev)
+    g = gp.Graph(x=R.randn((N, 11), 4).to(dev), edge_attr=R.randn((ea.shape[0], 3), 5).to(dev), edge_index=ei.to(dev))
+    ptrs = {p.data_ptr() for p in net.parameters()}
+    seen = []
+    ops.set_matrix_precision("bf16")
+    ops.set_grad_ready_hook(lambda pairs: seen.extend(pairs))
+    try:
+        out1 = net(g)
+        out1.square().sum().backward()
+        assert seen and all(p.data_ptr() in ptrs for p, _ in seen), "the hook must receive parameters, not rounded copies"
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(1.25)                        # what an optimiser step does, in place
+            out2 = net(g)
+        assert float((out2 - out1.detach()).abs().max()) > 1e-3 * float(out1.detach().abs().max())
+    finally:
+        ops.set_grad_ready_hook(None)
+        ops.set_matrix_precision("fp32")
+
+
+def sys_path_golden():
+    import sys
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if d not in sys.path:
+        sys.path.insert(0, d)
