@@ -1712,6 +1712,134 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_row64(const WgradLaunch L) {
 }
 
 
+// [r5] The same jobs on the split-bf16 matrix path (fp32-grade: six bf16 terms, fp32 accumulate, as k_wgrad_x6): a tile is 32 rows = ONE
+// K = 32 step.  Lane (c, g) fetches features 4c .. 4c + 3 of rows 8g .. 8g + 7 (eight 16-byte loads per operand: a wave instruction is four
+// 256-byte row pieces), so for each of its four features it HOLDS the eight K values of an MFMA operand lane; split8 makes the three
+// pieces, block q multiplies the strided feature set {q, 4 + q, ..} as in k_wgrad_row64, same accumulator / store mapping.  96 bf16 MFMAs
+// of 16 cycles per 32 rows where the exact-fp32 form issues 128 of 32 cycles: the exact form was matrix-bound (three 64 x 64 jobs over
+// 150 000 rows = 30 us of fp32 MFMA issue in a 57 us launch, profiles/r04_c5_fp32_kernel_stats.csv).  The next tile's loads are issued
+// as soon as an operand's rows have been split (they land under the 96 MFMAs); MGN_FP32_MFMA=1 keeps the exact-fp32 kernel.
+template <bool FULL>   // FULL: every job of the launch is 64 x 64 with kw = 64 (no lane is masked)
+__global__ void __launch_bounds__(256, 2) k_wgrad_row64x6(const WgradLaunch L) {
+  constexpr int H = 64;
+  __shared__ float red[3][H * H + H];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  int j = 0;
+  while (j + 1 < L.njobs && (int)blockIdx.x >= L.wg0[j + 1]) ++j;
+  const mgn_wgrad_job J = L.job[j];
+  const int nwg = L.wg0[j + 1] - L.wg0[j];
+  const int wg = blockIdx.x - L.wg0[j];
+  const long ntiles = (J.M + 31) >> 5;
+  const long t0 = ntiles * wg / nwg, t1 = ntiles * (wg + 1) / nwg;
+  const bool a_on = FULL || 4 * c < 16 * J.nja, b_on = FULL || 4 * c < J.kw;
+  f32x4 acc[4][4];  // [qa][qb]
+#pragma unroll
+  for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) acc[qa][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 av[8], bv[8];
+  // addressing: a wave-uniform row pointer (scalar registers) + ONE loop-invariant 32-bit lane offset per operand; rows past M read
+  // row M - 1 (A's are zeroed: 0 x finite = 0), masked lanes read column 0 and are zeroed
+  const unsigned voa = (unsigned)((8 * g * J.lda + (a_on ? 4 * c : 0)) * 4), vob = (unsigned)((8 * g * J.ldb + (b_on ? 4 * c : 0)) * 4);
+  auto load_op = [&](const float* X, int ld, unsigned vo, bool on, bool is_a, long tile, f32x4 (&v)[8]) {
+    if ((tile + 1) * 32 <= J.M) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = *(g_cf32x4*)((const char*)(X + (tile * 32 + r) * ld) + vo);
+    } else {
+      const long r0 = tile * 32 + 8 * g;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const long row = r0 + r < J.M ? r0 + r : J.M - 1;
+        v[r] = ld4(X + row * ld + (on ? 4 * c : 0));
+        if (is_a && r0 + r >= J.M) v[r] = zero;
+      }
+    }
+    if (!FULL && !on) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = zero;
+    }
+  };
+  // B's four blocks are split first (48 registers of pieces, its rows re-loaded at once); A's blocks one at a time, each
+  // followed by its 24 MFMAs (the accumulators carry the sums of all earlier tiles: the order within a tile does not matter)
+  u32x4 bp[4][3];
+  auto split_blk = [&](const f32x4 (&v)[8], int q, u32x4 (&p)[3]) {
+    const float x[8] = {v[0][q], v[1][q], v[2][q], v[3][q], v[4][q], v[5][q], v[6][q], v[7][q]};
+    split8(x, p[0], p[1], p[2]);
+  };
+  long tile = t0 + wv;
+  if (tile < t1) {
+    load_op(J.A, J.lda, voa, a_on, true, tile, av);
+    load_op(J.B, J.ldb, vob, b_on, false, tile, bv);
+    for (; tile < t1; tile += 4) {
+      const bool more = tile + 4 < t1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split_blk(bv, q, bp[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) load_op(J.B, J.ldb, vob, b_on, false, tile + 4, bv);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) cs += av[r];
+#pragma unroll
+      for (int qa = 0; qa < 4; ++qa) {
+        u32x4 ap[3];
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler hoists all four splits otherwise: 256 registers + scratch)
+        split_blk(av, qa, ap);
+        if (qa == 3) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) load_op(J.A, J.lda, voa, a_on, true, tile + 4, av);
+        }
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+          const int pa = (term == 0) ? 2 : (term == 1) ? 0 : (term == 2 || term == 3) ? 1 : 0;
+          const int pb = (term == 0) ? 0 : (term == 1) ? 2 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 1 : 0;
+#pragma unroll
+          for (int qb = 0; qb < 4; ++qb) acc[qa][qb] = MFMA_BF(ap[pa], bp[qb][pb], acc[qa][qb]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cs[q] = rowsum4(cs[q]);
+  auto put = [&](float* dst) {
+#pragma unroll
+    for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 o = {acc[qa][0][v], acc[qa][1][v], acc[qa][2][v], acc[qa][3][v]};
+        *(f32x4*)(dst + (16 * g + 4 * v + qa) * H + 4 * c) = o;
+      }
+    if (g == 0) *(f32x4*)(dst + H * H + 4 * c) = cs;
+  };
+  if (wv > 0) put(red[wv - 1]);
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+      for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const f32x4 o = *(const f32x4*)(red[w] + (16 * g + 4 * v + qa) * H + 4 * c);
+#pragma unroll
+          for (int qb = 0; qb < 4; ++qb) acc[qa][qb][v] += o[qb];
+        }
+      cs += *(const f32x4*)(red[w] + H * H + 4 * c);
+    }
+    float* P = L.partial + (size_t)blockIdx.x * (H * H + H);
+#pragma unroll
+    for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 o = {acc[qa][0][v], acc[qa][1][v], acc[qa][2][v], acc[qa][3][v]};
+        st4(P + (16 * g + 4 * v + qa) * H + 4 * c, o);
+      }
+    if (g == 0 && J.db != nullptr) st4(P + H * H + 4 * c, cs);
+  }
+}
+
+
 // dW[r,k] = sum over the job's workgroup partials.  64 outputs x 4 partial-lanes per block:
 // consecutive threads read consecutive addresses of one partial (coalesced), four lanes walk
 // the partials interleaved (short dependent chains), then a fixed-order LDS combine.
@@ -2796,6 +2924,14 @@ int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes,
     } else if (row64) {
       if (precision == 1)
         hipLaunchKernelGGL(k_wgrad_row64<true>, dim3(total), dim3(256), 0, s, L);
+      else if (getenv("MGN_FP32_MFMA") == nullptr && getenv("MGN_WGRAD_ROW64_EXACT") == nullptr) {   // [r5] fp32-grade on the split-bf16 matrix path
+        bool full = true;
+        for (int j = 0; full && j < L.njobs; ++j) full = L.job[j].nja == 4 && L.job[j].kw == 64;
+        if (full)
+          hipLaunchKernelGGL(k_wgrad_row64x6<true>, dim3(total), dim3(256), 0, s, L);
+        else
+          hipLaunchKernelGGL(k_wgrad_row64x6<false>, dim3(total), dim3(256), 0, s, L);
+      }
       else
         hipLaunchKernelGGL(k_wgrad_row64<false>, dim3(total), dim3(256), 0, s, L);
     } else {
