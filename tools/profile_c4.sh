@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the 1M-node kernels (run on the GPU box from the repo root through gpurun): kernel trace of
 # tools/c4_kernels.py, then FETCH_SIZE / WRITE_SIZE passes over the scatter-add kernels alone (counters only, separate runs).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$R/gpurun_out/prof_c4_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
