@@ -105,3 +105,44 @@ def sys_path_golden():
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     if d not in sys.path:
         sys.path.insert(0, d)
+
+
+@pytest.mark.gpu
+def test_default_inference_path_at_the_bench_batch_vs_oracle(dev):
+    """the ping-pong edge kernel takes the inference-mode launches from 65 536 edge rows BY DEFAULT, and was checked
+    against the oracle only through the 1M-node closure test.  Here directly: the bench batch (16 meshes, E = 180 082 rows per
+    launch), 3 rounds, no_grad forward against the CPU oracle, 1e-5 in all three readings."""
+    import graph_physics_amd as gp
+    from conftest import assert_close3
+    from oracle import mgn_oracle as O
+    sys_path_golden()
+    import recipe as R
+    L = 3
+    g = gp.cylinder_batch(16, 1885, 0)
+    N, E = g.x.shape[0], g.edge_index.shape[1]
+    assert E >= 65536 and os.environ.get("MGN_PP") in (None, "")
+    params = R.make_params(R.epd_param_shapes(L, 128, 11, 3, 2), 91)
+    x_in, e_in = R.randn((N, 11), 92), R.randn((E, 3), 93)
+    ref = O.epd_forward(x_in, e_in, g.edge_index, params, L)
+    net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=128).to(dev)
+    net.load_state_dict(params)
+    graph = gp.Graph(x=x_in.to(dev), edge_attr=e_in.to(dev), edge_index=g.edge_index.to(dev))
+    with torch.no_grad():
+        out = net(graph)
+    assert_close3(out.cpu(), ref, 1e-5, "inference forward, batch 16, default (ping-pong) edge kernel")
+
+
+@pytest.mark.gpu
+def test_training_mode_ping_pong_instance_vs_oracle(dev, monkeypatch):
+    """... and the TRAINING-mode instance (opt-in, MGN_PP=1: saves, masks, fused aggregation out of the ping-pong kernel) against
+    the oracle at the same size: forward 1e-5, gradients by the flip-aware criterion of tests/test_hip_configs.py (fp32 + fp64
+    oracle) -- an oracle-side test for that instance before it could ever become a default."""
+    import graph_physics_amd as gp
+    from conftest import assert_close3
+    from test_hip_configs import _check_grads, _grad_case
+    monkeypatch.setenv("MGN_PP", "1")
+    g = gp.cylinder_batch(16, 1885, 0)
+    out, grads, (o32, g32), (o64, g64), (flips, total, worst) = _grad_case(dev, g, 3, 94)
+    assert_close3(out, o32, 1e-5, "training-mode forward through k_edge_fwd_pp<true>")
+    assert flips <= 1e-6 * total, (flips, total)
+    _check_grads(grads, g32, g64, flips, worst)
