@@ -1845,7 +1845,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_row64x6(const WgradLaunch L) {
 // the partials interleaved (short dependent chains), then a fixed-order LDS combine.
 // (1024 threads = 64 elements x 16 groups of partials: a group sums every 16th partial, two accumulators; 4 groups of 256
 //  threads walked 128 partials each through dependent 16 KB-strided loads -- 13-15 us per launch, 72 launches per Transformer step)
-#define WRED_GROUPS 16
+// [r5] WRED_GROUPS is a template argument: with at most 64 partials per job (the producer / consumer kernel's 256 workgroups shared by ten
+// jobs; every launch of a one-mesh batch) four groups do -- 2 580 blocks of 1 024 threads for 165 000 sums cost 9-11 us per launch
+// whatever the partial count (21 launches per training step at batch 1).  The group count follows from the launch shape alone:
+// the summation order stays fixed run to run.
+template <int WRED_GROUPS>
 __global__ void __launch_bounds__(64 * WRED_GROUPS) k_wgrad_red(const WgradLaunch L) {
   __shared__ float red[WRED_GROUPS][64];
   const int H = L.H;
@@ -1860,7 +1864,7 @@ __global__ void __launch_bounds__(64 * WRED_GROUPS) k_wgrad_red(const WgradLaunc
   const bool is_w = i < rows * cols;
   const bool is_b = !is_w && i < rows * cols + rows && J.db != nullptr;
   int r = 0, k = 0;
-  float s0 = 0.f, s1 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (is_w || is_b) {
     const float* P;
     if (is_w) {
@@ -1872,13 +1876,17 @@ __global__ void __launch_bounds__(64 * WRED_GROUPS) k_wgrad_red(const WgradLaunc
       P = P0 + (size_t)H * H + r;
     }
     int b = pl;
-    for (; b + WRED_GROUPS < nwg; b += 2 * WRED_GROUPS) {
+    for (; b + 3 * WRED_GROUPS < nwg; b += 4 * WRED_GROUPS) {   // four independent chains: the loads are 66 KB apart (L2 misses)
       s0 += P[(size_t)b * st];
       s1 += P[(size_t)(b + WRED_GROUPS) * st];
+      s2 += P[(size_t)(b + 2 * WRED_GROUPS) * st];
+      s3 += P[(size_t)(b + 3 * WRED_GROUPS) * st];
     }
     if (b < nwg) s0 += P[(size_t)b * st];
+    if (b + WRED_GROUPS < nwg) s1 += P[(size_t)(b + WRED_GROUPS) * st];
+    if (b + 2 * WRED_GROUPS < nwg) s2 += P[(size_t)(b + 2 * WRED_GROUPS) * st];
   }
-  red[pl][threadIdx.x & 63] = s0 + s1;
+  red[pl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (pl == 0) {
     float v = 0.f;  // fixed order: deterministic
@@ -2943,7 +2951,12 @@ int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes,
       }
     }
     if (int rc = check_launch("mgn_wgrad")) return rc;
-    hipLaunchKernelGGL(k_wgrad_red, dim3((L.H * L.H + L.H + 63) / 64, L.njobs), dim3(64 * WRED_GROUPS), 0, s, L);
+    int max_nwg = 0;
+    for (int j = 0; j < L.njobs; ++j) max_nwg = (L.wg0[j + 1] - L.wg0[j] > max_nwg) ? L.wg0[j + 1] - L.wg0[j] : max_nwg;
+    if (max_nwg <= 64)
+      hipLaunchKernelGGL(k_wgrad_red<4>, dim3((L.H * L.H + L.H + 63) / 64, L.njobs), dim3(64 * 4), 0, s, L);
+    else
+      hipLaunchKernelGGL(k_wgrad_red<16>, dim3((L.H * L.H + L.H + 63) / 64, L.njobs), dim3(64 * 16), 0, s, L);
     if (int rc = check_launch("mgn_wgrad/reduce")) return rc;
   }
   return 0;

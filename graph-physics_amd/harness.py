@@ -363,6 +363,7 @@ class Engine:
         with torch.cuda.graph(g):
             self._r_pred = body()
         self._r_graph, self._r_static, self._r_last = g, st, last
+        self._r_seen = {}
         return g
 
     @torch.no_grad()
@@ -370,11 +371,25 @@ class Engine:
         """``rollout`` through the captured step (same shapes / topology for every frame)."""
         st, i0, i1 = self._r_static, self.sim.output_index_start, self.sim.output_index_end
         out = []
+        # a field whose source is the very tensor OBJECT copied last, at the same version, is not copied again: the mesh's edge
+        # features -- and, for a repeated frame, everything -- stay in place (3 launches of ~5 us each per step otherwise).  The
+        # object is kept referenced: an address alone may be recycled by the allocator for another frame's data.
+        seen = getattr(self, "_r_seen", None)
+        if seen is None:
+            seen = self._r_seen = {}
+
+        def put(name, dst, src):
+            last = seen.get(name)
+            if src is dst or (last is not None and last[0] is src and last[1] == src._version):
+                return
+            dst.copy_(src, non_blocking=True)
+            seen[name] = (src, src._version)
+
         for k, fr in enumerate(frames):
             if fr is not st:
-                st.x.copy_(fr.x, non_blocking=True)
-                st.y.copy_(fr.y, non_blocking=True)
-                st.edge_attr.copy_(fr.edge_attr, non_blocking=True)
+                put("x", st.x, fr.x)
+                put("y", st.y, fr.y)
+                put("edge_attr", st.edge_attr, fr.edge_attr)
             if k == 0:
                 self._r_last.copy_(fr.x[:, i0:i1])
             self._r_graph.replay()
