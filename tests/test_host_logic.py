@@ -259,3 +259,42 @@ def test_recompute_env_is_validated():
     assert ops._parse_recompute_env("6") == 6 and ops._parse_recompute_env(" auto ") == "auto"
     with pytest.raises(ValueError):
         ops._parse_recompute_env("onn")
+
+
+def test_round5_host_logic_recompute_size_rollout_modes_and_bench_ceilings():
+    """host-side pieces of round 5 that need no GPU: the two-byte saves are priced in the recompute estimate (advisor r4), the
+    rollout's replay switch validates its argument and falls back to the eager loop for frames it cannot key (CPU tensors,
+    different edge_index tensors), the streaming ceiling of a roofline object interpolates the read : write probe, and the PMC
+    traffic summary matches the scatter kernel's current name (`k_segsum2<8, false>` matched nothing)."""
+    import importlib.util
+    import os
+    from graph_physics_amd import ops
+
+    E, N, H, NL = 1000, 100, 128, 4
+    full, half = ops.saved_activation_bytes(E, N, H, NL, 1, 0), ops.saved_activation_bytes(E, N, H, NL, 1, 0, save16=True)
+    assert full - half == E * 2 * H * (NL - 1)          # H1..H3 of the EDGE rows at two bytes per value; node rows unchanged
+
+    eng = harness.Engine.__new__(harness.Engine)       # no device needed for the key logic
+    eng.grad_sync = None
+    g = gp.cylinder_mesh(64, 0)
+    frames = [g, g, g, g]
+    assert eng._rollout_graph_key(frames) is None       # CPU tensors: never replayed
+    with pytest.raises(ValueError):
+        eng.rollout(frames, graph="maybe")
+    with pytest.raises(ValueError):
+        eng.rollout(frames, graph="on")                 # "on" demands frames it can key
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.rw_ceiling_gbps(0.0) == pytest.approx(6370.0) and bench.rw_ceiling_gbps(1.0) == pytest.approx(4516.0)
+    assert 4890.0 <= bench.rw_ceiling_gbps(0.4) <= 4935.0 and bench.rw_ceiling_gbps(-1) == bench.rw_ceiling_gbps(0)
+    o = bench.hbm_obj("k", 0.1, 1e9, traffic=None, write_bytes=0.0)
+    assert o["read_bytes"] == int(1e9) and o["write_bytes"] == 0 and o["ceiling_gbps"] == 6370.0 and o["frac"] == pytest.approx(1e9 / 1e-4 / 1e9 / 8000.0, rel=1e-3)
+
+    src = open(os.path.join(repo, "tools", "pmc_traffic_summary.py")).read()
+    keys = [ln for ln in src.splitlines() if "k_segsum2<8" in ln and "KEYS" not in ln[:4]]
+    assert any('("k_segsum2<8", None)' in ln for ln in src.splitlines())
+    assert "k_segsum2<8, false>".startswith("k_segsum2<8") and not "k_segsum2<8, false>".startswith("k_segsum2<8>")
+    assert '("k_wgrad_pc", 256)' in src
