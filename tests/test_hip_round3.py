@@ -256,6 +256,37 @@ def test_c4_gradients_at_full_size_via_closure(dev, recompute):
     print(f"C4 gradients (recompute {recompute}): worst parameter {worst:.2e}")
 
 
+def test_c4_gradients_15_rounds_via_closure(dev):
+    """[r5] the config's own depth: every parameter gradient of the 15-round 1M-node training step -- partial activation recompute as
+    "auto" picks it (5 of 15 rounds re-run), k_wgrad_pc and k_segsum2 at 6M rows -- against the oracle on the 15-hop closures of six
+    seed nodes (SiLU network: no ReLU branch flips to blur the bar)"""
+    g = _c4_mesh()
+    N, ei = g.x.shape[0], g.edge_index
+    L = 15
+    params = R.make_params(R.epd_param_shapes(L, 128, 11, 3, 2), 26)
+    x_in = torch.randn(N, 11, generator=torch.Generator().manual_seed(22))
+    seeds = np.array([0, 1, N // 2, N // 2 + 1, N - 2, N - 1])
+    cot = R.randn((seeds.size, 2), 28)
+    nodes, kept, loc, sub_ei = _closure(ei, N, seeds, L)
+    assert nodes.size < 20000, nodes.size
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.epd_forward(x_in[nodes], g.edge_attr[torch.from_numpy(kept)], sub_ei, P, L, act="silu")
+    (ref[loc[seeds]] * cot).sum().backward()
+    with silu_models():
+        net = gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=128).to(dev)
+    net.load_state_dict(params)
+    graph = gp.Graph(x=x_in.to(dev), edge_attr=g.edge_attr.to(dev), edge_index=ei.to(dev), pos=g.pos.to(dev))
+    out = net(graph)
+    (out[torch.from_numpy(seeds).to(dev)] * cot.to(dev)).sum().backward()
+    assert_close3(out.detach().cpu()[seeds], ref.detach()[loc[seeds]], FWD_TOL, "forward on the seeds, 15 rounds")
+    worst = 0.0
+    for k, p in net.named_parameters():
+        e = rel_err(p.grad, P[k].grad)
+        worst = max(worst, e)
+        assert e < GRAD_TOL, (k, e)
+    print(f"C4 gradients, 15 rounds: worst parameter {worst:.2e}")
+
+
 def test_c4_relu_gradients_at_full_size_via_closure(dev):
     """The DEFAULT activation at the 1M-node size (every shipped JSON is ReLU, the large-M gradient
     checks ran SiLU networks): same closure construction, ReLU network, flip-aware bar -- a gradient either agrees with the
