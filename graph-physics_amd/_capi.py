@@ -25,7 +25,7 @@ DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 MAX_LAYERS = 8
 MAX_PHASES = 3
-MAX_WGRAD_JOBS = 12
+MAX_WGRAD_JOBS = 48
 
 _f32p = C.c_void_p  # raw device pointers travel as integers
 _i32p = C.c_void_p
@@ -254,7 +254,7 @@ _lock = threading.Lock()
 
 #: ABI version this binding was written against (mgn_version() of the library must match: the
 #: ctypes structs above mirror exactly that header)
-EXPECTED_VERSION = 132
+EXPECTED_VERSION = 133
 HASH_PATH = os.path.join(_CSRC, "libmgn_hip.srchash")
 LOCK_PATH = os.path.join(_CSRC, ".build.lock")
 

@@ -1264,6 +1264,32 @@ class ProcessorFunction(torch.autograd.Function):
             wdone = [None, None]
             main = torch.cuda.current_stream(dev)
         dx_buf, de_buf = [mk(Nn, H, **f), mk(Nn, H, **f)], [mk(E, H, **f), mk(E, H, **f)]
+        # [r5] Weight gradients of SEVERAL rounds in one launch (up to MAX_WGRAD_JOBS jobs = 4 rounds of the default block): a
+        # round's dW depends on nothing the rest of the backward pass waits for, so its jobs can wait until a launch is full -- one
+        # k_wgrad_pc + one k_wgrad_red per four rounds instead of per round (a one-mesh step: 39 -> 11 weight-gradient launches
+        # of ~14 us each).  The operands of a waiting round (dZ rows, the two scatters, the round's saved activations) stay alive
+        # until the launch and are read back from HBM instead of the Infinity Cache, so only steps whose rounds are small do it
+        # (MGN_WGRAD_BATCH_MB, default 256 MB per waiting round; 0: one launch per round.  Measured, tools/ab_wbatch.sh: one mesh
+        # per step 3.03 -> 2.88 ms; the 16-mesh batch -- 953 MB per round -- 12.60-12.64 against 12.53-12.70 ms: the launches it saves
+        # there are paid back by dZ rows that no longer come out of the cache the chain kernel just wrote them through); not with a
+        # grad-ready listener (it wants every round's gradients as soon as possible), a side
+        # stream, the partitioned mesh or the fused edge backward.
+        per_round_mb = 4.0 * H * ((2 * NL + 1) * E + (NL + 7) * Nn) / 2**20
+        wb_rounds = max(1, _capi.MAX_WGRAD_JOBS // (2 * NL + 3 + (1 if spec.gate else 0)))
+        defer_w = (x6 and side is None and halo is None and _grad_ready_hook is None and not empty and wb_rounds > 1
+                   and _os.environ.get("MGN_FUSED_BWD", "0") != "1"
+                   and per_round_mb <= float(_os.environ.get("MGN_WGRAD_BATCH_MB", "256")))
+        w_pend, w_rounds = [], 0
+        dzn_round = {}
+
+        def dzn_of(r):
+            """dZn rows of round r: a set of its own per round while weight-gradient jobs wait, the two alternating sets otherwise"""
+            if not defer_w:
+                return dZn_sets[r & 1]
+            if r not in dzn_round:
+                dzn_round[r] = [mk(Nn, H, **f) for _ in range(NL)]
+            return dzn_round[r]
+
         grads: List[Optional[torch.Tensor]] = [None] * (PB * L)
         nb = H // 16
         HH = H * H
@@ -1347,7 +1373,10 @@ class ProcessorFunction(torch.autograd.Function):
             gbn = [g[k_ + 2 * l + 1] for l in range(NL)]
             gse = g[2 * NL] if spec.layer_norm else None
             gsn = g[k_ + 2 * NL] if spec.layer_norm else None
-            dZn = dZn_sets[i & 1]
+            dZn = dzn_of(i)
+            if defer_w:   # this round's operand rows must outlive the round: fresh ones (the caching allocator recycles them)
+                dZe = [torch.empty_like(t) for t in dZe]
+                Sd, Ss = mk(N, H, **f), mk(N, H, **f)
             if side is not None:
                 dZn, dZe, Sd, Ss = wsets[i & 1]
                 if wdone[i & 1] is not None:  # the weight gradients of round i + 2 still read this set
@@ -1470,6 +1499,14 @@ class ProcessorFunction(torch.autograd.Function):
                         wgrad(alljobs, dev, prec)
                         wdone[i & 1] = torch.cuda.Event()
                         wdone[i & 1].record(side)
+                elif defer_w:
+                    w_pend += alljobs
+                    w_rounds += 1
+                    if w_rounds == wb_rounds or i == 0:
+                        wgrad(w_pend, dev, prec)
+                        w_pend, w_rounds = [], 0
+                        for r in [r for r in dzn_round if r >= i]:
+                            del dzn_round[r]
                 else:
                     wgrad(alljobs, dev, prec)
             if spec.gate:
@@ -1485,7 +1522,7 @@ class ProcessorFunction(torch.autograd.Function):
                 Sp = saved[i - 1]
                 _, _, _, _, _, snp, _ = _split_block(P[PB * (i - 1): PB * i], spec)
                 kn_p = [unit(i - 1, ukn + u) for u in range(NL)]
-                mlp_bwd(Nn, H, NL, dx, None, None, H, Sp["Un"], Sp["Rn"], snp, Sp["Hn"], WTn, dZn_sets[(i - 1) & 1],
+                mlp_bwd(Nn, H, NL, dx, None, None, H, Sp["Un"], Sp["Rn"], snp, Sp["Hn"], WTn, dzn_of(i - 1),
                         [(WT0n_agg, None, dAgg)], [None] * NL, gs[i - 1][k_ + 2 * NL], wpk=kx + kn_p, Ms=Sp["Mn"], precision=prec,
                         front=([dZn[0], Sd, Ss], dx, dx_new), defer=deferred)
                 node_done = True

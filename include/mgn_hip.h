@@ -39,7 +39,7 @@ extern "C" {
 
 #define MGN_MAX_LAYERS 8   /* Linear layers per MLP (reference uses 4) */
 #define MGN_MAX_PHASES 3   /* concatenated input blocks of the first layer */
-#define MGN_MAX_WGRAD_JOBS 12
+#define MGN_MAX_WGRAD_JOBS 48   /* [r5] 12 before: the jobs of four rounds of the default block in one launch (ops.py, MGN_WGRAD_BATCH_MB) */
 
 /* ABI version: major*10000 + minor*100 + patch. */
 int mgn_version(void);

@@ -53,7 +53,7 @@ def test_struct_layout_matches_header(tmp_path):
         assert int(got[name]) == ctypes.sizeof(st), name
         for fld, _ in st._fields_:
             assert int(got[f"{name}.{fld}"]) == getattr(st, fld).offset, f"{name}.{fld}"
-    assert c.MAX_LAYERS == 8 and c.MAX_PHASES == 3 and c.MAX_WGRAD_JOBS == 12
+    assert c.MAX_LAYERS == 8 and c.MAX_PHASES == 3 and c.MAX_WGRAD_JOBS == 48
     assert c.WPACK_BYTES == 98304
 
 
