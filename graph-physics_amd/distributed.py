@@ -301,7 +301,7 @@ class HipBackend:
         return module(x)
 
     def order_edges(self, edge_attr, ctx):
-        return edge_attr[ctx.perm_dst.long()]
+        return edge_attr[ctx.perm_dst_long]
 
     def block(self, block, x, e, ctx, pos=None, phi=None):
         from . import ops

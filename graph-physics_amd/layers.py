@@ -195,7 +195,7 @@ class GraphNetBlock(nn.Module):
         if self.use_rope and pos is None:
             raise ValueError("Node positions `pos` must be provided when use_rope=True.")
         topo = ops.get_topology(edge_index, x.shape[0])
-        e_sorted = edge_attr[topo.perm_dst.long()]
+        e_sorted = edge_attr[topo.perm_dst_long]
         if self.use_gated_mlp:
             from .gated import gated_block_forward
             x_new, e_new = gated_block_forward(self, x, e_sorted, topo, pos, phi)

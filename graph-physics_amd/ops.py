@@ -254,11 +254,18 @@ class Topology:
         return self.hub_dst is not None or self.hub_src is not None
 
     @property
+    def perm_dst_long(self) -> torch.Tensor:
+        """``perm_dst`` as int64 (what a torch row gather wants), converted once per topology instead of once per forward pass"""
+        if getattr(self, "_perm_long", None) is None:
+            self._perm_long = self.perm_dst.long()
+        return self._perm_long
+
+    @property
     def inv_perm(self) -> torch.Tensor:
         """position in the sorted order of each original edge id"""
         if self._inv is None:
             inv = torch.empty(self.E, dtype=torch.int64, device=self.device)
-            inv[self.perm_dst.long()] = torch.arange(self.E, device=self.device)
+            inv[self.perm_dst_long] = torch.arange(self.E, device=self.device)
             self._inv = inv
         return self._inv
 
@@ -925,7 +932,12 @@ class MlpFunction(torch.autograd.Function):
             mlp_bwd(M, H, NL, dy, None, None, out_w, U, R, scale, saveH, [None] * NL, dZ, din, [None] * NL, dscale,
                     wpk=units, Ms=Ms, Zs=Zs, act=act)
         else:
-            WT = [None] + [Wk[l].t().contiguous() for l in range(1, NL)]
+            # W^T operands of the generic chain: the H x H ones in ONE batched transpose launch (a torch transpose + copy each before)
+            sq = [l for l in range(1, NL) if tuple(Wk[l].shape) == (H, H) and Wk[l].is_contiguous()]
+            wt_buf = torch.empty(len(sq), H, H, **f) if sq else None
+            if sq:
+                transpose_blocks([(Wk[l].data_ptr(), H, wt_buf[k].data_ptr(), H) for k, l in enumerate(sq)], H, dev)
+            WT = [None] + [wt_buf[sq.index(l)] if l in sq else Wk[l].t().contiguous() for l in range(1, NL)]
             din = [(Wk[0].t().contiguous(), None, dx)] if want_dx else []
             # bias gradients are a by-product of the weight-gradient kernel (it reads dZ anyway)
             mlp_bwd(M, H, NL, dy, None, None, out_w, U, R, scale, saveH, WT, dZ, din, [None] * NL, dscale, act=act, Zs=Zs, precision=prec)
@@ -933,17 +945,17 @@ class MlpFunction(torch.autograd.Function):
         #  layer results are rounded by the kernels already)
         ins = [x.to(torch.bfloat16).to(torch.float32) if prec else x] + list(saveH)
         in_w = [kin] + [H] * (NL - 1)
-        dWs = [mk(widths[l], pad16(in_w[l]), **f) for l in range(NL)]
+        # (the first layer's gradient in its exact [H, kin] shape: the reduction writes columns < ldw only, so ldw = kin needs no
+        #  padded buffer -- and no strided slice that the optimiser would have to copy into a contiguous gradient every step)
+        dWs = [mk(widths[l], in_w[l], **f) for l in range(NL)]
         jobs = []
         for l in range(NL):
-            jobs.append((dZ[l], widths[l], widths[l] // 16, ins[l], in_w[l], pad16(in_w[l]) // 16, in_w[l], dWs[l], 0, pad16(in_w[l]), db[l]))
+            jobs.append((dZ[l], widths[l], widths[l] // 16, ins[l], in_w[l], pad16(in_w[l]) // 16, in_w[l], dWs[l], 0, in_w[l], db[l]))
         if M > 0:
             wgrad(jobs, dev)
         grads = []
         for l in range(NL):
             dW, dbl = dWs[l], db[l]
-            if l == 0 and kp != kin:
-                dW = dW[:, :kin]
             if l == NL - 1 and op != out_w:
                 dW, dbl = dW[:out_w], dbl[:out_w]
             grads += [dW, dbl]
@@ -1087,7 +1099,8 @@ class ProcessorFunction(torch.autograd.Function):
             Pd_, Ps_ = torch.empty(Nn, H, **f), torch.empty(N, H, **f)
             for slab, dst_t in ((1, Pd_), (2, Ps_)):
                 u = (unit(L, slab - 1) if i == 0 else unit(i - 1, up0 + slab - 1)) if x6 else None
-                mlp_fwd(Nn, H, [(xi, None, H)], [W0[:, slab * H:(slab + 1) * H].contiguous()], [None], None, H, None, dst_t,
+                # (packed path: the kernel multiplies by the packed unit, the fp32 slab is never dereferenced -- no copy of it)
+                mlp_fwd(Nn, H, [(xi, None, H)], [None if x6 else W0[:, slab * H:(slab + 1) * H].contiguous()], [None], None, H, None, dst_t,
                         wpk=[u] if x6 else (), precision=prec)
             return Pd_, Ps_
 

@@ -53,7 +53,7 @@ class EncodeProcessDecode(nn.Module):
             # cached per edge_index; built without a host synchronisation; large meshes are renumbered for locality
             # (ops.set_node_renumbering) -- node rows are permuted here on entry and back on exit
             topo = ops.get_topology(edge_index, n, pos=getattr(graph, "pos", None), renumber=True)
-        perm = topo.perm_dst.long()
+        perm = topo.perm_dst_long
         order, rank = topo.node_order, topo.node_rank
         x_in = graph.x if order is None else graph.x.index_select(0, order)
         if self.only_processor:

@@ -8,7 +8,7 @@ from graph_physics_amd import harness, ops
 from torch.profiler import profile, ProfilerActivity
 dev = torch.device("cuda:0")
 eng = harness.Engine(gp.cylinder_config(15, 128), dev, learning_rate=1e-4, num_steps=10000, warmup=100)
-batch = gp.cylinder_batch(16, 1885, 0).to(dev)
+batch = gp.cylinder_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 16, 1885, 0).to(dev)
 batch.mgn_topology = ops.Topology(batch.edge_index, batch.x.shape[0])
 for _ in range(3): eng.train_step(batch)
 torch.cuda.synchronize()
