@@ -399,6 +399,77 @@ class PartitionedEPD(torch.nn.Module):
         return be.mlp(m.decode_module, x_own)
 
 
+class PartitionedETD(torch.nn.Module):
+    """EncodeTransformDecode (processors.py:218-384, the sparse-attention branch) over a node-partitioned mesh [r5].
+
+    A Transformer block's attention row i = sum over the edges with ``edge_index[0] == i`` of softmax_i(q_i . k_j) v_j,
+    j = ``edge_index[1]`` (layers.py:493-559: rows of ``dglsp.spmatrix(indices=edge_index)``), so a rank must hold every edge
+    whose ROW it owns and the latents of the columns it does not own: build the plan on the FLIPPED edge list,
+
+        plan = partition.build_rank_plan(edge_index.flip(0), part, rank, world)
+
+    (its "destination" is then the attention row).  Per block the ghosts' latents are exchanged (``HaloExchange``:
+    differentiable, fixed-order backward), the block runs on owned + ghost rows -- the ghosts' k / v come out of their
+    exchanged latents, their own outputs (rows without their edges here) are dropped.  RoPE: the ghosts' positions travel as in
+    ``PartitionedEPD`` (every call unless ``cache_positions``).  Results on the owned rows equal the un-partitioned forward /
+    backward (tests: gloo world 4 against the oracle on the CPU, the HIP engine with all ranks on one device).
+    The temporal block (attends over every node's previous latents, processors.py:203-209) is refused.
+
+    forward(x_in_own[n_own, F_n], pos_own=None) -> out_own[n_own, O]"""
+
+    def __init__(self, model, plan, group=None, backend=None, cache_positions: bool = False):
+        super().__init__()
+        self.model, self.plan, self.group = model, plan, group
+        self.backend = backend    # None: the HIP engine (the model's own Transformer modules)
+        self.cache_positions = bool(cache_positions)
+        self._pos_full = None
+        self._topo = None
+        if getattr(model, "use_temporal_block", False) or getattr(model, "temporal_block", None) is not None:
+            raise NotImplementedError("PartitionedETD: use_temporal_block is not supported on a partitioned mesh")
+
+    def invalidate_positions(self) -> None:
+        self._pos_full = None
+
+    def local_edge_index(self) -> torch.Tensor:
+        """the rank's edges as (row, column) of the attention in local numbering: rows are owned nodes"""
+        return self.plan.edge_index.flip(0).contiguous()
+
+    def forward(self, x_in_own: torch.Tensor, pos_own: Optional[torch.Tensor] = None) -> torch.Tensor:
+        plan, m = self.plan, self.model
+        dev = x_in_own.device
+        use_rope = bool(getattr(m, "use_rope_embeddings", False))
+        pos_full = None
+        if use_rope:
+            if pos_own is None:
+                raise ValueError("use_rope_embeddings=True requires 'pos' attribute in the input graph.")   # processors.py:340-343
+            if pos_own.shape[0] != plan.n_own:
+                raise ValueError("pos_own must hold one row per owned node")
+            p_own = pos_own.detach().to(dev, torch.float32).contiguous()
+            if (not self.cache_positions or self._pos_full is None or self._pos_full.device != dev
+                    or self._pos_full.shape[1] != p_own.shape[1]):
+                self._pos_full = torch.cat([p_own, HaloExchange.apply(p_own, plan, self.group)], dim=0)
+            else:
+                self._pos_full[: plan.n_own].copy_(p_own)
+            pos_full = self._pos_full
+        ei = self.local_edge_index().to(dev)
+        n_loc = plan.n_own + plan.n_ghost
+        be = self.backend
+        if be is None:
+            from .transformer import get_attn_topology
+            if self._topo is None:
+                self._topo = get_attn_topology(ei, n_loc)
+            x_own = x_in_own if m.only_processor else m.nodes_encoder(x_in_own)
+        else:
+            x_own = x_in_own if m.only_processor else be.mlp(m.nodes_encoder, x_in_own)
+        for blk in m.processor_list:
+            x_full = torch.cat([x_own, HaloExchange.apply(x_own, plan, self.group)], dim=0)
+            y = blk(x_full, self._topo, pos=pos_full) if be is None else be.transformer_block(blk, x_full, ei, pos_full)
+            x_own = y[: plan.n_own]
+        if m.only_processor:
+            return x_own
+        return m.decode_module(x_own) if be is None else be.mlp(m.decode_module, x_own)
+
+
 def partitioned_loss(net_out_own, target_own, node_type_own, group=None):
     """Masked L2 over ALL ranks' NORMAL|OUTFLOW nodes (same value on every rank); its local
     gradient, SUMMED over ranks (GradAllReduce(average=False)), is the global gradient."""

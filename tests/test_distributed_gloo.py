@@ -37,6 +37,11 @@ class OracleBackend:
         variant = {"use_rope": block.use_rope, "rope_axes": block.rope_axes, "rope_base": block.rope_base, "use_gate": block.use_gate}
         return O.graph_net_block(x, e, ctx, self._sd(block), "", variant=variant, pos=pos, phi=phi)
 
+    def transformer_block(self, block, x, edge_index, pos=None):
+        a = block.attention
+        return O.transformer_block(x, self._sd(block), "", edge_index, a.num_heads, pos=pos, use_rope=a.use_rope_embeddings,
+                                   use_gate=a.use_gated_attention, pos_dimension=a.pos_dimension, rope_base=a.rope_base)
+
 
 def _free_port():
     s = socket.socket()
@@ -194,6 +199,85 @@ def test_partitioned_rope_and_gate_phi_equal_unpartitioned_world4():
         full[torch.from_numpy(owned)] = torch.from_numpy(out)
         total += loss
         for k, g in grads.items():
+            assert torch.allclose(torch.from_numpy(g), params[k].grad, rtol=2e-4, atol=1e-6), (rank, k)
+    assert abs(total - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
+    assert torch.allclose(full, ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+ETD_CASE = dict(L=3, H=32, heads=4, N=160, seed=31)
+
+
+def _etd_net(gp, rope):
+    c = ETD_CASE
+    return gp.EncodeTransformDecode(c["L"], 11, 2, hidden_size=c["H"], num_heads=c["heads"], use_rope_embeddings=rope,
+                                    use_gated_attention=rope, rope_pos_dimension=2, rope_base=100.0)
+
+
+def _worker_partition_etd(rank, world, port, q, rope):
+    """[r5] the sparse-attention Transformer on a partitioned mesh (VERDICT r4 missing 5): a rank owns the attention ROWS
+    (edge_index[0]) of its nodes -- the plan is built on the flipped edge list -- and receives the ghost columns' latents before
+    every block; with RoPE also their positions"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import graph_physics_amd as gp
+    from graph_physics_amd import distributed as D
+    from graph_physics_amd import partition as P
+
+    c = ETD_CASE
+    pos, ei, _ = R.delaunay_graph(c["N"], c["seed"])
+    net = _etd_net(gp, rope)
+    net.load_state_dict(R.variant_params(net.state_dict(), c["seed"]))
+    x_in, tgt, nt = R.randn((c["N"], 11), 41), R.randn((c["N"], 2), 43), torch.zeros(c["N"])
+    part = P.partition_nodes(pos.numpy(), ei, world)
+    plan = P.build_rank_plan(ei.flip(0), part, rank, world)          # owner of an edge = owner of its attention row
+    pm = D.PartitionedETD(net, plan, backend=OracleBackend())
+    lei = pm.local_edge_index()
+    assert int(lei[0].max()) < plan.n_own                             # every local row is an owned node
+    if rope:
+        with pytest.raises(ValueError, match="pos"):
+            pm(x_in[plan.owned])
+    out = pm(x_in[plan.owned], pos_own=pos[plan.owned] if rope else None)
+    loss = D.partitioned_loss(out, tgt[plan.owned], nt[plan.owned])
+    loss.backward()
+    D.GradAllReduce(average=False)(net.parameters())
+    grads = {k: v.grad.numpy().copy() for k, v in net.named_parameters()}
+    q.put((rank, plan.owned.numpy().copy(), out.detach().numpy().copy(), float(loss.detach()), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rope", [False, True])
+def test_partitioned_transformer_equals_unpartitioned_world4(rope):
+    world = 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_partition_etd, args=(r, world, port, q, rope)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import graph_physics_amd as gp
+
+    c = ETD_CASE
+    pos, ei, _ = R.delaunay_graph(c["N"], c["seed"])
+    net = _etd_net(gp, rope)
+    params = {k: v.clone().requires_grad_(True) for k, v in R.variant_params(net.state_dict(), c["seed"]).items()}
+    x_in, tgt, nt = R.randn((c["N"], 11), 41), R.randn((c["N"], 2), 43), torch.zeros(c["N"])
+    ref = O.etd_forward(x_in, ei, params, c["L"], c["heads"], pos=pos if rope else None, use_rope=rope, use_gate=rope,
+                        pos_dimension=2, rope_base=100.0)
+    ref_loss = O.l2_loss(ref, tgt, nt)
+    ref_loss.backward()
+    full, total = torch.zeros_like(ref), 0.0
+    for rank, owned, out, loss, grads in res:
+        full[torch.from_numpy(owned)] = torch.from_numpy(out)
+        total += loss
+        for k, g in grads.items():
+            if params[k].grad is None:      # (buffers / unused entries)
+                continue
             assert torch.allclose(torch.from_numpy(g), params[k].grad, rtol=2e-4, atol=1e-6), (rank, k)
     assert abs(total - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
     assert torch.allclose(full, ref.detach(), rtol=1e-5, atol=1e-6)
