@@ -353,25 +353,102 @@ class TemporalAttention(nn.Module):
         return dense(m1, self.mixer[2].weight, self.mixer[2].bias, resid=h_corr)
 
 
+class TransformerConv(nn.Module):
+    """``torch_geometric.nn.TransformerConv(in_channels, out_channels, heads, concat=False, beta=True)`` -- the block the reference builds
+    when DGL is absent (processors.py:303-314; its own CI runs that branch) -- with PyG's parameter names (``lin_key``, ``lin_query``,
+    ``lin_value``, ``lin_skip``, ``lin_beta``: a checkpoint of that branch loads).  PyG 2.6.1 is not installable here, so the
+    arithmetic follows its published algorithm (oracle/mgn_oracle.py::transformer_conv: parity unpinned).  Projections on the
+    engine's fused Linear launches, one sparse-attention call per head (PyG keeps head h in columns h*C .. h*C + C - 1 and, without
+    ``concat``, every head is ``out_channels`` wide), softmax over the IN-edges of a node (rows = ``edge_index[1]``)."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = False, beta: bool = True):
+        super().__init__()
+        if concat or not beta:
+            raise NotImplementedError("TransformerConv: only the reference's configuration (concat=False, beta=True)")
+        self.in_channels, self.out_channels, self.heads, self.concat, self.beta = in_channels, out_channels, heads, concat, beta
+        self.lin_key = nn.Linear(in_channels, heads * out_channels)
+        self.lin_query = nn.Linear(in_channels, heads * out_channels)
+        self.lin_value = nn.Linear(in_channels, heads * out_channels)
+        self.lin_skip = nn.Linear(in_channels, out_channels)
+        self.lin_beta = nn.Linear(3 * out_channels, 1, bias=False)
+
+    def forward(self, x: torch.Tensor, edge_index) -> torch.Tensor:
+        ops._require_device(x)
+        N, C, Hh = x.size(0), self.out_channels, self.heads
+        topo = edge_index if isinstance(edge_index, AttnTopology) else get_attn_topology(_flipped(edge_index), N)
+        q, k, v = (dense(x, m.weight, m.bias) for m in (self.lin_query, self.lin_key, self.lin_value))
+        out = None
+        for h in range(Hh):   # one head = one [N, C] problem (1 / sqrt(C) scaling inside the kernel)
+            sl = slice(h * C, (h + 1) * C)
+            y = sparse_attention(q[:, sl].contiguous(), k[:, sl].contiguous(), v[:, sl].contiguous(), topo, 1)
+            out = y if out is None else out + y
+        out = out / Hh
+        r = dense(x, self.lin_skip.weight, self.lin_skip.bias)
+        w = self.lin_beta.weight.view(3, C)
+        beta = torch.sigmoid((out * w[0] + r * w[1] + (out - r) * w[2]).sum(dim=-1, keepdim=True))
+        return beta * r + (1 - beta) * out
+
+
+_flip_cache: dict = {}
+
+
+def _flipped(edge_index: torch.Tensor) -> torch.Tensor:
+    """edge_index with its two rows swapped, the same tensor object for the same input (the attention topology is cached per object)"""
+    import weakref
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape))
+    hit = _flip_cache.get(key)
+    if hit is not None and hit[0]() is edge_index:
+        return hit[1]
+    f = edge_index.flip(0).contiguous()
+    if len(_flip_cache) > 64:
+        _flip_cache.clear()
+    _flip_cache[key] = (weakref.ref(edge_index), f)
+    return f
+
+
+def default_attention_backend() -> str:
+    """"dgl" (the sparse-attention Transformer blocks, what the reference builds when DGL is importable) unless
+    MGN_ATTENTION_BACKEND=pyg asks for the TransformerConv branch of a DGL-less installation (processors.py:303-314).  The
+    reference's own GRAPH_PHYSICS_ASSUME_NO_DGL only silences its prompt and is set by anyone importing the reference
+    unattended -- it does not say which branch a checkpoint was trained with, so it is deliberately NOT read here."""
+    import os
+    v = os.getenv("MGN_ATTENTION_BACKEND", "dgl").strip().lower()
+    if v not in ("dgl", "pyg"):
+        raise ValueError("MGN_ATTENTION_BACKEND must be 'dgl' or 'pyg'")
+    return v
+
+
 class EncodeTransformDecode(nn.Module):
-    """processors.py:218-384 (the DGL branch: Transformer blocks over the sparse adjacency)"""
+    """processors.py:218-384 (the DGL branch: Transformer blocks over the sparse adjacency; ``attention_backend="pyg"`` or
+    MGN_ATTENTION_BACKEND=pyg: the non-DGL branch, TransformerConv blocks)"""
 
     def __init__(self, message_passing_num: int, node_input_size: int, output_size: int, hidden_size: int = 128, num_heads: int = 4,
                  only_processor: bool = False, use_proj_bias: bool = True, use_separate_proj_weight: bool = True,
                  use_rope_embeddings: bool = False, use_gated_attention: bool = False, rope_pos_dimension: int = 3,
-                 rope_base: float = 10000.0, use_temporal_block: bool = False):
+                 rope_base: float = 10000.0, use_temporal_block: bool = False, attention_backend: Optional[str] = None):
         super().__init__()
+        self.attention_backend = attention_backend if attention_backend is not None else default_attention_backend()
+        if self.attention_backend not in ("dgl", "pyg"):
+            raise ValueError("attention_backend must be 'dgl' or 'pyg'")
+        pyg = self.attention_backend == "pyg"
         self.hidden_size, self.only_processor, self.d = hidden_size, only_processor, output_size
-        self.use_rope_embeddings, self.use_gated_attention = use_rope_embeddings, use_gated_attention
+        # (the reference drops RoPE / the gate without DGL, with a warning: processors.py:267,317-326)
+        self.use_rope_embeddings, self.use_gated_attention = use_rope_embeddings and not pyg, use_gated_attention
         self._requested_rope, self.use_temporal_block = use_rope_embeddings, use_temporal_block
+        if pyg and use_temporal_block:
+            raise NotImplementedError("EncodeTransformDecode: the temporal block without a sparse adjacency (non-DGL branch) is not implemented")
         if not self.only_processor:
             self.nodes_encoder = build_mlp(node_input_size, hidden_size, hidden_size)
             self.decode_module = build_mlp(hidden_size, hidden_size, output_size, layer_norm=False)
-        self.processor_list = nn.ModuleList([
-            Transformer(input_dim=hidden_size, output_dim=hidden_size, num_heads=num_heads, use_proj_bias=use_proj_bias,
-                        use_separate_proj_weight=use_separate_proj_weight, use_rope_embeddings=use_rope_embeddings,
-                        use_gated_attention=use_gated_attention, pos_dimension=rope_pos_dimension, rope_base=rope_base)
-            for _ in range(message_passing_num)])
+        if pyg:
+            self.processor_list = nn.ModuleList([TransformerConv(hidden_size, hidden_size, heads=num_heads, concat=False, beta=True)
+                                                 for _ in range(message_passing_num)])
+        else:
+            self.processor_list = nn.ModuleList([
+                Transformer(input_dim=hidden_size, output_dim=hidden_size, num_heads=num_heads, use_proj_bias=use_proj_bias,
+                            use_separate_proj_weight=use_separate_proj_weight, use_rope_embeddings=use_rope_embeddings,
+                            use_gated_attention=use_gated_attention, pos_dimension=rope_pos_dimension, rope_base=rope_base)
+                for _ in range(message_passing_num)])
         self.temporal_block = TemporalAttention(hidden_size=hidden_size, num_heads=num_heads) if use_temporal_block else None
 
     def forward(self, graph) -> torch.Tensor:
@@ -379,6 +456,11 @@ class EncodeTransformDecode(nn.Module):
         pos = getattr(graph, "pos", None)
         if self.use_rope_embeddings and pos is None:
             raise ValueError("use_rope_embeddings=True requires 'pos' attribute in the input graph.")
+        if self.attention_backend == "pyg":   # processors.py:372-375: x = block(x, edge_index), nothing around it
+            topo = get_attn_topology(_flipped(graph.edge_index), x.shape[0])   # rows = the node that aggregates = edge_index[1]
+            for block in self.processor_list:
+                x = block(x, topo)
+            return x if self.only_processor else self.decode_module(x)
         topo = getattr(graph, "mgn_attn_topology", None)
         if topo is None:
             topo = get_attn_topology(graph.edge_index, x.shape[0])

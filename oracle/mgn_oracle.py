@@ -641,11 +641,42 @@ def temporal_attention(h_prev, h_pred, p, prefix, edge_index, num_heads=4):
     return h_corr + lin("mixer.2", torch.nn.functional.silu(lin("mixer.0", torch.cat([h_corr, h_prev], dim=-1))))
 
 
+def transformer_conv(x, p, prefix, edge_index, heads):
+    """torch_geometric.nn.TransformerConv(in, out, heads, concat=False, beta=True) -- the block of the reference's NON-DGL branch
+    (processors.py:303-314, called as ``block(prev_x, edge_index)`` at :372-375).  PyG is a pinned third-party dependency
+    (torch-geometric==2.6.1, requirements.txt:7) that is not installable here: this is its PUBLISHED algorithm
+    (torch_geometric/nn/conv/transformer_conv.py, Shi et al. 2021 eq. 3-6) restated -- **parity unpinned** for this function:
+        q_i = W_q x_i + b_q,  k_j = W_k x_j + b_k,  v_j = W_v x_j + b_v            (per head: view(-1, H, C), head index SLOW)
+        alpha_ij = softmax over the in-edges j -> i (i = edge_index[1], j = edge_index[0]) of  q_i . k_j / sqrt(C)
+        m_i = mean over heads of  sum_j alpha_ij v_j                                  (concat=False)
+        r_i = W_skip x_i + b_skip;  beta_i = sigmoid(w_beta . [m_i, r_i, m_i - r_i]);  out_i = beta_i r_i + (1 - beta_i) m_i
+    (dropout 0, no edge features)."""
+    src, dst = edge_index[0], edge_index[1]
+    N = x.shape[0]
+    lin = lambda name, t: _linear(t, p[f"{prefix}{name}.weight"], p.get(f"{prefix}{name}.bias"))  # noqa: E731
+    C = p[prefix + "lin_skip.weight"].shape[0]
+    q, k, v = (lin(n, x).view(N, heads, C) for n in ("lin_query", "lin_key", "lin_value"))
+    score = (q[dst] * k[src]).sum(dim=-1) / math.sqrt(C)                                        # [E, H]
+    mx = torch.full((N, heads), float("-inf"), dtype=x.dtype).scatter_reduce(0, dst.view(-1, 1).expand(-1, heads), score, "amax")
+    ex = torch.exp(score - mx[dst])
+    den = torch.zeros(N, heads, dtype=x.dtype).index_add_(0, dst, ex)
+    alpha = ex / den[dst]
+    out = torch.zeros(N, heads, C, dtype=x.dtype).index_add_(0, dst, alpha.unsqueeze(-1) * v[src]).mean(dim=1)
+    r = lin("lin_skip", x)
+    beta = torch.sigmoid(_linear(torch.cat([out, r, out - r], dim=-1), p[prefix + "lin_beta.weight"], None))
+    return beta * r + (1 - beta) * out
+
+
 def etd_forward(x_in, edge_index, p, message_passing_num, num_heads, act="relu", pos=None, use_rope=False, use_gate=False,
-                pos_dimension=3, rope_base=10000.0, use_temporal_block=False):
-    """EncodeTransformDecode.forward, processors.py:334-371 (DGL branch)."""
+                pos_dimension=3, rope_base=10000.0, use_temporal_block=False, conv="dgl"):
+    """EncodeTransformDecode.forward, processors.py:334-371 (``conv="dgl"``: the sparse-attention Transformer blocks;
+    ``conv="pyg"``: the non-DGL branch, TransformerConv blocks applied as ``x = block(x, edge_index)``, :372-375)."""
     x = mlp(x_in, p, "nodes_encoder.", act)
     prev_x = last_x = x
+    if conv == "pyg":
+        for i in range(message_passing_num):
+            x = transformer_conv(x, p, f"processor_list.{i}.", edge_index, num_heads)
+        return mlp(x, p, "decode_module.", act)
     for i in range(message_passing_num):
         prev_x = x
         last_x = transformer_block(prev_x, p, f"processor_list.{i}.", edge_index, num_heads, act, pos=pos, use_rope=use_rope,
