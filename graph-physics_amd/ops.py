@@ -1284,15 +1284,16 @@ class ProcessorFunction(torch.autograd.Function):
         # until the launch and are read back from HBM instead of the Infinity Cache, so only steps whose rounds are small do it
         # (MGN_WGRAD_BATCH_MB, default 256 MB per waiting round; 0: one launch per round.  Measured, tools/ab_wbatch.sh: one mesh
         # per step 3.03 -> 2.88 ms; the 16-mesh batch -- 953 MB per round -- 12.60-12.64 against 12.53-12.70 ms: the launches it saves
-        # there are paid back by dZ rows that no longer come out of the cache the chain kernel just wrote them through); not with a
-        # grad-ready listener (it wants every round's gradients as soon as possible), a side
-        # stream, the partitioned mesh or the fused edge backward.
+        # there are paid back by dZ rows that no longer come out of the cache the chain kernel just wrote them through); not with a side
+        # stream, the partitioned mesh or the fused edge backward.  A grad-ready listener hears of a waiting round when its launch
+        # has been queued (the same launches with or without a listener: a rank's gradients do not depend on how they are reduced).
         per_round_mb = 4.0 * H * ((2 * NL + 1) * E + (NL + 7) * Nn) / 2**20
         wb_rounds = max(1, _capi.MAX_WGRAD_JOBS // (2 * NL + 3 + (1 if spec.gate else 0)))
-        defer_w = (x6 and side is None and halo is None and _grad_ready_hook is None and not empty and wb_rounds > 1
+        defer_w = (x6 and side is None and halo is None and not empty and wb_rounds > 1
                    and _os.environ.get("MGN_FUSED_BWD", "0") != "1"
                    and per_round_mb <= float(_os.environ.get("MGN_WGRAD_BATCH_MB", "256")))
         w_pend, w_rounds = [], 0
+        hook_pend = []   # grad-ready reports of rounds whose weight-gradient launch has not been queued yet
         dzn_round = {}
 
         def dzn_of(r):
@@ -1518,6 +1519,9 @@ class ProcessorFunction(torch.autograd.Function):
                     if w_rounds == wb_rounds or i == 0:
                         wgrad(w_pend, dev, prec)
                         w_pend, w_rounds = [], 0
+                        for rep in hook_pend:
+                            _grad_ready_hook(rep)
+                        hook_pend = []
                         for r in [r for r in dzn_round if r >= i]:
                             del dzn_round[r]
                 else:
@@ -1559,7 +1563,11 @@ class ProcessorFunction(torch.autograd.Function):
                 # this round's weight / bias gradients are final once their launches are queued (the two RMSNorm scale gradients come
                 # out of the deferred reduction at the very end): a data-parallel wrapper may start reducing them now
                 late = {2 * NL, k_ + 2 * NL} if (spec.layer_norm and deferred is not None) else set()
-                _grad_ready_hook([(P_params[PB * i + t], g[t]) for t in range(len(g)) if t not in late])
+                rep = [(P_params[PB * i + t], g[t]) for t in range(len(g)) if t not in late]
+                if defer_w and w_rounds > 0:     # this round's jobs are still waiting for their launch
+                    hook_pend.append(rep)
+                else:
+                    _grad_ready_hook(rep)
             dx, de = dx_new, de_new
         if side is not None:
             for ev in wdone:
