@@ -283,6 +283,162 @@ __global__ void __launch_bounds__(256) k_linear(const mgn_linear_args a, const i
   }  // tiles
 }
 
+// ------------------------------------------------------------------ [r5] the same launch on the split-bf16 matrix path
+// precision 0 at row counts where the LDS-resident weight image pays: every fp32 operand as three bf16 pieces, a product as the six
+// terms of order <= 2^-16 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- the arithmetic of the H = 128 chain kernels (DESIGN 4.1;
+// 5.6e-7 against fp64 where the exact-fp32 MFMA gives 5.6e-7).  16x16x4_f32 issues at 32 cycles for 2 048 flop, a K = 32 slice costs
+// 8 of them = 256 cycles; its six bf16 terms cost 96.  At configs[4]'s 150 000 rows the exact-fp32 products were 40 % of a launch's time.
+//   * 512 threads: eight waves (16 rows each, 128 rows per tile) share ONE piece image of the weights, staged and split once per
+//     persistent workgroup: row n = [piece][K-slice][g] 16-byte chunks (lane (c, g) of output block ob reads chunk (p, s, g) of row
+//     16 ob + c = the A operand of slice s), rows padded by one chunk (odd chunk stride: the 16 rows of a fragment read spread
+//     over the banks).  6 bytes per weight: 64 -> 192 = 77 KB, two workgroups per CU.
+//   * a wave splits its rows once per tile (44 vector instructions per 8 values) and keeps the pieces as B operands for all output
+//     blocks; per output block and slice: three ds_read_b128 and six MFMAs on two accumulators (small terms / large terms).
+// Same prologue / epilogue as k_linear (RMSNorm, gathers, saves, activation, gated product, residual), same [ob0, ob1) slicing.
+__device__ __forceinline__ void split3_bf16x8(const f32x4& lo, const f32x4& hi, u32x4_d& p1, u32x4_d& p2, u32x4_d& p3) {
+  p1 = pack_bf16x8(lo, hi);
+  f32x4 rl, rh;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    rl[2 * d] = lo[2 * d] - __uint_as_float(p1[d] << 16);
+    rl[2 * d + 1] = lo[2 * d + 1] - __uint_as_float(p1[d] & 0xffff0000u);
+    rh[2 * d] = hi[2 * d] - __uint_as_float(p1[2 + d] << 16);
+    rh[2 * d + 1] = hi[2 * d + 1] - __uint_as_float(p1[2 + d] & 0xffff0000u);
+  }
+  p2 = pack_bf16x8(rl, rh);
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    rl[2 * d] -= __uint_as_float(p2[d] << 16);
+    rl[2 * d + 1] -= __uint_as_float(p2[d] & 0xffff0000u);
+    rh[2 * d] -= __uint_as_float(p2[2 + d] << 16);
+    rh[2 * d + 1] -= __uint_as_float(p2[2 + d] & 0xffff0000u);
+  }
+  p3 = pack_bf16x8(rl, rh);
+}
+template <int KB, bool GATE>
+__global__ void __launch_bounds__(512) k_linear_x6(const mgn_linear_args a, const int ob0, const int ob1) {
+  static_assert(KB % 2 == 0, "K = 32 matrix steps");
+  constexpr int S = KB / 2;               // K = 32 slices
+  constexpr int RB = (12 * S + 1) * 16;   // bytes of an image row: 3 pieces x S slices x 4 lane groups, + one chunk of padding
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  extern __shared__ __attribute__((aligned(16))) char li_[];
+  const int NC = 16 * (ob1 - ob0);
+  {
+    const int items = NC * S * 4;   // (row n, slice s, lane group g): 8 weights -> three chunks
+    for (int i = threadIdx.x; i < items * (GATE ? 2 : 1); i += 512) {
+      const int mat = i >= items, j = mat ? i - items : i;
+      const int n = j / (S * 4), s_ = (j / 4) % S, g_ = j & 3;
+      const float* w = (mat ? a.W2 : a.W) + (size_t)(16 * ob0 + n) * a.ldw + 32 * s_ + 4 * g_;
+      u32x4_d p1, p2, p3;
+      split3_bf16x8(*(const f32x4*)w, *(const f32x4*)(w + 16), p1, p2, p3);
+      char* d = li_ + (size_t)(mat * NC + n) * RB + (s_ * 4 + g_) * 16;
+      *(u32x4_d*)d = p1;
+      *(u32x4_d*)(d + S * 64) = p2;
+      *(u32x4_d*)(d + 2 * S * 64) = p3;
+    }
+    __syncthreads();
+  }
+  const long ntiles = (a.M + 127) / 128;
+  const int K = 16 * KB, kb1 = a.K1 >> 4, kb2 = kb1 + (a.K2 >> 4);
+  const char* l1 = li_ + (size_t)c * RB + g * 16;
+  const char* l2 = li_ + (size_t)(NC + c) * RB + g * 16;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long m = (tile * 8 + wv) * 16 + c;
+    const bool valid = m < a.M;
+    const long mm = valid ? m : a.M - 1;
+    f32x4 in[KB];
+    {
+      const long r1 = a.idx != nullptr ? (long)a.idx[mm] : mm;
+      const long r2 = a.idx2 != nullptr ? (long)a.idx2[mm] : mm;
+      const long r3 = a.idx3 != nullptr ? (long)a.idx3[mm] : mm;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+        in[kb] = (kb < kb1)   ? *(const f32x4*)(a.x + r1 * a.ldx + 16 * kb + 4 * g)
+                 : (kb < kb2) ? *(const f32x4*)(a.x2 + r2 * a.ldx2 + 16 * (kb - kb1) + 4 * g)
+                              : *(const f32x4*)(a.x3 + r3 * a.ldx3 + 16 * (kb - kb2) + 4 * g);
+    }
+    if (a.norm_scale != nullptr) {  // RMSNorm prologue (as k_linear)
+      float ss = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss = fmaf(in[kb][r], in[kb][r], ss);
+      ss = rowsum4d(ss);
+      const float inv = 1.0f / (sqrtf(ss) / sqrtf((float)K) + a.eps);
+      if (a.inv_out != nullptr && valid && g == 0 && ob0 == 0) a.inv_out[mm] = inv;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) in[kb] = *(const f32x4*)(a.norm_scale + 16 * kb + 4 * g) * (in[kb] * inv);
+      if (a.n_out != nullptr && valid && ob0 == 0) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) *(f32x4*)(a.n_out + mm * K + 16 * kb + 4 * g) = in[kb];
+      }
+    }
+    u32x4_d x1[S], x2[S], x3[S];
+#pragma unroll
+    for (int s_ = 0; s_ < S; ++s_) split3_bf16x8(in[2 * s_], in[2 * s_ + 1], x1[s_], x2[s_], x3[s_]);
+    for (int ob = ob0; ob < ob1; ++ob) {
+      const int n0 = 16 * ob + 4 * g;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      f32x4 hi = (a.b != nullptr) ? *(const f32x4*)(a.b + n0) : zero, lo = zero;
+      f32x4 hi2 = (GATE && a.b2 != nullptr) ? *(const f32x4*)(a.b2 + n0) : zero, lo2 = zero;
+      const char* w1 = l1 + (size_t)16 * (ob - ob0) * RB;
+      const char* w2 = l2 + (size_t)16 * (ob - ob0) * RB;
+#pragma unroll
+      for (int s_ = 0; s_ < S; ++s_) {
+        const u32x4_d a1 = *(const u32x4_d*)(w1 + s_ * 64), a2 = *(const u32x4_d*)(w1 + (S + s_) * 64), a3 = *(const u32x4_d*)(w1 + (2 * S + s_) * 64);
+        lo = MFMA_BF16(a3, x1[s_], lo);
+        hi = MFMA_BF16(a2, x1[s_], hi);
+        lo = MFMA_BF16(a2, x2[s_], lo);
+        hi = MFMA_BF16(a1, x2[s_], hi);
+        lo = MFMA_BF16(a1, x3[s_], lo);
+        hi = MFMA_BF16(a1, x1[s_], hi);
+        if (GATE) {
+          const u32x4_d c1 = *(const u32x4_d*)(w2 + s_ * 64), c2 = *(const u32x4_d*)(w2 + (S + s_) * 64), c3 = *(const u32x4_d*)(w2 + (2 * S + s_) * 64);
+          lo2 = MFMA_BF16(c3, x1[s_], lo2);
+          hi2 = MFMA_BF16(c2, x1[s_], hi2);
+          lo2 = MFMA_BF16(c2, x2[s_], lo2);
+          hi2 = MFMA_BF16(c1, x2[s_], hi2);
+          lo2 = MFMA_BF16(c1, x3[s_], lo2);
+          hi2 = MFMA_BF16(c1, x1[s_], hi2);
+        }
+      }
+      const f32x4 acc = hi + lo, acc2 = hi2 + lo2;
+      if (valid) {
+        if (a.saveZ1 != nullptr) *(f32x4*)(a.saveZ1 + mm * a.N + n0) = acc;
+        if (GATE && a.saveZ2 != nullptr) *(f32x4*)(a.saveZ2 + mm * a.N + n0) = acc2;
+      }
+      f32x4 y;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = d_act(acc[r], a.act);
+      if (GATE) y = y * acc2;
+      if (a.resid != nullptr) y = *(const f32x4*)(a.resid + mm * a.ldr + n0) + y;
+      if (valid) *(f32x4*)(a.out + mm * a.ldo + n0) = y;
+    }
+  }
+}
+template <int KB>
+static int launch_linear_x6(const mgn_linear_args& a, unsigned grid, size_t lds, int nchunk, hipStream_t s) {
+  if constexpr (KB % 2 == 0) {
+    const bool gate = a.W2 != nullptr;
+    const int nbc = (a.N >> 4) / nchunk;
+#define LINX_GO(GATE_)                                                                                                                  \
+  do {                                                                                                                                  \
+    if (lds > 48 * 1024 &&                                                                                                              \
+        hipFuncSetAttribute((const void*)k_linear_x6<KB, GATE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)   \
+      return 2;                                                                                                                         \
+    for (int ch = 0; ch < nchunk; ++ch)                                                                                                 \
+      hipLaunchKernelGGL((k_linear_x6<KB, GATE_>), dim3(grid), dim3(512), lds, s, a, ch * nbc, (ch + 1) * nbc);                         \
+  } while (0)
+    if (gate) LINX_GO(true);
+    else LINX_GO(false);
+#undef LINX_GO
+    return 0;
+  } else {
+    return 2;
+  }
+}
+
 template <int KB, bool LDSW>
 static int launch_linear_v(const mgn_linear_args& a, unsigned grid, size_t lds, int nchunk, hipStream_t s) {
   const bool bf = a.precision == 1, gate = a.W2 != nullptr;
@@ -310,6 +466,27 @@ static int launch_linear(const mgn_linear_args& a, hipStream_t s) {
   // the LDS-resident weight image pays once every workgroup walks several tiles and three or more workgroups fit a CU; an image
   // above 64 KB is cut into 2 or 3 groups of output blocks (MGN_LINEAR_NO_CHUNK: such launches stay on the L2 path, for A/B)
   const int NB = a.N >> 4;
+  // [r5] precision 0, an even number of input blocks, 65 536 rows or more: the six-term split-bf16 form (MGN_LINEAR_X6=0: the
+  // exact-fp32 matrix instruction everywhere, for A/B).  The piece image is 6 bytes per weight; it is cut into groups of output
+  // blocks until two 512-thread workgroups fit a CU.
+  if (KB % 2 == 0 && a.precision == 0 && ntiles >= 1024) {
+    static const bool x6_on = [] { const char* e = getenv("MGN_LINEAR_X6"); return e == nullptr || e[0] != '0'; }();
+    if (x6_on) {
+      const size_t rowb = (size_t)(12 * (KB / 2) + 1) * 16;
+      const size_t fullx = (size_t)(a.W2 != nullptr ? 2 : 1) * a.N * rowb;
+      int nc = 1;
+      while (nc <= NB && (fullx / nc > 79 * 1024 || NB % nc != 0)) ++nc;
+      if (nc <= NB) {
+        const size_t imgx = fullx / nc;
+        const long nt128 = (a.M + 127) / 128;
+        int per_cu = (int)((160 * 1024) / imgx);
+        if (per_cu > 4) per_cu = 4;
+        unsigned grid = 256u * (unsigned)per_cu;
+        if ((long)grid > nt128) grid = (unsigned)nt128;
+        return launch_linear_x6<KB>(a, grid, imgx, nc, s);
+      }
+    }
+  }
   int nchunk = 1;
   while (nchunk < 4 && (full / nchunk > 64 * 1024 || NB % nchunk != 0)) ++nchunk;
   if (nchunk > 1 && getenv("MGN_LINEAR_NO_CHUNK") != nullptr) nchunk = 4;
