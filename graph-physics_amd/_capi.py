@@ -152,7 +152,7 @@ class LinearArgs(C.Structure):
         ("x3", _f32p), ("ldx3", C.c_int), ("K3", C.c_int), ("idx", C.c_void_p), ("idx2", C.c_void_p), ("idx3", C.c_void_p),
         ("norm_scale", _f32p), ("eps", C.c_float), ("inv_out", _f32p), ("n_out", _f32p), ("W", _f32p), ("ldw", C.c_int), ("b", _f32p),
         ("W2", _f32p), ("b2", _f32p), ("act", C.c_int), ("N", C.c_int), ("resid", _f32p), ("ldr", C.c_int), ("out", _f32p),
-        ("ldo", C.c_int), ("saveZ1", _f32p), ("saveZ2", _f32p), ("precision", C.c_int),
+        ("ldo", C.c_int), ("saveZ1", _f32p), ("saveZ2", _f32p), ("precision", C.c_int), ("w_transposed", C.c_int),
     ]
 
 
@@ -241,6 +241,7 @@ SYMBOLS = {
     "mgn_sparse_attn_weights": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mgn_attn_last_error": (C.c_char_p, []),
     "mgn_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    "mgn_linear_accepts_transposed": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mgn_act_gate_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgn_rownorm_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgn_rownorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int]),
@@ -254,7 +255,7 @@ _lock = threading.Lock()
 
 #: ABI version this binding was written against (mgn_version() of the library must match: the
 #: ctypes structs above mirror exactly that header)
-EXPECTED_VERSION = 133
+EXPECTED_VERSION = 134
 HASH_PATH = os.path.join(_CSRC, "libmgn_hip.srchash")
 LOCK_PATH = os.path.join(_CSRC, ".build.lock")
 

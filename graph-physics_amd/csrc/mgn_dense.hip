@@ -315,16 +315,53 @@ __device__ __forceinline__ void split3_bf16x8(const f32x4& lo, const f32x4& hi, 
   }
   p3 = pack_bf16x8(rl, rh);
 }
-template <int KB, bool GATE>
-__global__ void __launch_bounds__(512) k_linear_x6(const mgn_linear_args a, const int ob0, const int ob1) {
+// BF (precision 1, the reference under bf16-mixed): ONE piece = the operands rounded to bf16, bias / result / activation roundings
+// as in k_linear<.., BF = true>; the same 512-thread workgroup and image layout with a third of the bytes.
+// (second launch bound = waves per SIMD: two workgroups per CU -> at most 128 registers up to 192 inputs)
+template <int KB, bool GATE, bool BF>
+__global__ void __launch_bounds__(512, (KB <= 12 ? 4 : 2)) k_linear_x6(const mgn_linear_args a, const int ob0, const int ob1) {
   static_assert(KB % 2 == 0, "K = 32 matrix steps");
   constexpr int S = KB / 2;               // K = 32 slices
-  constexpr int RB = (12 * S + 1) * 16;   // bytes of an image row: 3 pieces x S slices x 4 lane groups, + one chunk of padding
+  constexpr int NP = BF ? 1 : 3;          // pieces
+  constexpr int RB = (4 * NP * S + 1) * 16;   // bytes of an image row: pieces x S slices x 4 lane groups, + one chunk of padding
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   extern __shared__ __attribute__((aligned(16))) char li_[];
   const int NC = 16 * (ob1 - ob0);
-  {
+  constexpr int K_ = 16 * KB;
+  const long ntiles = (a.M + 127) / 128;
+  const int K = 16 * KB, kb1 = a.K1 >> 4, kb2 = kb1 + (a.K2 >> 4);
+  const char* l1 = li_ + (size_t)c * RB + g * 16;
+  const char* l2 = li_ + (size_t)(NC + c) * RB + g * 16;
+  // (the first tile's rows requested BEFORE the staging: in[] then lives across the loop and the instances grow from 79 / 116 to
+  //  107 / 205 registers -- one workgroup per CU instead of two; not done)
+  if (a.w_transposed) {
+    // the array handed over is [K][ldw]: element (image row n, input k) = W[k][16 ob0 + n].  An item = four consecutive rows n x the
+    // eight inputs of one chunk (k = 32 s + 4 g + r and + 16): eight 16-byte loads ALONG n (consecutive lanes = consecutive quads of n:
+    // coalesced), transposed in registers, then the ordinary split and three 16-byte chunks per row
+    const int nq = NC / 4, items = nq * S * 4;
+    for (int i = threadIdx.x; i < items * (GATE ? 2 : 1); i += 512) {
+      const int mat = i >= items, j = mat ? i - items : i;
+      const int q = j % nq, sg = j / nq;   // sg = 4 s + g
+      const float* w = (mat ? a.W2 : a.W) + (size_t)(32 * (sg >> 2) + 4 * (sg & 3)) * a.ldw + 16 * ob0 + 4 * q;
+      f32x4 v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = *(const f32x4*)(w + (size_t)r * a.ldw), v[4 + r] = *(const f32x4*)(w + (size_t)(16 + r) * a.ldw);
+      char* d = li_ + (size_t)(mat * NC + 4 * q) * RB + sg * 16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 lo_ = {v[0][e], v[1][e], v[2][e], v[3][e]}, hi_ = {v[4][e], v[5][e], v[6][e], v[7][e]};
+        u32x4_d p1, p2, p3;
+        split3_bf16x8(lo_, hi_, p1, p2, p3);
+        *(u32x4_d*)(d + (size_t)e * RB) = p1;
+        if (!BF) {
+          *(u32x4_d*)(d + (size_t)e * RB + S * 64) = p2;
+          *(u32x4_d*)(d + (size_t)e * RB + 2 * S * 64) = p3;
+        }
+      }
+    }
+    __syncthreads();
+  } else {
     const int items = NC * S * 4;   // (row n, slice s, lane group g): 8 weights -> three chunks
     for (int i = threadIdx.x; i < items * (GATE ? 2 : 1); i += 512) {
       const int mat = i >= items, j = mat ? i - items : i;
@@ -334,15 +371,13 @@ __global__ void __launch_bounds__(512) k_linear_x6(const mgn_linear_args a, cons
       split3_bf16x8(*(const f32x4*)w, *(const f32x4*)(w + 16), p1, p2, p3);
       char* d = li_ + (size_t)(mat * NC + n) * RB + (s_ * 4 + g_) * 16;
       *(u32x4_d*)d = p1;
-      *(u32x4_d*)(d + S * 64) = p2;
-      *(u32x4_d*)(d + 2 * S * 64) = p3;
+      if (!BF) {
+        *(u32x4_d*)(d + S * 64) = p2;
+        *(u32x4_d*)(d + 2 * S * 64) = p3;
+      }
     }
     __syncthreads();
   }
-  const long ntiles = (a.M + 127) / 128;
-  const int K = 16 * KB, kb1 = a.K1 >> 4, kb2 = kb1 + (a.K2 >> 4);
-  const char* l1 = li_ + (size_t)c * RB + g * 16;
-  const char* l2 = li_ + (size_t)(NC + c) * RB + g * 16;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long m = (tile * 8 + wv) * 16 + c;
     const bool valid = m < a.M;
@@ -374,9 +409,12 @@ __global__ void __launch_bounds__(512) k_linear_x6(const mgn_linear_args a, cons
         for (int kb = 0; kb < KB; ++kb) *(f32x4*)(a.n_out + mm * K + 16 * kb + 4 * g) = in[kb];
       }
     }
-    u32x4_d x1[S], x2[S], x3[S];
+    u32x4_d x1[S], x2[BF ? 1 : S], x3[BF ? 1 : S];
 #pragma unroll
-    for (int s_ = 0; s_ < S; ++s_) split3_bf16x8(in[2 * s_], in[2 * s_ + 1], x1[s_], x2[s_], x3[s_]);
+    for (int s_ = 0; s_ < S; ++s_) {
+      if (BF) x1[s_] = pack_bf16x8(in[2 * s_], in[2 * s_ + 1]);
+      else split3_bf16x8(in[2 * s_], in[2 * s_ + 1], x1[s_], x2[BF ? 0 : s_], x3[BF ? 0 : s_]);
+    }
     for (int ob = ob0; ob < ob1; ++ob) {
       const int n0 = 16 * ob + 4 * g;
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -384,6 +422,18 @@ __global__ void __launch_bounds__(512) k_linear_x6(const mgn_linear_args a, cons
       f32x4 hi2 = (GATE && a.b2 != nullptr) ? *(const f32x4*)(a.b2 + n0) : zero, lo2 = zero;
       const char* w1 = l1 + (size_t)16 * (ob - ob0) * RB;
       const char* w2 = l2 + (size_t)16 * (ob - ob0) * RB;
+      if (BF) {
+        hi = bf16r4(hi), hi2 = bf16r4(hi2);
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) {   // slices alternate between the two accumulators
+          if (s_ & 1) lo = MFMA_BF16(*(const u32x4_d*)(w1 + s_ * 64), x1[s_], lo);
+          else hi = MFMA_BF16(*(const u32x4_d*)(w1 + s_ * 64), x1[s_], hi);
+          if (GATE) {
+            if (s_ & 1) lo2 = MFMA_BF16(*(const u32x4_d*)(w2 + s_ * 64), x1[s_], lo2);
+            else hi2 = MFMA_BF16(*(const u32x4_d*)(w2 + s_ * 64), x1[s_], hi2);
+          }
+        }
+      } else {
 #pragma unroll
       for (int s_ = 0; s_ < S; ++s_) {
         const u32x4_d a1 = *(const u32x4_d*)(w1 + s_ * 64), a2 = *(const u32x4_d*)(w1 + (S + s_) * 64), a3 = *(const u32x4_d*)(w1 + (2 * S + s_) * 64);
@@ -403,7 +453,9 @@ __global__ void __launch_bounds__(512) k_linear_x6(const mgn_linear_args a, cons
           hi2 = MFMA_BF16(c1, x1[s_], hi2);
         }
       }
-      const f32x4 acc = hi + lo, acc2 = hi2 + lo2;
+      }
+      f32x4 acc = hi + lo, acc2 = hi2 + lo2;
+      if (BF) acc = bf16r4(acc), acc2 = bf16r4(acc2);   // a bf16 nn.Linear returns bf16
       if (valid) {
         if (a.saveZ1 != nullptr) *(f32x4*)(a.saveZ1 + mm * a.N + n0) = acc;
         if (GATE && a.saveZ2 != nullptr) *(f32x4*)(a.saveZ2 + mm * a.N + n0) = acc2;
@@ -411,27 +463,50 @@ __global__ void __launch_bounds__(512) k_linear_x6(const mgn_linear_args a, cons
       f32x4 y;
 #pragma unroll
       for (int r = 0; r < 4; ++r) y[r] = d_act(acc[r], a.act);
-      if (GATE) y = y * acc2;
+      if (BF && a.act >= 0) y = bf16r4(y);
+      if (GATE) {
+        y = y * acc2;
+        if (BF) y = bf16r4(y);
+      }
       if (a.resid != nullptr) y = *(const f32x4*)(a.resid + mm * a.ldr + n0) + y;
       if (valid) *(f32x4*)(a.out + mm * a.ldo + n0) = y;
     }
   }
 }
+// number of launches (groups of output blocks) of the k_linear_x6 form, 0 = the launch stays on k_linear
+static int linear_x6_plan(long M, int KB, int N, bool gated, int precision, size_t* img) {
+  static const bool x6_on = [] { const char* e = getenv("MGN_LINEAR_X6"); return e == nullptr || e[0] != '0'; }();
+  if (!x6_on || (KB & 1) || (M + 63) / 64 < 1024) return 0;
+  const int NB = N >> 4;
+  const size_t rowb = (size_t)(4 * (precision == 1 ? 1 : 3) * (KB / 2) + 1) * 16;
+  const size_t full = (size_t)(gated ? 2 : 1) * N * rowb;
+  int nc = 1;
+  while (nc <= NB && (full / nc > 79 * 1024 || NB % nc != 0)) ++nc;
+  if (nc > NB) return 0;
+  *img = full / nc;
+  return nc;
+}
+extern "C" int mgn_linear_accepts_transposed(int64_t M, int K, int N, int gated, int precision) {
+  size_t img;
+  return (K >= 32 && K <= 384 && (K & 31) == 0 && N >= 16 && (N & 15) == 0) ? (linear_x6_plan((long)M, K >> 4, N, gated != 0, precision, &img) > 0) : 0;
+}
 template <int KB>
 static int launch_linear_x6(const mgn_linear_args& a, unsigned grid, size_t lds, int nchunk, hipStream_t s) {
   if constexpr (KB % 2 == 0) {
-    const bool gate = a.W2 != nullptr;
+    const bool gate = a.W2 != nullptr, bf = a.precision == 1;
     const int nbc = (a.N >> 4) / nchunk;
-#define LINX_GO(GATE_)                                                                                                                  \
-  do {                                                                                                                                  \
-    if (lds > 48 * 1024 &&                                                                                                              \
-        hipFuncSetAttribute((const void*)k_linear_x6<KB, GATE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)   \
-      return 2;                                                                                                                         \
-    for (int ch = 0; ch < nchunk; ++ch)                                                                                                 \
-      hipLaunchKernelGGL((k_linear_x6<KB, GATE_>), dim3(grid), dim3(512), lds, s, a, ch * nbc, (ch + 1) * nbc);                         \
+#define LINX_GO(GATE_, BF_)                                                                                                                  \
+  do {                                                                                                                                       \
+    if (lds > 48 * 1024 &&                                                                                                                   \
+        hipFuncSetAttribute((const void*)k_linear_x6<KB, GATE_, BF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)   \
+      return 2;                                                                                                                              \
+    for (int ch = 0; ch < nchunk; ++ch)                                                                                                      \
+      hipLaunchKernelGGL((k_linear_x6<KB, GATE_, BF_>), dim3(grid), dim3(512), lds, s, a, ch * nbc, (ch + 1) * nbc);                         \
   } while (0)
-    if (gate) LINX_GO(true);
-    else LINX_GO(false);
+    if (gate && bf) LINX_GO(true, true);
+    else if (gate) LINX_GO(true, false);
+    else if (bf) LINX_GO(false, true);
+    else LINX_GO(false, false);
 #undef LINX_GO
     return 0;
   } else {
@@ -466,27 +541,22 @@ static int launch_linear(const mgn_linear_args& a, hipStream_t s) {
   // the LDS-resident weight image pays once every workgroup walks several tiles and three or more workgroups fit a CU; an image
   // above 64 KB is cut into 2 or 3 groups of output blocks (MGN_LINEAR_NO_CHUNK: such launches stay on the L2 path, for A/B)
   const int NB = a.N >> 4;
-  // [r5] precision 0, an even number of input blocks, 65 536 rows or more: the six-term split-bf16 form (MGN_LINEAR_X6=0: the
-  // exact-fp32 matrix instruction everywhere, for A/B).  The piece image is 6 bytes per weight; it is cut into groups of output
-  // blocks until two 512-thread workgroups fit a CU.
-  if (KB % 2 == 0 && a.precision == 0 && ntiles >= 1024) {
-    static const bool x6_on = [] { const char* e = getenv("MGN_LINEAR_X6"); return e == nullptr || e[0] != '0'; }();
-    if (x6_on) {
-      const size_t rowb = (size_t)(12 * (KB / 2) + 1) * 16;
-      const size_t fullx = (size_t)(a.W2 != nullptr ? 2 : 1) * a.N * rowb;
-      int nc = 1;
-      while (nc <= NB && (fullx / nc > 79 * 1024 || NB % nc != 0)) ++nc;
-      if (nc <= NB) {
-        const size_t imgx = fullx / nc;
-        const long nt128 = (a.M + 127) / 128;
-        int per_cu = (int)((160 * 1024) / imgx);
-        if (per_cu > 4) per_cu = 4;
-        unsigned grid = 256u * (unsigned)per_cu;
-        if ((long)grid > nt128) grid = (unsigned)nt128;
-        return launch_linear_x6<KB>(a, grid, imgx, nc, s);
-      }
+  // [r5] an even number of input blocks, 65 536 rows or more: k_linear_x6 -- precision 0 as the six-term split-bf16 form, precision 1
+  // as its one-piece form (MGN_LINEAR_X6=0: k_linear everywhere, for A/B).  The piece image is 6 (2) bytes per weight; it is cut into
+  // groups of output blocks until two 512-thread workgroups fit a CU.
+  {
+    size_t imgx;
+    const int nc = linear_x6_plan(a.M, KB, a.N, a.W2 != nullptr, a.precision, &imgx);
+    if (nc > 0) {
+      const long nt128 = (a.M + 127) / 128;
+      int per_cu = (int)((160 * 1024) / imgx);
+      if (per_cu > 4) per_cu = 4;
+      unsigned grid = 256u * (unsigned)per_cu;
+      if ((long)grid > nt128) grid = (unsigned)nt128;
+      return launch_linear_x6<KB>(a, grid, imgx, nc, s);
     }
   }
+  if (a.w_transposed) return 3;
   int nchunk = 1;
   while (nchunk < 4 && (full / nchunk > 64 * 1024 || NB % nchunk != 0)) ++nchunk;
   if (nchunk > 1 && getenv("MGN_LINEAR_NO_CHUNK") != nullptr) nchunk = 4;
@@ -510,7 +580,7 @@ extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
     return dfail(1, "mgn_linear_fwd: input widths must be multiples of 16, at most 384 together");
   if (a.K3 > 0 && (a.ldx3 < a.K3 || (a.ldx3 & 3))) return dfail(1, "mgn_linear_fwd: bad leading dimension of the third phase");
   if (a.N < 16 || (a.N & 15) || a.N > 1024) return dfail(1, "mgn_linear_fwd: output width must be a multiple of 16");
-  if (a.ldx < a.K1 || (a.ldx & 3) || (a.K2 > 0 && (a.ldx2 < a.K2 || (a.ldx2 & 3))) || a.ldw < K || (a.ldw & 3) || a.ldo < a.N || (a.ldo & 3) ||
+  if (a.ldx < a.K1 || (a.ldx & 3) || (a.K2 > 0 && (a.ldx2 < a.K2 || (a.ldx2 & 3))) || a.ldw < (a.w_transposed ? a.N : K) || (a.ldw & 3) || a.ldo < a.N || (a.ldo & 3) ||
       (a.resid != nullptr && (a.ldr < a.N || (a.ldr & 3))))
     return dfail(1, "mgn_linear_fwd: leading dimensions must cover the widths and keep rows 16-byte aligned");
   if (a.act < -1 || a.act > MGN_ACT_GELU) return dfail(1, "mgn_linear_fwd: act must be MGN_ACT_NONE, _RELU, _SILU or _GELU");
@@ -518,7 +588,12 @@ extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
   if (a.M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   switch (K >> 4) {
-#define LIN_CASE(KB_) case KB_: if (launch_linear<KB_>(a, s)) return dfail(2, "mgn_linear_fwd: cannot reserve LDS"); break;
+#define LIN_CASE(KB_)                                                                                                                \
+  case KB_: {                                                                                                                        \
+    const int rc_ = launch_linear<KB_>(a, s);                                                                                        \
+    if (rc_ == 3) return dfail(1, "mgn_linear_fwd: a transposed weight needs the LDS-staged form (mgn_linear_accepts_transposed)");  \
+    if (rc_) return dfail(2, "mgn_linear_fwd: cannot reserve LDS");                                                                  \
+  } break;
     LIN_CASE(1) LIN_CASE(2) LIN_CASE(3) LIN_CASE(4) LIN_CASE(6) LIN_CASE(8) LIN_CASE(12) LIN_CASE(16) LIN_CASE(24)
 #undef LIN_CASE
     default: return dfail(1, "mgn_linear_fwd: total input width must be 16, 32, 48, 64, 96, 128, 192, 256 or 384");

@@ -7,6 +7,7 @@ concatenated input as two phases -- wrapped in a ``torch.autograd.Function`` who
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -22,14 +23,16 @@ def _prec() -> int:
 
 
 def linear_launch(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act: int = ACT_NONE, resid=None, out=None, inv_out=None,
-                  n_out=None, saveZ1=None, saveZ2=None, precision: int = 0, x3=None, idx=(None, None, None), M: Optional[int] = None):
+                  n_out=None, saveZ1=None, saveZ2=None, precision: int = 0, x3=None, idx=(None, None, None), M: Optional[int] = None,
+                  w_transposed: bool = False):
     """one ``mgn_linear_fwd`` launch (include/mgn_hip.h); x / x2 / x3 / resid may be row-strided views (stride(1) == 1);
-    ``idx[p]`` (int32 [M]) gathers the rows of phase p; ``M`` = output rows (default: rows of x)."""
+    ``idx[p]`` (int32 [M]) gathers the rows of phase p; ``M`` = output rows (default: rows of x); ``w_transposed``: W (and W2) are
+    [K, N] -- the launch multiplies by their transpose (see :func:`input_gradient`)."""
     M = int(x.shape[0]) if M is None else int(M)
     K1 = int(x.shape[1])
     K2 = int(x2.shape[1]) if x2 is not None else 0
     K3 = int(x3.shape[1]) if x3 is not None else 0
-    N = int(W.shape[0])
+    N = int(W.shape[1] if w_transposed else W.shape[0])
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     a = _capi.LinearArgs()
@@ -45,10 +48,25 @@ def linear_launch(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act:
     a.resid, a.ldr = ops._ptr(resid), (int(resid.stride(0)) if resid is not None else 0)
     a.out, a.ldo = out.data_ptr(), int(out.stride(0))
     a.saveZ1, a.saveZ2, a.precision = ops._ptr(saveZ1), ops._ptr(saveZ2), precision
+    a.w_transposed = 1 if w_transposed else 0
     with torch.cuda.device(x.device):
         rc = _capi.lib().mgn_linear_fwd(C.byref(a), ops._stream(x.device))
     _capi.check(rc, "mgn_linear_fwd", dense=True)
     return out
+
+
+#: MGN_DENSE_WT=0: always materialise W^T (for A/B; tools/c5_modes.py flips the list entry in one process)
+_WT_ON = [os.environ.get("MGN_DENSE_WT", "1") != "0"]
+
+
+def input_gradient(dZ, W, resid=None, precision: int = 0):
+    """dX = dZ W [+ resid] for the ``nn.Linear`` weight W [N, K] on the same launch.  At row counts where the launch stages its weights
+    through LDS the staging reads W transposed (no copy); elsewhere W^T is materialised first."""
+    M, N = int(dZ.shape[0]), int(dZ.shape[1])
+    K = int(W.shape[1])
+    if _WT_ON[0] and W.stride(1) == 1 and (W.stride(0) & 3) == 0 and _capi.lib().mgn_linear_accepts_transposed(M, N, K, 0, precision):
+        return linear_launch(dZ, W, resid=resid, precision=precision, w_transposed=True)
+    return linear_launch(dZ, W.t().contiguous(), resid=resid, precision=precision)
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:
@@ -123,9 +141,9 @@ class DenseFn(torch.autograd.Function):
         if M > 0 and (any(want) or norm_scale is not None):
             if N > 384:
                 raise NotImplementedError("input gradient of a Linear wider than 384 outputs")
-            dn = linear_launch(dZ1, W.t().contiguous(), precision=prec)
+            dn = input_gradient(dZ1, W, precision=prec)
             if W2 is not None:
-                dn = linear_launch(dZ2, W2.t().contiguous(), resid=dn, precision=prec)
+                dn = input_gradient(dZ2, W2, resid=dn, precision=prec)
             if norm_scale is not None:
                 nph = sum(1 for t in xs if t is not None)
                 rows = [torch.empty(M, Ks[p], **f) for p in range(nph)]       # per (edge) row

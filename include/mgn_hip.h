@@ -619,8 +619,13 @@ typedef struct {
   float* saveZ1;
   float* saveZ2;
   int precision;
+  int w_transposed;   /* W (and W2) are [K, ldw] row-major, ldw >= N: the launch multiplies by their TRANSPOSE -- the input gradient
+                         dX = dZ W of a Linear straight from its nn.Linear weight.  Accepted where the weights are staged through LDS
+                         (mgn_linear_accepts_transposed); elsewhere mgn_linear_fwd returns 1. */
 } mgn_linear_args;
 int mgn_linear_fwd(const mgn_linear_args* args, void* stream);
+/* 1 when mgn_linear_fwd takes w_transposed for this shape (M rows, K = K1 + K2 + K3 inputs, N outputs, gated product or not) */
+int mgn_linear_accepts_transposed(int64_t M, int K, int N, int gated, int precision);
 /* dZ1 = dP * (Z2 or 1) * act'(Z1);  dZ2 = dP * act(Z1)   over [M, N] (Z2 / dZ2 NULL: a plain activation) */
 int mgn_act_gate_bwd(const float* dP, const float* Z1, const float* Z2, int64_t M, int N, int act, int precision, float* dZ1,
                      float* dZ2, void* stream);

@@ -23,8 +23,12 @@ def timed(fn, k=4):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(k): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / k * 1e3
-for rep in range(2):
+from graph_physics_amd import dense as _D
+for rep in range(3):
     for mode in ("fp32", "bf16"):
         ops.set_matrix_precision(mode)
-        print(mode, f"forward {timed(fwd):.2f} ms  train {timed(train):.2f} ms", flush=True)
+        for wt in ((True, False) if "wt" in sys.argv[1:] else (True,)):
+            _D._WT_ON[0] = wt
+            print(mode, f"forward {timed(fwd):.2f} ms  train {timed(train, 8):.2f} ms" + ("" if wt else "   (W^T materialised)"), flush=True)
+_D._WT_ON[0] = True
 ops.set_matrix_precision("fp32")

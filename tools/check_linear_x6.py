@@ -44,6 +44,10 @@ for K, N in ((64, 64), (64, 192), (192, 64), (128, 128), (32, 64), (384, 64), (2
         idx = torch.randint(0, M // 3, (M,), dtype=torch.int32, device=dev)
         o = D.linear_launch(xa, W, None, x2=xb, idx=(None, idx, None), M=M)
         e4 = rel(o, xa.to(d) @ W[:, :k1].to(d).t() + xb.to(d)[idx.long()] @ W[:, k1:].to(d).t())
-    worst = max(worst, e1, e2, e3, e4)
-    print(f"{K:4d} -> {N:4d}: resid {e1:.2e}  norm+gelu+saves {e2:.2e}  gated silu {e3:.2e}  two phases / gather {e4:.2e}", flush=True)
+    # the input gradient of a Linear straight from its weight (staged transposed)
+    dz = torch.randn(M, N, **f)
+    o = D.input_gradient(dz, W, resid=x)
+    e5 = rel(o, x.to(d) + dz.to(d) @ W.to(d))
+    worst = max(worst, e1, e2, e3, e4, e5)
+    print(f"{K:4d} -> {N:4d}: resid {e1:.2e}  norm+gelu+saves {e2:.2e}  gated silu {e3:.2e}  two phases / gather {e4:.2e}  dX = dZ W {e5:.2e}", flush=True)
 print(f"MGN_LINEAR_X6={os.environ.get('MGN_LINEAR_X6', '1')}  rows {M}  worst {worst:.2e}")

@@ -12,6 +12,8 @@ from graph_physics_amd import dense as D
 from tools.kbench import timeit
 
 dev = torch.device("cuda:0")
+PREC = int(os.environ.get("KB_PREC", "0"))   # 1: the bf16 matrix mode of the Linear launches
+LL = lambda *a_, **k_: D.linear_launch(*a_, precision=PREC, **k_)  # noqa: E731
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 150000
 f = dict(dtype=torch.float32, device=dev)
 torch.manual_seed(0)
@@ -30,14 +32,17 @@ def rep(name, fn, nbytes):
 
 
 row = 4.0 * M
-rep("linear 64->64 plain", lambda: D.linear_launch(x64, W[(64, 64)], b64, out=o64), row * 128)
-rep("linear 64->64 norm prologue (inference)", lambda: D.linear_launch(x64, W[(64, 64)], b64, norm_scale=sc, out=o64), row * 128)
-rep("linear 64->64 norm prologue + inv + n_out (training)", lambda: D.linear_launch(x64, W[(64, 64)], b64, norm_scale=sc, out=o64, inv_out=inv, n_out=n_out), row * 192)
-rep("linear 64->64 + residual", lambda: D.linear_launch(x64, W[(64, 64)], b64, resid=x64, out=o64), row * 192)
-rep("gated 64->192 norm, gelu (inference)", lambda: D.linear_launch(x64, W[(192, 64)], b192, W2=W[(192, 64)], b2=b192, norm_scale=sc, act=2, out=o192), row * 256)
-rep("gated 64->192 norm, gelu + Z1 Z2 n_out (training)", lambda: D.linear_launch(x64, W[(192, 64)], b192, W2=W[(192, 64)], b2=b192, norm_scale=sc, act=2, out=o192, inv_out=inv, n_out=n_out, saveZ1=z1, saveZ2=z2), row * (64 + 192 * 3 + 64))
-rep("linear 192->64 + residual", lambda: D.linear_launch(x192, W[(64, 192)], b64, resid=x64, out=o64), row * 320)
-rep("linear 192->64 (dX of the gate Linears)", lambda: D.linear_launch(x192, W[(64, 192)], None, out=o64), row * 256)
+rep("linear 64->64 plain", lambda: LL(x64, W[(64, 64)], b64, out=o64), row * 128)
+rep("linear 64->64 norm prologue (inference)", lambda: LL(x64, W[(64, 64)], b64, norm_scale=sc, out=o64), row * 128)
+rep("linear 64->64 norm prologue + inv + n_out (training)", lambda: LL(x64, W[(64, 64)], b64, norm_scale=sc, out=o64, inv_out=inv, n_out=n_out), row * 192)
+rep("linear 64->64 + residual", lambda: LL(x64, W[(64, 64)], b64, resid=x64, out=o64), row * 192)
+rep("gated 64->192 norm, gelu (inference)", lambda: LL(x64, W[(192, 64)], b192, W2=W[(192, 64)], b2=b192, norm_scale=sc, act=2, out=o192), row * 256)
+rep("gated 64->192 norm, gelu + Z1 Z2 n_out (training)", lambda: LL(x64, W[(192, 64)], b192, W2=W[(192, 64)], b2=b192, norm_scale=sc, act=2, out=o192, inv_out=inv, n_out=n_out, saveZ1=z1, saveZ2=z2), row * (64 + 192 * 3 + 64))
+rep("linear 192->64 + residual", lambda: LL(x192, W[(64, 192)], b64, resid=x64, out=o64), row * 320)
+rep("linear 192->64 (dX of the gate Linears)", lambda: LL(x192, W[(64, 192)], None, out=o64), row * 256)
+WT = torch.randn(192, 64, **f) * 0.1   # the nn.Linear weight of a 64 -> 192 Linear: its input gradient is 192 -> 64
+rep("dX = dZ W, 192 -> 64, weight staged transposed", lambda: D.input_gradient(x192, WT, precision=PREC), row * 256)
+rep("dX = dZ W, 192 -> 64, + residual", lambda: D.input_gradient(x192, WT, resid=x64, precision=PREC), row * 320)
 L = _capi.lib()
 dx, dscale = torch.empty(M, 64, **f), torch.empty(64, **f)
 ws = torch.empty(L.mgn_rownorm_bwd_workspace_bytes(64), dtype=torch.uint8, device=dev)
