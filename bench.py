@@ -560,7 +560,8 @@ def c5_record(args, gp, ops, harness, dev):
     torch.manual_seed(0)
     net = gp.get_model(cfg).to(dev)
     graph = gp.Graph(x=torch.randn(n, 23, device=dev), edge_index=ei, pos=torch.from_numpy(pts).to(dev))
-    graph.mgn_attn_topology = T.get_attn_topology(ei, n)
+    # (no pinned topology: EncodeTransformDecode.forward builds and caches it, renumbering the randomly numbered nodes along a
+    #  Morton curve of graph.pos -- transformer.ATTN_RENUMBER_MIN_NODES)
     tgt = torch.randn(n, 3, device=dev)
     opt = harness.FusedClipAdamW(net.parameters(), 1e-4, max_norm=1.0)
 
@@ -594,8 +595,10 @@ def c5_record(args, gp, ops, harness, dev):
                          "train_steps_per_s": round(1.0 / tt, 2)}
     finally:
         ops.set_matrix_precision(prev)
-    # the sparse-attention kernels on their own
-    topo = graph.mgn_attn_topology
+    rec["node_renumbering"] = ("Morton order of graph.pos inside EncodeTransformDecode.forward (rows permuted on entry, back on exit): "
+                               + ("on" if T.want_attn_renumbering(n, graph.pos) else "off"))
+    # the sparse-attention kernels on their own, on the topology the model runs on
+    topo = T.get_attn_topology(ei, n, pos=graph.pos, renumber=True)
     q, k, v = (torch.randn(n, H, device=dev) for _ in range(3))
     dy = torch.randn(n, H, device=dev)
 
@@ -701,7 +704,6 @@ def c5_dp_record(args, gp, D, ops, harness, rank, world, dev):
     net = gp.get_model(cfg).to(dev)
     D.broadcast_parameters(net)
     graph = gp.Graph(x=torch.randn(n, 23, device=dev), edge_index=ei, pos=torch.from_numpy(pts).to(dev))
-    graph.mgn_attn_topology = T.get_attn_topology(ei, n)
     tgt = torch.randn(n, 3, device=dev)
     opt = harness.FusedClipAdamW(net.parameters(), 1e-4, max_norm=1.0)
     sync = D.GradAllReduce()

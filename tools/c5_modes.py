@@ -7,12 +7,20 @@ from graph_physics_amd import harness, ops, preprocess as PP, transformer as T
 dev = torch.device("cuda:0")
 n = 150000
 pts = np.random.default_rng(0).random((n, 3)).astype(np.float32)
+if "sorted" in sys.argv[1:]:   # the points numbered along a Morton curve (what a node renumbering inside the engine would see)
+    q = (pts * 1023).astype(np.int64)
+    key = np.zeros(n, dtype=np.int64)
+    for b in range(10):
+        for ax in range(3):
+            key |= ((q[:, ax] >> b) & 1) << (3 * b + ax)
+    pts = pts[np.argsort(key, kind="stable")]
 ei = PP.faces_to_edges(torch.from_numpy(Delaunay(pts).simplices.T.astype(np.int64)).to(dev), n)
 cfg = {"model": {"type": "transformer", "message_passing_num": 10, "hidden_size": 64, "node_input_size": 14, "output_size": 3, "edge_input_size": 0, "num_heads": 4}, "training": {"use_temporal_block": False}}
 torch.manual_seed(0)
 net = gp.get_model(cfg).to(dev)
 g = gp.Graph(x=torch.randn(n, 23, device=dev), edge_index=ei, pos=torch.from_numpy(pts).to(dev))
-g.mgn_attn_topology = T.get_attn_topology(ei, n)
+if os.environ.get("C5_PIN_TOPOLOGY"):   # the caller's numbering (no Morton renumbering inside the engine)
+    g.mgn_attn_topology = T.get_attn_topology(ei, n)
 tgt = torch.randn(n, 3, device=dev)
 opt = harness.FusedClipAdamW(net.parameters(), 1e-4, max_norm=1.0)
 def train():

@@ -1,4 +1,5 @@
 """kernel-trace target: a few configs[4] training steps in one matrix mode (argv[1] = fp32 | bf16)"""
+import os
 import sys
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
@@ -14,7 +15,8 @@ cfg = {"model": {"type": "transformer", "message_passing_num": 10, "hidden_size"
 torch.manual_seed(0)
 net = gp.get_model(cfg).to(dev)
 g = gp.Graph(x=torch.randn(n, 23, device=dev), edge_index=ei, pos=torch.from_numpy(pts).to(dev))
-g.mgn_attn_topology = T.get_attn_topology(ei, n)
+if os.environ.get("C5_PIN_TOPOLOGY"):   # the caller's numbering (no Morton renumbering inside the engine)
+    g.mgn_attn_topology = T.get_attn_topology(ei, n)
 tgt = torch.randn(n, 3, device=dev)
 opt = harness.FusedClipAdamW(net.parameters(), 1e-4, max_norm=1.0)
 ops.set_matrix_precision(mode)
