@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "mgn_hip.h"
 
 static thread_local char g_aerr[256] = "";
@@ -108,6 +109,39 @@ __device__ __forceinline__ void head_reduce(float (&p)[4], int NH) {
   }
 }
 
+// [r5] Four heads (the reference's default, coarse-aneurysm.json): a lane's four features are the four heads of one head-dim index, so
+// after head_reduce ALL lanes of a row hold the same four scores and the per-head scalar work -- the exponentials above all: 9
+// instructions each, these kernels are bound by vector-instruction issue -- was done four times per lane, identically.  Q4: lane l
+// does it for head l & 3 only and the quad hands the results round (v_mov_b32_dpp quad_perm:[r,r,r,r]); the per-feature updates
+// stay per lane; the score itself comes from head_reduce_own below.
+template <int R>
+__device__ __forceinline__ float quad_bcast(float x) {
+  constexpr int ctrl = R | (R << 2) | (R << 4) | (R << 6);
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sel4(const float (&p)[4], int h) { return h == 0 ? p[0] : h == 1 ? p[1] : h == 2 ? p[2] : p[3]; }
+// Q4: the sum over the row's lanes of p[l & 3] ONLY (what lane l needs), as a reduce-scatter inside the quad -- pairs exchange the two
+// heads the partner keeps (2 adds), then the one head (1 add) -- followed by the strides >= 4 on that one value: 6 selects + 3..6 DPP
+// adds where the all-lanes butterfly of head_reduce takes 16 adds (+ 3 selects to pick the head).  Another association of the same
+// 16 terms than head_reduce's (results differ in the last bit; forward and backward use the same one).
+#define ATTN_DPP_ADD(MINE, GIVE, CTRL) \
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(MINE) : "v"(GIVE))
+template <int LPR>
+__device__ __forceinline__ float head_reduce_own(const float (&p)[4], int l) {
+  const bool b0 = l & 1, b1 = l & 2;
+  float m0 = b0 ? p[1] : p[0], m1 = b0 ? p[3] : p[2];
+  const float g0 = b0 ? p[0] : p[1], g1 = b0 ? p[2] : p[3];
+  ATTN_DPP_ADD(m0, g0, "quad_perm:[1,0,3,2]");
+  ATTN_DPP_ADD(m1, g1, "quad_perm:[1,0,3,2]");
+  float m = b1 ? m1 : m0;
+  const float g = b1 ? m0 : m1;
+  ATTN_DPP_ADD(m, g, "quad_perm:[2,3,0,1]");
+  if constexpr (LPR >= 32) m = xor_add<16, LPR>(m);
+  if constexpr (LPR >= 16) m = xor_add<8, LPR>(m);
+  if constexpr (LPR >= 8) m = xor_add<4, LPR>(m);
+  return m;
+}
+
 // The edge loops below are software-pipelined by hand: the column index of edge e + 2 and the gathered rows of edge e + 1 are
 // requested before edge e is processed (a lane walks ONE row's edges serially, and index -> row -> arithmetic is a dependent
 // chain of two memory latencies per edge otherwise; rows of a wave have different degrees, so the compiler does not do it).
@@ -162,7 +196,7 @@ struct AttnLd {
 };
 
 // y[i] and lse[i] (per feature: log-sum-exp of its head's scores) for every row i
-template <int LPR, int GS, bool B16>
+template <int LPR, int GS, int B16, bool Q4>
 __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
                                                  const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
                                                  float scale, float sd, float* __restrict__ y, float* __restrict__ lse, float* __restrict__ y_raw, AttnLd ld) {
@@ -171,19 +205,37 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
   const int l = threadIdx.x % LPR;
   if (i >= N) return;
   const float4 qv = *(const float4*)(q + (size_t)i * ld.q + 4 * l);
-  const float qq[4] = {qscaled<B16>(qv.x, scale, sd), qscaled<B16>(qv.y, scale, sd), qscaled<B16>(qv.z, scale, sd), qscaled<B16>(qv.w, scale, sd)};
+  const float qq[4] = {qscaled<(B16 != 0)>(qv.x, scale, sd), qscaled<(B16 != 0)>(qv.y, scale, sd), qscaled<(B16 != 0)>(qv.z, scale, sd), qscaled<(B16 != 0)>(qv.w, scale, sd)};
   float m[4] = {ATTN_M0, ATTN_M0, ATTN_M0, ATTN_M0}, s[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int hm = l & 3;               // Q4: the head this lane keeps the softmax state of
+  float m_ = ATTN_M0, s_ = 0.f;
   const int e0 = rowptr[i], e1 = rowptr[i + 1];
   if (e0 < e1) {
-    float4 kv = ldkv<B16>(k, (size_t)col[e0], ld.k, l), vv = ldkv<B16>(v, (size_t)col[e0], ld.v, l);
+    float4 kv = ldkv<B16 == 1>(k, (size_t)col[e0], ld.k, l), vv = ldkv<B16 == 1>(v, (size_t)col[e0], ld.v, l);
     int jn = (e0 + 1 < e1) ? col[e0 + 1] : 0;
     for (int e = e0; e < e1; ++e) {
       float4 kn = kv, vn = vv;
-      if (e + 1 < e1) kn = ldkv<B16>(k, (size_t)jn, ld.k, l), vn = ldkv<B16>(v, (size_t)jn, ld.v, l);
+      if (e + 1 < e1) kn = ldkv<B16 == 1>(k, (size_t)jn, ld.k, l), vn = ldkv<B16 == 1>(v, (size_t)jn, ld.v, l);
       if (e + 2 < e1) jn = col[e + 2];
       float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
-      head_reduce<LPR, GS>(p, NH);
+      if constexpr (!Q4) head_reduce<LPR, GS>(p, NH);
       const float vr[4] = {vv.x, vv.y, vv.z, vv.w};
+      if constexpr (Q4) {
+        const float pm = head_reduce_own<LPR>(p, l);
+        const bool up = pm > m_;
+        const float t = exp_sm(-fabsf(pm - m_));
+        s_ = up ? __builtin_fmaf(s_, t, 1.f) : s_ + t;
+        m_ = up ? pm : m_;
+        const float ts = up ? -t : t;   // the factor with "the maximum moved" in its sign bit (t >= 0; -0 keeps the bit)
+#define ATTN_Q4_ACC(R)                                                                                  \
+  {                                                                                                     \
+    const float tb = quad_bcast<R>(ts);                                                                 \
+    const float tt = fabsf(tb);                                                                         \
+    acc[R] = (__builtin_bit_cast(int, tb) < 0) ? __builtin_fmaf(acc[R], tt, vr[R]) : __builtin_fmaf(tt, vr[R], acc[R]); \
+  }
+        ATTN_Q4_ACC(0) ATTN_Q4_ACC(1) ATTN_Q4_ACC(2) ATTN_Q4_ACC(3)
+#undef ATTN_Q4_ACC
+      } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         // online softmax with ONE exponential per head and edge: of the two factors exp(m - nm), exp(p - nm) one is exactly 1, so the
@@ -196,8 +248,13 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
         acc[r] = up ? __builtin_fmaf(acc[r], t, vr[r]) : __builtin_fmaf(t, vr[r], acc[r]);
         m[r] = up ? p[r] : m[r];
       }
+      }
       kv = kn, vv = vn;
     }
+  }
+  if constexpr (Q4) {
+    s[0] = quad_bcast<0>(s_), s[1] = quad_bcast<1>(s_), s[2] = quad_bcast<2>(s_), s[3] = quad_bcast<3>(s_);
+    m[0] = quad_bcast<0>(m_), m[1] = quad_bcast<1>(m_), m[2] = quad_bcast<2>(m_), m[3] = quad_bcast<3>(m_);
   }
   float4 o, ls;
   float* op = &o.x;
@@ -219,7 +276,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
 // backward, pass A (by row): dq[i]; per edge and head the attention weight a and the score gradient ds
 //   D[h] = sum_d dy[i,d,h] y[i,d,h];  a = exp(score - lse);  dA = sum_d dy[i,d,h] v[j,d,h];  ds = a (dA - D)
 //   dq[i,f] = scale * sum_e ds[e,h(f)] k[j_e,f]
-template <int LPR, int GS, bool B16>
+template <int LPR, int GS, int B16, bool Q4>
 __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
                                                      const float* __restrict__ y, const float* __restrict__ lse, const float* __restrict__ dy,
                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
@@ -234,7 +291,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
   const float4 qv = *(const float4*)(q + (size_t)i * ld.q + 4 * l), yv = *(const float4*)(y + ro), lv = *(const float4*)(lse + ro);
   float4 gv = *(const float4*)(dy + ro);
   if (B16) gv = make_float4(bf16r(gv.x), bf16r(gv.y), bf16r(gv.z), bf16r(gv.w));
-  const float qq[4] = {qscaled<B16>(qv.x, scale, sd), qscaled<B16>(qv.y, scale, sd), qscaled<B16>(qv.z, scale, sd), qscaled<B16>(qv.w, scale, sd)};
+  const float qq[4] = {qscaled<(B16 != 0)>(qv.x, scale, sd), qscaled<(B16 != 0)>(qv.y, scale, sd), qscaled<(B16 != 0)>(qv.z, scale, sd), qscaled<(B16 != 0)>(qv.w, scale, sd)};
   const float g[4] = {gv.x, gv.y, gv.z, gv.w}, ls[4] = {lv.x, lv.y, lv.z, lv.w};
   if (B16 && q16 != nullptr) {   // the column pass gathers these rows per edge: hand it the bf16 tensors themselves (both ARE bf16 values)
     auto pk2 = [](float a_, float b_) { return (__builtin_bit_cast(unsigned, a_) >> 16) | (__builtin_bit_cast(unsigned, b_) & 0xffff0000u); };
@@ -243,23 +300,38 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
   }
   float D[4] = {gv.x * yv.x, gv.y * yv.y, gv.z * yv.z, gv.w * yv.w};
   head_reduce<LPR, GS>(D, NH);
+  const float ls_m = sel4(ls, l & 3), D_m = sel4(D, l & 3);   // Q4
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int gs = (NH >= 4) ? (NH >> 2) : 1;     // lanes 0 .. gs-1 hold one copy of every head between them
   const int nr = (NH >= 4) ? 4 : NH;
   const int e0 = rowptr[i], e1 = rowptr[i + 1];
   if (e0 < e1) {
-    float4 kv = ldkv<B16>(k, (size_t)col[e0], ld.k, l), vv = ldkv<B16>(v, (size_t)col[e0], ld.v, l);
+    float4 kv = ldkv<B16 == 1>(k, (size_t)col[e0], ld.k, l), vv = ldkv<B16 == 1>(v, (size_t)col[e0], ld.v, l);
     int jn = (e0 + 1 < e1) ? col[e0 + 1] : 0;
     for (int e = e0; e < e1; ++e) {
       float4 kn = kv, vn = vv;
-      if (e + 1 < e1) kn = ldkv<B16>(k, (size_t)jn, ld.k, l), vn = ldkv<B16>(v, (size_t)jn, ld.v, l);
+      if (e + 1 < e1) kn = ldkv<B16 == 1>(k, (size_t)jn, ld.k, l), vn = ldkv<B16 == 1>(v, (size_t)jn, ld.v, l);
       if (e + 2 < e1) jn = col[e + 2];
       const float kr[4] = {kv.x, kv.y, kv.z, kv.w};
       float p[4] = {qq[0] * kv.x, qq[1] * kv.y, qq[2] * kv.z, qq[3] * kv.w};
       float dA[4] = {g[0] * vv.x, g[1] * vv.y, g[2] * vv.z, g[3] * vv.w};
+      float a4[4], d4[4];
+      if constexpr (Q4) {   // head l & 3 per lane, the score gradient handed round the quad; lanes 0..3 store their head's pair
+        const float a_m = exp_sm(head_reduce_own<LPR>(p, l) - ls_m);
+        const float d_m = a_m * (head_reduce_own<LPR>(dA, l) - D_m);
+        acc[0] += quad_bcast<0>(d_m) * kr[0];
+        acc[1] += quad_bcast<1>(d_m) * kr[1];
+        acc[2] += quad_bcast<2>(d_m) * kr[2];
+        acc[3] += quad_bcast<3>(d_m) * kr[3];
+        if (l < 4) {
+          a_out[(size_t)e * 4 + l] = a_m;
+          ds_out[(size_t)e * 4 + l] = d_m;
+        }
+        kv = kn, vv = vn;
+        continue;
+      }
       head_reduce<LPR, GS>(p, NH);
       head_reduce<LPR, GS>(dA, NH);
-      float a4[4], d4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         a4[r] = exp_sm(p[r] - ls[r]);
@@ -292,7 +364,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
 // backward, pass B (by column j through the column-grouped order of the same edges: the t-th edge of that order is the
 // row-sorted edge cperm[t], whose row is crow[t]):
 //   dk[j,f] = scale * sum_e ds[e,h(f)] q[i_e,f];   dv[j,f] = sum_e a[e,h(f)] dy[i_e,f]
-template <int LPR, int GS, bool B16>
+template <int LPR, int GS, int B16, bool Q4_UNUSED>
 __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ q, const float* __restrict__ dy, const float* __restrict__ a_in,
                                                      const float* __restrict__ ds_in, const int32_t* __restrict__ cptr,
                                                      const int32_t* __restrict__ cperm, const int32_t* __restrict__ crow, long N, int NH,
@@ -366,7 +438,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
 
 // attention weights per edge and head (return_attention=True, layers.py:543-559): a[e,h] = exp(score[e,h] - lse[i_e,h]),
 // written at out_pos[e] (the edge's position in the caller's edge_index; NULL: the row-sorted position itself)
-template <int LPR, int GS, bool B16_UNUSED>
+template <int LPR, int GS, int B16_UNUSED, bool Q4_UNUSED>
 __global__ void __launch_bounds__(256) k_attn_weights(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ lse,
                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                      const int32_t* __restrict__ out_pos, long N, int NH, float scale, float* __restrict__ a_out) {
@@ -398,25 +470,32 @@ static int attn_args_ok(int64_t N, int H, int NH) {
   return 1;
 }
 
-#define ATTN_DISPATCH_GS(KERNEL, GS_, B16, ...)                                                                        \
+// MGN_ATTN_Q4=0: four heads on the every-lane form (A/B; the two forms agree to the last bits: another association of the head sums)
+static bool attn_q4_on() {
+  static const bool on = [] { const char* e = getenv("MGN_ATTN_Q4"); return e == nullptr || e[0] != '0'; }();
+  return on;
+}
+#define ATTN_DISPATCH_GS(KERNEL, GS_, B16, Q4_, ...)                                                                       \
   do {                                                                                                           \
     const unsigned grid = (unsigned)(((long)N * (H / 4) + 255) / 256);                                           \
     switch (H) {                                                                                                 \
-      case 128: hipLaunchKernelGGL((KERNEL<32, GS_, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;     \
-      case 64: hipLaunchKernelGGL((KERNEL<16, GS_, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;      \
-      case 32: hipLaunchKernelGGL((KERNEL<8, GS_, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;       \
-      default: hipLaunchKernelGGL((KERNEL<4, GS_, B16>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;       \
+      case 128: hipLaunchKernelGGL((KERNEL<32, GS_, B16, Q4_>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;     \
+      case 64: hipLaunchKernelGGL((KERNEL<16, GS_, B16, Q4_>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;      \
+      case 32: hipLaunchKernelGGL((KERNEL<8, GS_, B16, Q4_>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;       \
+      default: hipLaunchKernelGGL((KERNEL<4, GS_, B16, Q4_>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); break;       \
     }                                                                                                            \
   } while (0)
 // the reduction stride is a template argument: 1 (up to 4 heads), 2 (8 heads), 4 (16 heads)
 #define ATTN_DISPATCH(KERNEL, B16, ...)                                    \
   do {                                                                     \
-    if (num_heads <= 4)                                                    \
-      ATTN_DISPATCH_GS(KERNEL, 1, B16, __VA_ARGS__);                       \
+    if (num_heads == 4 && attn_q4_on())                                    \
+      ATTN_DISPATCH_GS(KERNEL, 1, B16, true, __VA_ARGS__);                 \
+    else if (num_heads <= 4)                                               \
+      ATTN_DISPATCH_GS(KERNEL, 1, B16, false, __VA_ARGS__);                \
     else if (num_heads == 8)                                               \
-      ATTN_DISPATCH_GS(KERNEL, 2, B16, __VA_ARGS__);                       \
+      ATTN_DISPATCH_GS(KERNEL, 2, B16, false, __VA_ARGS__);                \
     else                                                                   \
-      ATTN_DISPATCH_GS(KERNEL, 4, B16, __VA_ARGS__);                       \
+      ATTN_DISPATCH_GS(KERNEL, 4, B16, false, __VA_ARGS__);                \
   } while (0)
 
 static int attn_ld_ok(const AttnLd& ld, int H, bool grads) {
@@ -427,7 +506,7 @@ static int attn_ld_ok(const AttnLd& ld, int H, bool grads) {
 }
 static AttnLd attn_dense_ld(int H) { return AttnLd{H, H, H, H, H, H}; }
 
-static int attn_fwd_any(bool b16, const float* q, const void* k, const void* v, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
+static int attn_fwd_any(int b16, const float* q, const void* k, const void* v, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
                         int num_heads, float* y, float* lse, float* y_raw, AttnLd ld, void* stream, const char* who) {
   if (!attn_args_ok(N, H, num_heads)) {
     snprintf(g_aerr, sizeof(g_aerr), "%s: hidden must be 16/32/64/128 and num_heads 1/2/4/8/16 dividing it", who);
@@ -440,14 +519,16 @@ static int attn_fwd_any(bool b16, const float* q, const void* k, const void* v, 
   if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const float sd = sqrtf((float)(H / num_heads)), scale = 1.0f / sd;
-  if (b16)
-    ATTN_DISPATCH(k_attn_fwd, true, q, k, v, rowptr, col, (long)N, num_heads, scale, sd, y, lse, y_raw, ld);
+  if (b16 == 1)
+    ATTN_DISPATCH(k_attn_fwd, 1, q, k, v, rowptr, col, (long)N, num_heads, scale, sd, y, lse, y_raw, ld);
+  else if (b16 == 2)
+    ATTN_DISPATCH(k_attn_fwd, 2, q, k, v, rowptr, col, (long)N, num_heads, scale, sd, y, lse, y_raw, ld);
   else
-    ATTN_DISPATCH(k_attn_fwd, false, q, k, v, rowptr, col, (long)N, num_heads, scale, sd, y, lse, y_raw, ld);
+    ATTN_DISPATCH(k_attn_fwd, 0, q, k, v, rowptr, col, (long)N, num_heads, scale, sd, y, lse, y_raw, ld);
   return acheck(who);
 }
 
-static int attn_bwd_any(bool b16, const float* q, const void* k, const void* v, const float* y, const float* lse, const float* dy,
+static int attn_bwd_any(int b16, const float* q, const void* k, const void* v, const float* y, const float* lse, const float* dy,
                         const int32_t* rowptr, const int32_t* col, const int32_t* cptr, const int32_t* cperm, const int32_t* crow, int64_t N,
                         int64_t E, int H, int num_heads, float* dq, float* dk, float* dv, float* ws, size_t ws_bytes, AttnLd ld, void* stream,
                         const char* who) {
@@ -471,25 +552,26 @@ static int attn_bwd_any(bool b16, const float* q, const void* k, const void* v, 
   // bf16 mode with N * H more floats of workspace: the row pass leaves bf16(q / sd) and bf16(dy) as two-byte rows for the column pass
   uint16_t* q16 = nullptr;
   uint16_t* g16 = nullptr;
-  if (b16 && ws_bytes >= ((size_t)2 * E * num_heads + (size_t)N * H) * sizeof(float)) {
+  if (b16 == 1 && ws_bytes >= ((size_t)2 * E * num_heads + (size_t)N * H) * sizeof(float)) {
     q16 = (uint16_t*)(ws + (size_t)2 * E * num_heads);
     g16 = q16 + (size_t)N * H;
   }
-  if (b16) {
-    ATTN_DISPATCH(k_attn_bwd_row, true, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e, ld, q16, g16);
-    ATTN_DISPATCH(k_attn_bwd_col, true, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv, ld,
-                  (const uint16_t*)q16, (const uint16_t*)g16);
-  } else {
-    ATTN_DISPATCH(k_attn_bwd_row, false, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e, ld, q16, g16);
-    ATTN_DISPATCH(k_attn_bwd_col, false, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv, ld,
-                  (const uint16_t*)q16, (const uint16_t*)g16);
-  }
+#define ATTN_BWD_GO(B16_)                                                                                                                       \
+  do {                                                                                                                                         \
+    ATTN_DISPATCH(k_attn_bwd_row, B16_, q, k, v, y, lse, dy, rowptr, col, (long)N, num_heads, scale, sd, dq, a_e, ds_e, ld, q16, g16);            \
+    ATTN_DISPATCH(k_attn_bwd_col, B16_, q, dy, (const float*)a_e, (const float*)ds_e, cptr, cperm, crow, (long)N, num_heads, scale, sd, dk, dv, \
+                  ld, (const uint16_t*)q16, (const uint16_t*)g16);                                                                             \
+  } while (0)
+  if (b16 == 1) ATTN_BWD_GO(1);
+  else if (b16 == 2) ATTN_BWD_GO(2);
+  else ATTN_BWD_GO(0);
+#undef ATTN_BWD_GO
   return acheck(who);
 }
 
 extern "C" int mgn_sparse_attn_fwd(const float* q, const float* k, const float* v, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
                                    int num_heads, float* y, float* lse, void* stream) {
-  return attn_fwd_any(false, q, k, v, rowptr, col, N, H, num_heads, y, lse, nullptr, attn_dense_ld(H), stream, "mgn_sparse_attn_fwd");
+  return attn_fwd_any(0, q, k, v, rowptr, col, N, H, num_heads, y, lse, nullptr, attn_dense_ld(H), stream, "mgn_sparse_attn_fwd");
 }
 
 extern "C" int mgn_sparse_attn_bwd(const float* q, const float* k, const float* v, const float* y, const float* lse, const float* dy,
@@ -502,7 +584,7 @@ extern "C" int mgn_sparse_attn_bwd(const float* q, const float* k, const float* 
 
 extern "C" int mgn_sparse_attn_fwd_b16(const float* q, const uint16_t* k16, const uint16_t* v16, const int32_t* rowptr, const int32_t* col,
                                        int64_t N, int H, int num_heads, float* y, float* lse, float* y_raw, void* stream) {
-  return attn_fwd_any(true, q, k16, v16, rowptr, col, N, H, num_heads, y, lse, y_raw, attn_dense_ld(H), stream, "mgn_sparse_attn_fwd_b16");
+  return attn_fwd_any(1, q, k16, v16, rowptr, col, N, H, num_heads, y, lse, y_raw, attn_dense_ld(H), stream, "mgn_sparse_attn_fwd_b16");
 }
 
 extern "C" int mgn_sparse_attn_bwd_b16(const float* q, const uint16_t* k16, const uint16_t* v16, const float* y, const float* lse,
@@ -513,13 +595,16 @@ extern "C" int mgn_sparse_attn_bwd_b16(const float* q, const uint16_t* k16, cons
                       "mgn_sparse_attn_bwd_b16");
 }
 
-// Strided forms: q / k / v as column slabs of one projection output (ldq / ldk / ldv = row pitches in elements; kv_bf16: k / v are
-// bf16 rows and the bf16-mode roundings apply, as in the *_b16 pair), dq / dk / dv as slabs of its gradient.
+// Strided forms: q / k / v as column slabs of one projection output (ldq / ldk / ldv = row pitches in elements; kv_bf16 = 1: k / v are
+// bf16 rows and the bf16-mode roundings apply, as in the *_b16 pair; [r5] kv_bf16 = 2: the same roundings on k / v kept as FP32 rows
+// whose values are bf16 numbers -- the slabs of a bf16-mode projection as they are, no narrowing copy, and the gather path of the
+// fp32 kernels, which is the faster one once the rows are cache-local), dq / dk / dv as slabs of its gradient.
 extern "C" int mgn_sparse_attn_fwd_s(const float* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int kv_bf16,
                                      const int32_t* rowptr, const int32_t* col, int64_t N, int H, int num_heads, float* y, float* lse,
                                      float* y_raw, void* stream) {
   const AttnLd ld{(int)ldq, (int)ldk, (int)ldv, H, H, H};
-  return attn_fwd_any(kv_bf16 != 0, q, k, v, rowptr, col, N, H, num_heads, y, lse, y_raw, ld, stream, "mgn_sparse_attn_fwd_s");
+  if (kv_bf16 < 0 || kv_bf16 > 2) return afail(1, "mgn_sparse_attn_fwd_s: kv_bf16 must be 0, 1 or 2");
+  return attn_fwd_any(kv_bf16, q, k, v, rowptr, col, N, H, num_heads, y, lse, y_raw, ld, stream, "mgn_sparse_attn_fwd_s");
 }
 
 extern "C" int mgn_sparse_attn_bwd_s(const float* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int kv_bf16,
@@ -528,7 +613,8 @@ extern "C" int mgn_sparse_attn_bwd_s(const float* q, int64_t ldq, const void* k,
                                      int num_heads, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* ws,
                                      size_t ws_bytes, void* stream) {
   const AttnLd ld{(int)ldq, (int)ldk, (int)ldv, (int)lddq, (int)lddk, (int)lddv};
-  return attn_bwd_any(kv_bf16 != 0, q, k, v, y, lse, dy, rowptr, col, cptr, cperm, crow, N, E, H, num_heads, dq, dk, dv, ws, ws_bytes, ld,
+  if (kv_bf16 < 0 || kv_bf16 > 2) return afail(1, "mgn_sparse_attn_bwd_s: kv_bf16 must be 0, 1 or 2");
+  return attn_bwd_any(kv_bf16, q, k, v, y, lse, dy, rowptr, col, cptr, cperm, crow, N, E, H, num_heads, dq, dk, dv, ws, ws_bytes, ld,
                       stream, "mgn_sparse_attn_bwd_s");
 }
 
@@ -538,6 +624,6 @@ extern "C" int mgn_sparse_attn_weights(const float* q, const float* k, const flo
   if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const float scale = 1.0f / sqrtf((float)(H / num_heads));
-  ATTN_DISPATCH(k_attn_weights, false, q, k, lse, rowptr, col, out_pos, (long)N, num_heads, scale, attn);
+  ATTN_DISPATCH(k_attn_weights, 0, q, k, lse, rowptr, col, out_pos, (long)N, num_heads, scale, attn);
   return acheck("mgn_sparse_attn_weights");
 }

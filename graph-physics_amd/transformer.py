@@ -16,6 +16,7 @@ prologue, activation / gated product / bias / residual as epilogue, concatenated
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -140,8 +141,10 @@ class _StackRows(torch.autograd.Function):
 
 class PackedAttentionFn(torch.autograd.Function):
     """Sparse attention over q | k | v held as column slabs of ONE [N, 3H] projection output (mgn_sparse_attn_fwd_s / _bwd_s): no
-    copies out of it, and dq | dk | dv written as slabs of its gradient.  ``b16``: bf16 matrix mode (k | v narrowed to bf16 rows in one
-    pass, the roundings inside the kernels -- the *_b16 semantic)."""
+    copies out of it, and dq | dk | dv written as slabs of its gradient.  ``b16``: bf16 matrix mode -- the *_b16 semantic (roundings of the
+    scaled query, y, dy, dq inside the kernels) on the k | v slabs AS THEY ARE: fp32 rows whose values are bf16 numbers, what a
+    bf16-mode projection writes (kv_bf16 = 2; MGN_ATTN_KV16=1: narrowed to two-byte rows first, kv_bf16 = 1, the round-4 form).  The
+    caller guarantees that k and v hold bf16-representable values in this mode."""
 
     @staticmethod
     def forward(ctx, qkv, topo: AttnTopology, num_heads: int, b16: bool):
@@ -149,34 +152,35 @@ class PackedAttentionFn(torch.autograd.Function):
         qkv = ops._f32c(qkv)
         N, H3 = qkv.shape
         H = H3 // 3
-        kv = qkv[:, H:].to(torch.bfloat16) if b16 else qkv[:, H:]         # [N, 2H]: k | v
+        mode = (1 if os.environ.get("MGN_ATTN_KV16") == "1" else 2) if b16 else 0
+        kv = qkv[:, H:].to(torch.bfloat16) if mode == 1 else qkv[:, H:]         # [N, 2H]: k | v
         es, ekv = qkv.element_size(), kv.element_size()
         y, lse = torch.empty(N, H, dtype=torch.float32, device=qkv.device), torch.empty(N, H, dtype=torch.float32, device=qkv.device)
         need_raw = b16 and ctx.needs_input_grad[0]
         y_raw = torch.empty_like(y) if need_raw else None
         with torch.cuda.device(qkv.device):
             rc = _capi.lib().mgn_sparse_attn_fwd_s(qkv.data_ptr(), H3, kv.data_ptr(), int(kv.stride(0)), kv.data_ptr() + H * ekv, int(kv.stride(0)),
-                                                   int(b16), topo.rowptr.data_ptr(), topo.col.data_ptr(), N, H, num_heads, y.data_ptr(),
+                                                   mode, topo.rowptr.data_ptr(), topo.col.data_ptr(), N, H, num_heads, y.data_ptr(),
                                                    lse.data_ptr(), y_raw.data_ptr() if need_raw else None, ops._stream(qkv.device))
         _capi.check(rc, "mgn_sparse_attn_fwd_s", attn=True)
-        ctx.save_for_backward(qkv, kv if b16 else qkv.new_empty(0), y_raw if need_raw else y, lse)
-        ctx.topo, ctx.num_heads, ctx.b16 = topo, num_heads, b16
+        ctx.save_for_backward(qkv, kv if mode == 1 else qkv.new_empty(0), y_raw if need_raw else y, lse)
+        ctx.topo, ctx.num_heads, ctx.b16 = topo, num_heads, mode
         return y
 
     @staticmethod
     def backward(ctx, dy):
         qkv, kv16, y, lse = ctx.saved_tensors
-        topo, nh, b16 = ctx.topo, ctx.num_heads, ctx.b16
+        topo, nh, mode = ctx.topo, ctx.num_heads, ctx.b16
         dy = ops._f32c(dy)
         N, H3 = qkv.shape
         H = H3 // 3
-        kv = kv16 if b16 else qkv[:, H:]
+        kv = kv16 if mode == 1 else qkv[:, H:]
         ekv = kv.element_size()
         d = torch.empty_like(qkv)
-        ws = torch.empty(max(2 * topo.E * nh + (N * H if b16 else 0), 1), dtype=torch.float32, device=qkv.device)
+        ws = torch.empty(max(2 * topo.E * nh + (N * H if mode == 1 else 0), 1), dtype=torch.float32, device=qkv.device)
         with torch.cuda.device(qkv.device):
             rc = _capi.lib().mgn_sparse_attn_bwd_s(qkv.data_ptr(), H3, kv.data_ptr(), int(kv.stride(0)), kv.data_ptr() + H * ekv, int(kv.stride(0)),
-                                                   int(b16), y.data_ptr(), lse.data_ptr(), dy.data_ptr(), topo.rowptr.data_ptr(),
+                                                   mode, y.data_ptr(), lse.data_ptr(), dy.data_ptr(), topo.rowptr.data_ptr(),
                                                    topo.col.data_ptr(), topo.cptr.data_ptr(), topo.cperm.data_ptr(), topo.crow.data_ptr(),
                                                    N, topo.E, H, nh, d.data_ptr(), H3, d.data_ptr() + 4 * H, H3, d.data_ptr() + 8 * H, H3,
                                                    ws.data_ptr(), ws.numel() * 4, ops._stream(qkv.device))

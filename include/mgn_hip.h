@@ -564,7 +564,9 @@ int mgn_sparse_attn_bwd_b16(const float* q, const uint16_t* k16, const uint16_t*
 /* Strided forms of both pairs ([r4]): q / k / v are column slabs of ONE [N, 3H] projection output (Attention's three Linears,
  * layers.py:606-616,668-671, issued as a single launch over the concatenated weights) -- ldq / ldk / ldv are the row pitches in
  * elements (multiples of 4, >= H; of the uint16 rows when kv_bf16) -- and dq / dk / dv slabs of that output's gradient, so neither
- * side needs a copy or a concatenation.  kv_bf16 != 0: the *_b16 semantic (k, v bf16 rows; y_raw as there).  y, lse, dy dense. */
+ * side needs a copy or a concatenation.  kv_bf16 = 1: the *_b16 semantic (k, v bf16 rows; y_raw as there); kv_bf16 = 2: the same
+ * roundings with k, v left as fp32 rows holding bf16-representable values (the slabs of a bf16-mode projection as they are).
+ * y, lse, dy dense. */
 int mgn_sparse_attn_fwd_s(const float* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int kv_bf16,
                           const int32_t* rowptr, const int32_t* col, int64_t N, int H, int num_heads, float* y, float* lse,
                           float* y_raw, void* stream);

@@ -261,3 +261,33 @@ def test_gated_mlp_block_on_the_six_term_launches_vs_oracle(dev, mode):
         assert rel_err(y.detach().cpu(), ref[True][0]) < 0.5 * gap + 1e-3
         for k in got:
             assert rms_err(got[k].cpu(), ref[True][1][k]) < max(1.5 * rms_err(ref[True][1][k], ref[False][1][k]), 2e-2), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,nh", [(64, 4), (128, 4), (32, 2), (16, 4), (64, 16)])
+def test_packed_attention_bf16_semantic_on_fp32_rows_equals_the_two_byte_form(dev, monkeypatch, H, nh):
+    """mgn_sparse_attn_fwd_s / _bwd_s with kv_bf16 = 2 (round 5's default in bf16 mode: the *_b16 roundings on the k | v slabs of a
+    bf16-mode projection as they are -- fp32 rows holding bf16 numbers) against kv_bf16 = 1 (the slabs narrowed to two-byte rows first,
+    the form test_sparse_attention_b16_entry_points_equal_the_fp32_kernels_around_explicit_roundings pins to the fp32 kernels): the
+    same arithmetic on the same values.  Four heads also cover the quad-distributed softmax state (Q4) against MGN_ATTN_Q4's
+    every-lane form through the oracle-side tests of tests/test_transformer.py."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import recipe as R
+    from graph_physics_amd import transformer as T
+    N, E, seed = 700, 6000, 11 + H + nh
+    ei = R.random_graph(N, E, seed).to(dev)
+    topo = T.AttnTopology(ei, N)
+    qkv0 = R.randn((N, 3 * H), seed + 1)
+    qkv0[:, H:] = qkv0[:, H:].bfloat16().float()      # k | v as a bf16-mode projection leaves them
+    cot = R.randn((N, H), seed + 2).to(dev)
+    outs = {}
+    for kv16 in ("1", "0"):
+        monkeypatch.setenv("MGN_ATTN_KV16", kv16)
+        qkv = qkv0.clone().to(dev).requires_grad_(True)
+        y = T.PackedAttentionFn.apply(qkv, topo, nh, True)
+        (y * cot).sum().backward()
+        outs[kv16] = (y.detach(), qkv.grad.detach())
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    # dq, dk, dv: the column pass reads bf16(q / sd), bf16(dy) either from the row pass's two-byte copies or re-rounds the fp32 rows
+    assert rel_err(outs["0"][1], outs["1"][1]) < 1e-6
