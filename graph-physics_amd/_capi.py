@@ -153,12 +153,13 @@ class LinearArgs(C.Structure):
         ("norm_scale", _f32p), ("eps", C.c_float), ("inv_out", _f32p), ("n_out", _f32p), ("W", _f32p), ("ldw", C.c_int), ("b", _f32p),
         ("W2", _f32p), ("b2", _f32p), ("act", C.c_int), ("N", C.c_int), ("resid", _f32p), ("ldr", C.c_int), ("out", _f32p),
         ("ldo", C.c_int), ("saveZ1", _f32p), ("saveZ2", _f32p), ("precision", C.c_int), ("w_transposed", C.c_int),
+        ("gb_z1", _f32p), ("gb_z2", _f32p), ("out2", _f32p), ("norm_scale_outer", _f32p), ("inv_outer_out", _f32p),
     ]
 
 
 class RownormPhase(C.Structure):
     """mgn_rownorm_phase (include/mgn_hip.h)"""
-    _fields_ = [("x", _f32p), ("ldx", C.c_int), ("K", C.c_int), ("idx", C.c_void_p), ("dx", _f32p), ("lddx", C.c_int)]
+    _fields_ = [("x", _f32p), ("ldx", C.c_int), ("K", C.c_int), ("idx", C.c_void_p), ("dx", _f32p), ("lddx", C.c_int), ("acc", _f32p)]
 
 
 class OptTensor(C.Structure):
@@ -242,6 +243,8 @@ SYMBOLS = {
     "mgn_attn_last_error": (C.c_char_p, []),
     "mgn_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "mgn_linear_accepts_transposed": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mgn_rownorm2_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_act_gate_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgn_rownorm_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgn_rownorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int]),
@@ -255,7 +258,7 @@ _lock = threading.Lock()
 
 #: ABI version this binding was written against (mgn_version() of the library must match: the
 #: ctypes structs above mirror exactly that header)
-EXPECTED_VERSION = 134
+EXPECTED_VERSION = 135
 HASH_PATH = os.path.join(_CSRC, "libmgn_hip.srchash")
 LOCK_PATH = os.path.join(_CSRC, ".build.lock")
 

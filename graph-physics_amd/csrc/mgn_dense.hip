@@ -393,6 +393,18 @@ __global__ void __launch_bounds__(512, (KB <= 12 ? 4 : 2)) k_linear_x6(const mgn
                  : (kb < kb2) ? *(const f32x4*)(a.x2 + r2 * a.ldx2 + 16 * (kb - kb1) + 4 * g)
                               : *(const f32x4*)(a.x3 + r3 * a.ldx3 + 16 * (kb - kb2) + 4 * g);
     }
+    if (a.norm_scale_outer != nullptr) {  // a norm in front of the norm prologue: the same formula on the raw row first
+      float ss = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss = fmaf(in[kb][r], in[kb][r], ss);
+      ss = rowsum4d(ss);
+      const float inv = 1.0f / (sqrtf(ss) / sqrtf((float)K) + a.eps);
+      if (a.inv_outer_out != nullptr && valid && g == 0 && ob0 == 0) a.inv_outer_out[mm] = inv;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) in[kb] = *(const f32x4*)(a.norm_scale_outer + 16 * kb + 4 * g) * (in[kb] * inv);
+    }
     if (a.norm_scale != nullptr) {  // RMSNorm prologue (as k_linear)
       float ss = 0.f;
 #pragma unroll
@@ -459,6 +471,23 @@ __global__ void __launch_bounds__(512, (KB <= 12 ? 4 : 2)) k_linear_x6(const mgn
       if (valid) {
         if (a.saveZ1 != nullptr) *(f32x4*)(a.saveZ1 + mm * a.N + n0) = acc;
         if (GATE && a.saveZ2 != nullptr) *(f32x4*)(a.saveZ2 + mm * a.N + n0) = acc2;
+      }
+      if (!GATE && a.gb_z1 != nullptr) {   // the gated product's backward as the epilogue (mgn_act_gate_bwd on the accumulator)
+        const f32x4 z1 = *(const f32x4*)(a.gb_z1 + mm * a.N + n0), z2 = *(const f32x4*)(a.gb_z2 + mm * a.N + n0);
+        f32x4 a1, a2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float h = d_act(z1[r], a.act);
+          if (BF) h = bf16r(h);
+          a1[r] = acc[r] * z2[r] * d_dact(z1[r], a.act);
+          a2[r] = acc[r] * h;
+        }
+        if (BF) a1 = bf16r4(a1), a2 = bf16r4(a2);
+        if (valid) {
+          *(f32x4*)(a.out + mm * a.ldo + n0) = a1;
+          *(f32x4*)(a.out2 + mm * a.ldo + n0) = a2;
+        }
+        continue;
       }
       f32x4 y;
 #pragma unroll
@@ -556,7 +585,7 @@ static int launch_linear(const mgn_linear_args& a, hipStream_t s) {
       return launch_linear_x6<KB>(a, grid, imgx, nc, s);
     }
   }
-  if (a.w_transposed) return 3;
+  if (a.w_transposed || a.gb_z1 != nullptr || a.norm_scale_outer != nullptr) return 3;
   int nchunk = 1;
   while (nchunk < 4 && (full / nchunk > 64 * 1024 || NB % nchunk != 0)) ++nchunk;
   if (nchunk > 1 && getenv("MGN_LINEAR_NO_CHUNK") != nullptr) nchunk = 4;
@@ -584,6 +613,11 @@ extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
       (a.resid != nullptr && (a.ldr < a.N || (a.ldr & 3))))
     return dfail(1, "mgn_linear_fwd: leading dimensions must cover the widths and keep rows 16-byte aligned");
   if (a.act < -1 || a.act > MGN_ACT_GELU) return dfail(1, "mgn_linear_fwd: act must be MGN_ACT_NONE, _RELU, _SILU or _GELU");
+  if (a.norm_scale_outer != nullptr && (a.norm_scale == nullptr || a.K2 > 0 || a.idx != nullptr))
+    return dfail(1, "mgn_linear_fwd: norm_scale_outer needs norm_scale and a single ungathered input phase");
+  if (a.gb_z1 != nullptr && (a.gb_z2 == nullptr || a.out2 == nullptr || a.W2 != nullptr || a.b != nullptr || a.resid != nullptr || a.saveZ1 != nullptr ||
+                             a.ldo != a.N))
+    return dfail(1, "mgn_linear_fwd: the gated-backward epilogue takes gb_z1, gb_z2, out2, dense outputs, no W2 / bias / residual / saves");
   if (a.precision != 0 && a.precision != 1) return dfail(1, "mgn_linear_fwd: precision must be 0 or 1");
   if (a.M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -591,7 +625,7 @@ extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
 #define LIN_CASE(KB_)                                                                                                                \
   case KB_: {                                                                                                                        \
     const int rc_ = launch_linear<KB_>(a, s);                                                                                        \
-    if (rc_ == 3) return dfail(1, "mgn_linear_fwd: a transposed weight needs the LDS-staged form (mgn_linear_accepts_transposed)");  \
+    if (rc_ == 3) return dfail(1, "mgn_linear_fwd: a transposed weight / the gated-backward epilogue / an outer norm need the LDS-staged form (mgn_linear_accepts_transposed)");  \
     if (rc_) return dfail(2, "mgn_linear_fwd: cannot reserve LDS");                                                                  \
   } break;
     LIN_CASE(1) LIN_CASE(2) LIN_CASE(3) LIN_CASE(4) LIN_CASE(6) LIN_CASE(8) LIN_CASE(12) LIN_CASE(16) LIN_CASE(24)
@@ -685,6 +719,7 @@ struct RnPhases {
   int ld[3];
   float* dx[3];
   int lddx[3];
+  const float* acc[3];
   int k0[4];   // first column of each phase, k0[3] = K
 };
 template <int KPL>  // columns per lane (K / 64 rounded up)
@@ -737,9 +772,12 @@ __global__ void __launch_bounds__(256) k_rownorm_bwd(const float* __restrict__ d
       if (k < K) {
         const int p = ph[j];
         float* dp = (p == 0) ? P.dx[0] : (p == 1) ? P.dx[1] : P.dx[2];
+        const float* ap = (p == 0) ? P.acc[0] : (p == 1) ? P.acc[1] : P.acc[2];
         const int ldd = (p == 0) ? P.lddx[0] : (p == 1) ? P.lddx[1] : P.lddx[2];
         const int k0p = (p == 0) ? P.k0[0] : (p == 1) ? P.k0[1] : P.k0[2];
-        dp[m * ldd + (k - k0p)] = c * gv[j] - xv[j] * k2;   // per EDGE row: the caller sums gathered phases over their segments
+        float v = c * gv[j] - xv[j] * k2;   // per EDGE row: the caller sums gathered phases over their segments
+        if (ap != nullptr) v = ap[m * ldd + (k - k0p)] + v;
+        dp[m * ldd + (k - k0p)] = v;
       }
     }
   }
@@ -748,6 +786,72 @@ __global__ void __launch_bounds__(256) k_rownorm_bwd(const float* __restrict__ d
   for (int j = 0; j < KPL; ++j) red[wv][lane + 64 * j] = ds[j];
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += 256) part[(size_t)blockIdx.x * K + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+}
+// [r5] two stacked RMSNorms (n = s_i * h c_i, h = s_o * x c_o) backward in one pass over the rows: h is recomputed from x (never stored),
+// dx = acc + ..., partial column sums of both scale gradients side by side ([ds_inner | ds_outer], 2 K columns per workgroup)
+template <int KPL>
+__global__ void __launch_bounds__(256) k_rownorm2_bwd(const float* __restrict__ dn, const float* __restrict__ x, int ldx, int K,
+                                                     const float* __restrict__ inv_o, const float* __restrict__ sc_o, const float* __restrict__ inv_i,
+                                                     const float* __restrict__ sc_i, float eps, long M, const float* __restrict__ acc,
+                                                     float* __restrict__ dx, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float dsi[KPL], dso[KPL], so[KPL], si[KPL];
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) {
+    const int k = lane + 64 * j;
+    dsi[j] = dso[j] = 0.f;
+    so[j] = (k < K) ? sc_o[k] : 0.f;
+    si[j] = (k < K) ? sc_i[k] : 0.f;
+  }
+  for (long m = (long)blockIdx.x * 4 + wv; m < M; m += (long)gridDim.x * 4) {
+    float xv[KPL], hv[KPL], g0[KPL], av[KPL];
+    const float co = inv_o[m], ci = inv_i[m];
+    float dot0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const int k = lane + 64 * j;
+      xv[j] = hv[j] = g0[j] = av[j] = 0.f;
+      if (k < K) {
+        xv[j] = x[m * ldx + k];
+        const float d = dn[m * K + k];
+        if (acc != nullptr) av[j] = acc[m * K + k];
+        hv[j] = so[j] * (xv[j] * co);
+        dsi[j] += d * hv[j] * ci;
+        g0[j] = si[j] * d;
+        dot0 = fmaf(g0[j], hv[j], dot0);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot0 += __shfl_xor(dot0, o);
+    const float r0 = 1.0f / ci - eps;
+    const float k0 = (r0 > 0.f) ? ci * ci * dot0 / ((float)K * r0) : 0.f;
+    float g2[KPL];
+    float dot2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const float dh = ci * g0[j] - hv[j] * k0;
+      dso[j] += dh * xv[j] * co;
+      g2[j] = so[j] * dh;
+      dot2 = fmaf(g2[j], xv[j], dot2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot2 += __shfl_xor(dot2, o);
+    const float r2 = 1.0f / co - eps;
+    const float k2 = (r2 > 0.f) ? co * co * dot2 / ((float)K * r2) : 0.f;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const int k = lane + 64 * j;
+      if (k < K) dx[m * K + k] = av[j] + (co * g2[j] - xv[j] * k2);
+    }
+  }
+  __shared__ float red[4][128 * KPL];
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) red[wv][lane + 64 * j] = dsi[j], red[wv][64 * KPL + lane + 64 * j] = dso[j];
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * K; k += 256) {
+    const int q = (k < K) ? k : 64 * KPL + (k - K);
+    part[(size_t)blockIdx.x * 2 * K + k] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+  }
 }
 // column sums of the workgroups' partials: 64 columns per block, 4 slices of the partial list per column, combined in a fixed
 // order (deterministic)
@@ -790,6 +894,7 @@ extern "C" int mgn_rownorm_bwd(const float* dn, const mgn_rownorm_phase* phases,
     P.ld[p] = on ? phases[p].ldx : 0;
     P.dx[p] = on ? phases[p].dx : phases[0].dx;
     P.lddx[p] = on ? phases[p].lddx : 0;
+    P.acc[p] = on ? phases[p].acc : nullptr;
     P.k0[p] = K;
     K += on ? phases[p].K : 0;
   }
@@ -818,4 +923,41 @@ extern "C" int mgn_rownorm_bwd(const float* dn, const mgn_rownorm_phase* phases,
     hipLaunchKernelGGL(k_colsum_parts, dim3(kb_, 1), dim3(256), 0, s, (const float*)part, (int)grid, (int)grid, K, dscale);
   }
   return dcheck("mgn_rownorm_bwd");
+}
+
+extern "C" int mgn_rownorm2_bwd(const float* dn, const float* x, int ldx, int K, const float* inv_outer, const float* scale_outer,
+                                const float* inv_inner, const float* scale_inner, float eps, int64_t M, const float* acc, float* dx,
+                                float* dscale_io, void* ws, size_t ws_bytes, void* stream) {
+  if (M < 0 || dn == nullptr || x == nullptr || inv_outer == nullptr || scale_outer == nullptr || inv_inner == nullptr || scale_inner == nullptr ||
+      dx == nullptr || dscale_io == nullptr || K < 1 || K > 192 || ldx < K)
+    return dfail(1, "mgn_rownorm2_bwd: bad arguments (at most 192 columns)");
+  if (ws == nullptr || ws_bytes < mgn_rownorm_bwd_workspace_bytes(2 * K)) return dfail(1, "mgn_rownorm2_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned grid = (unsigned)((M + 15) / 16);
+  if (grid > RN_GRID) grid = RN_GRID;
+  if (grid == 0) grid = 1;
+  float* part = (float*)ws;
+  float* both = dscale_io;   // [ds_inner | ds_outer]
+  if (M == 0) {
+    hipMemsetAsync(dscale_io, 0, (size_t)2 * K * sizeof(float), s);
+    return dcheck("mgn_rownorm2_bwd");
+  }
+  switch ((K + 63) / 64) {
+#define RN2_CASE(P_) \
+  case P_: hipLaunchKernelGGL(k_rownorm2_bwd<P_>, dim3(grid), dim3(256), 0, s, dn, x, ldx, K, inv_outer, scale_outer, inv_inner, scale_inner, eps, (long)M, acc, dx, part); break;
+    RN2_CASE(1) RN2_CASE(2) RN2_CASE(3)
+#undef RN2_CASE
+    default: return dfail(1, "mgn_rownorm2_bwd: width out of range");
+  }
+  const int K2 = 2 * K;
+  const unsigned kb_ = (unsigned)((K2 + 63) / 64);
+  if (grid > RN_CHUNK) {
+    const unsigned nch = (grid + RN_CHUNK - 1) / RN_CHUNK;
+    float* part2 = part + (size_t)RN_GRID * K2;
+    hipLaunchKernelGGL(k_colsum_parts, dim3(kb_, nch), dim3(256), 0, s, (const float*)part, (int)grid, RN_CHUNK, K2, part2);
+    hipLaunchKernelGGL(k_colsum_parts, dim3(kb_, 1), dim3(256), 0, s, (const float*)part2, (int)nch, (int)nch, K2, both);
+  } else {
+    hipLaunchKernelGGL(k_colsum_parts, dim3(kb_, 1), dim3(256), 0, s, (const float*)part, (int)grid, (int)grid, K2, both);
+  }
+  return dcheck("mgn_rownorm2_bwd");
 }

@@ -2440,7 +2440,7 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
 
 extern "C" {
 
-int mgn_version(void) { return 134; }
+int mgn_version(void) { return 135; }
 const char* mgn_last_error(void) { return g_err; }
 
 size_t mgn_csr_workspace_bytes(int64_t E, int64_t N) {

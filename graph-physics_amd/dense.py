@@ -24,7 +24,7 @@ def _prec() -> int:
 
 def linear_launch(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act: int = ACT_NONE, resid=None, out=None, inv_out=None,
                   n_out=None, saveZ1=None, saveZ2=None, precision: int = 0, x3=None, idx=(None, None, None), M: Optional[int] = None,
-                  w_transposed: bool = False):
+                  w_transposed: bool = False, gate_bwd=None, norm_outer=None):
     """one ``mgn_linear_fwd`` launch (include/mgn_hip.h); x / x2 / x3 / resid may be row-strided views (stride(1) == 1);
     ``idx[p]`` (int32 [M]) gathers the rows of phase p; ``M`` = output rows (default: rows of x); ``w_transposed``: W (and W2) are
     [K, N] -- the launch multiplies by their transpose (see :func:`input_gradient`)."""
@@ -49,6 +49,10 @@ def linear_launch(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act:
     a.out, a.ldo = out.data_ptr(), int(out.stride(0))
     a.saveZ1, a.saveZ2, a.precision = ops._ptr(saveZ1), ops._ptr(saveZ2), precision
     a.w_transposed = 1 if w_transposed else 0
+    if norm_outer is not None:   # (scale, inv_out or None): a second RMSNorm in front of the norm prologue
+        a.norm_scale_outer, a.inv_outer_out = norm_outer[0].data_ptr(), ops._ptr(norm_outer[1])
+    if gate_bwd is not None:   # (Z1, Z2, out2): the gated product's backward as the epilogue -- out = dZ1, out2 = dZ2
+        a.gb_z1, a.gb_z2, a.out2 = gate_bwd[0].data_ptr(), gate_bwd[1].data_ptr(), gate_bwd[2].data_ptr()
     with torch.cuda.device(x.device):
         rc = _capi.lib().mgn_linear_fwd(C.byref(a), ops._stream(x.device))
     _capi.check(rc, "mgn_linear_fwd", dense=True)
@@ -227,6 +231,109 @@ def dense(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act: Optiona
         return DenseFn.apply(x, x2, x3, W, b, W2, b2, norm_scale, resid, ACT_IDS[act], _prec(), gather)
     finally:
         ops._call.grad = True
+
+
+def _wgrad_jobs(dZ, n, dW, db):
+    """64-column slab jobs of dW [N, K] = dZ^T n (+ db), as DenseFn.backward cuts them"""
+    N, K = dW.shape
+    slab = 64 if (N <= 64 or K <= 64) else 128
+    jobs = []
+    for j0 in range(0, N, slab):
+        nj = min(slab, N - j0)
+        first = True
+        for k0 in range(0, K, slab):
+            nk = min(slab, K - k0)
+            job = (dZ[:, j0:j0 + nj], int(dZ.stride(0)), nj // 16, n[:, k0:k0 + nk], int(n.stride(0)), nk // 16, nk, dW, j0 * K + k0, K)
+            if first and db is not None:
+                job = job + (db[j0:j0 + nj],)
+            first = False
+            jobs.append(job)
+    return jobs
+
+
+class GatedMlpResidualFn(torch.autograd.Function):
+    """x + W3 (act(W1 n + b1) * (W2 n + b2)) + b3,  n = RMSNorm(RMSNorm(x; s_outer); s_inner) -- the second half of a Transformer block
+    (layers.py:700-819: x + gated_mlp(norm2(x)), build_gated_mlp starting with a norm of its own, :256-278) as ONE autograd node on the
+    launches of this module, so that its backward can keep what separate nodes hand each other through HBM:
+      * dP = dY W3 never exists: the launch that forms it applies the gated product's backward in its epilogue and writes dZ1 / dZ2
+        (``gate_bwd`` of :func:`linear_launch`; mgn_act_gate_bwd read and wrote five [M, 3K] matrices for it);
+      * both norms are the prologue of the gated launch (norm2's output is never stored) and one backward pass (mgn_rownorm2_bwd);
+      * the residual's gradient is the accumulator input of that pass (no autograd add).
+    Taken by :class:`transformer.Transformer` where the LDS-staged launches apply (mgn_linear_accepts_transposed: 65 536 rows or more);
+    elsewhere the block stays on :func:`dense` / :func:`rms_norm`."""
+
+    @staticmethod
+    def usable(x, W1, W3, precision: int) -> bool:
+        M, K = int(x.shape[0]), int(x.shape[1])
+        N = int(W1.shape[0])
+        L = _capi.lib()
+        return bool(x.is_cuda and _FUSED_MLP[0] and K <= 192 and L.mgn_linear_accepts_transposed(M, N, K, 0, precision)
+                    and L.mgn_linear_accepts_transposed(M, K, N, 1, precision))
+
+    @staticmethod
+    def forward(ctx, x, s_outer, s_inner, W1, b1, W2, b2, W3, b3, act: int, precision: int):
+        ops._require_device(x, s_outer, s_inner, W1, b1, W2, b2, W3, b3)
+        x = _rows(x)
+        W1, W2, W3 = ops._f32c(W1), ops._f32c(W2), ops._f32c(W3)
+        M, K = x.shape
+        N = W1.shape[0]
+        dev = x.device
+        f = dict(dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad) and ops._saving()
+        Z1 = torch.empty(M, N, **f) if need else None
+        Z2 = torch.empty(M, N, **f) if need else None
+        inv_o = torch.empty(M, **f) if need else None
+        inv_i = torch.empty(M, **f) if need else None
+        n = torch.empty(M, K, **f) if need else None
+        # both norms are the prologue of the gated launch (the outer one's output is never stored)
+        p_ = linear_launch(x, W1, b1, W2=W2, b2=b2, norm_scale=s_inner, act=act, inv_out=inv_i, n_out=n, saveZ1=Z1, saveZ2=Z2, precision=precision,
+                           norm_outer=(s_outer, inv_o))
+        out = linear_launch(p_, W3, b3, resid=x, precision=precision)
+        if need:
+            ctx.save_for_backward(x, s_outer, s_inner, W1, W2, W3)
+            ctx.aux = (act, precision, inv_o, inv_i, n, Z1, Z2, p_, b1 is not None, b2 is not None, b3 is not None)
+        else:
+            ctx.aux = None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.aux is None:
+            raise RuntimeError("GatedMlpResidualFn: no saved activations (the forward ran under no_grad, or backward ran twice)")
+        x, s_outer, s_inner, W1, W2, W3 = ctx.saved_tensors
+        act, prec, inv_o, inv_i, n, Z1, Z2, p_, has_b1, has_b2, has_b3 = ctx.aux
+        ctx.aux = None
+        dy = ops._f32c(dy)
+        M, K = x.shape
+        N = W1.shape[0]
+        dev = dy.device
+        f = dict(dtype=torch.float32, device=dev)
+        L = _capi.lib()
+        # W3: weight gradient from (dy, p_); its input gradient goes straight through the gated product's backward
+        dW3, db3 = torch.empty(K, N, **f), (torch.empty(K, **f) if has_b3 else None)
+        ops.wgrad(_wgrad_jobs(dy, p_, dW3, db3), dev, prec)
+        dZ1, dZ2 = torch.empty(M, N, **f), torch.empty(M, N, **f)
+        linear_launch(dy, W3, out=dZ1, precision=prec, w_transposed=True, act=act, gate_bwd=(Z1, Z2, dZ2))
+        dn = input_gradient(dZ1, W1, precision=prec)
+        dn = input_gradient(dZ2, W2, resid=dn, precision=prec)
+        dW1, db1 = torch.empty(N, K, **f), (torch.empty(N, **f) if has_b1 else None)
+        dW2, db2 = torch.empty(N, K, **f), (torch.empty(N, **f) if has_b2 else None)
+        ops.wgrad(_wgrad_jobs(dZ1, n, dW1, db1) + _wgrad_jobs(dZ2, n, dW2, db2), dev, prec)
+
+        # both norms backward in one pass; dx = dy (the residual) + the norm path
+        dx, ds_io = torch.empty(M, K, **f), torch.empty(2 * K, **f)
+        ws = torch.empty(max(L.mgn_rownorm_bwd_workspace_bytes(2 * K), 16), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.mgn_rownorm2_bwd(dn.data_ptr(), x.data_ptr(), int(x.stride(0)), K, inv_o.data_ptr(), s_outer.data_ptr(), inv_i.data_ptr(),
+                                    s_inner.data_ptr(), ops.EPS, M, dy.data_ptr(), dx.data_ptr(), ds_io.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    ops._stream(dev))
+        _capi.check(rc, "mgn_rownorm2_bwd", dense=True)
+        ds_inner, ds_outer = ds_io[:K], ds_io[K:]
+        return dx, ds_outer, ds_inner, dW1, db1, dW2, db2, dW3, db3, None, None
+
+
+#: MGN_FUSED_MLP=0: Transformer blocks keep the gated-MLP half on separate autograd nodes (A/B)
+_FUSED_MLP = [os.environ.get("MGN_FUSED_MLP", "1") != "0"]
 
 
 class SigmoidGateFn(torch.autograd.Function):

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _capi, ops
-from .dense import SigmoidGateFn, dense, rms_norm
+from .dense import ACT_IDS, GatedMlpResidualFn, SigmoidGateFn, dense, rms_norm
 from .gated import build_gated_mlp
 from .layers import RMSNorm, build_mlp
 
@@ -335,9 +335,20 @@ class Transformer(nn.Module):
         # x + gated_mlp(norm2(x)); build_gated_mlp starts with a norm of its own (layers.py:256-278), so norm2 is a launch of
         # its own and the inner one the prologue of the two gate Linears
         gm = self.gated_mlp
+        act = "silu" if isinstance(gm[1].activation, nn.SiLU) else "gelu"
+        prec = 1 if ops.get_matrix_precision() == "bf16" else 0
+        if GatedMlpResidualFn.usable(x, gm[1].linear1.weight, gm[2].weight, prec):
+            # large meshes: the whole half as one autograd node (dense.GatedMlpResidualFn: the gated product's backward as the epilogue of
+            # the launch that forms its incoming gradient, the residual's gradient added inside the last norm backward)
+            ops._call.grad = torch.is_grad_enabled()
+            try:
+                x = GatedMlpResidualFn.apply(x, self.norm2.scale, gm[0].scale, gm[1].linear1.weight, gm[1].linear1.bias, gm[1].linear2.weight,
+                                             gm[1].linear2.bias, gm[2].weight, gm[2].bias, ACT_IDS[act], prec)
+            finally:
+                ops._call.grad = True
+            return (x, attn) if return_attention else x
         h = rms_norm(x, self.norm2.scale)
-        p_ = dense(h, gm[1].linear1.weight, gm[1].linear1.bias, W2=gm[1].linear2.weight, b2=gm[1].linear2.bias, norm_scale=gm[0].scale,
-                   act=("silu" if isinstance(gm[1].activation, nn.SiLU) else "gelu"))
+        p_ = dense(h, gm[1].linear1.weight, gm[1].linear1.bias, W2=gm[1].linear2.weight, b2=gm[1].linear2.bias, norm_scale=gm[0].scale, act=act)
         x = dense(p_, gm[2].weight, gm[2].bias, resid=x)
         return (x, attn) if return_attention else x
 

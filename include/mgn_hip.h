@@ -624,6 +624,18 @@ typedef struct {
   int w_transposed;   /* W (and W2) are [K, ldw] row-major, ldw >= N: the launch multiplies by their TRANSPOSE -- the input gradient
                          dX = dZ W of a Linear straight from its nn.Linear weight.  Accepted where the weights are staged through LDS
                          (mgn_linear_accepts_transposed); elsewhere mgn_linear_fwd returns 1. */
+  /* [r5] gated-product BACKWARD as the epilogue (same shapes as w_transposed; W2, b, resid NULL): with P = n W^T the gradient of the
+   * gated product's output (P = dY W3 of the Linear behind a GatedMLP, layers.py:249-253,274-277), the launch writes
+   *   out = P * Z2 * act'(Z1)  (= dZ1)   and   out2 = P * act(Z1)  (= dZ2)      -- mgn_act_gate_bwd without materialising P;
+   * gb_z1 / gb_z2 [M, N] = the saved pre-activations, act = the product's activation.  NULL: off. */
+  const float* gb_z1;
+  const float* gb_z2;
+  float* out2;
+  /* [r5] a second RMSNorm in FRONT of the norm prologue (the Transformer block's norm2 before build_gated_mlp's own norm,
+   * layers.py:256-278,700-819): n = RMSNorm(RMSNorm(x; norm_scale_outer); norm_scale); inv_outer_out [M] optional.  Same shapes as
+   * w_transposed (the LDS-staged form); needs norm_scale. */
+  const float* norm_scale_outer;
+  float* inv_outer_out;
 } mgn_linear_args;
 int mgn_linear_fwd(const mgn_linear_args* args, void* stream);
 /* 1 when mgn_linear_fwd takes w_transposed for this shape (M rows, K = K1 + K2 + K3 inputs, N outputs, gated product or not) */
@@ -640,10 +652,18 @@ typedef struct {
   const float* x; int ldx; int K;
   const int32_t* idx;
   float* dx; int lddx;
+  const float* acc;   /* [r5] optional [M, lddx]: dx = acc + (the norm's input gradient) -- the gradient a residual connection carries
+                         past the norm, added here instead of by an autograd node of its own */
 } mgn_rownorm_phase;
 size_t mgn_rownorm_bwd_workspace_bytes(int K);
 int mgn_rownorm_bwd(const float* dn, const mgn_rownorm_phase* phases, int nphase, const float* inv, const float* scale, float eps,
                     int64_t M, float* dscale, void* ws, size_t ws_bytes, void* stream);
+/* [r5] backward of the two stacked RMSNorms above in one pass: from dn [M, K] (gradient of n), the raw rows x, both inv vectors and both
+ * scales: dx [M, K] = acc + d x (acc optional: the gradient a residual connection carries past the norms), dscale_io [2 K] = the inner
+ * scale's gradient followed by the outer one's (fixed summation order).  K <= 192.  ws: mgn_rownorm_bwd_workspace_bytes(2 K). */
+int mgn_rownorm2_bwd(const float* dn, const float* x, int ldx, int K, const float* inv_outer, const float* scale_outer,
+                     const float* inv_inner, const float* scale_inner, float eps, int64_t M, const float* acc, float* dx,
+                     float* dscale_io, void* ws, size_t ws_bytes, void* stream);
 const char* mgn_dense_last_error(void);
 
 #ifdef __cplusplus

@@ -207,12 +207,13 @@ def test_six_term_dense_launch_vs_fp64(dev, K, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_gated_mlp_block_on_the_six_term_launches_vs_oracle(dev, mode):
+def test_gated_mlp_block_on_the_six_term_launches_vs_oracle(dev, mode, fused):
     """x + gated_mlp(norm2(x)) of a Transformer block (layers.py:256-278, 700-819) at 70 001 rows -- every Linear on k_linear_x6
     (six terms in fp32 mode, its one-piece form in bf16 mode), the input gradients through the transposed staging -- forward and
     every gradient against the oracle's restatement (oracle.gated_mlp / rms_norm; bf16 mode: under oracle.bf16_mixed, judged like the
-    other bf16-mode tests on the tensor's scale)."""
+    other bf16-mode tests on the tensor's scale).  ``fused``: dense.GatedMlpResidualFn instead of the separate autograd nodes."""
     import graph_physics_amd as gp
     from graph_physics_amd import ops, transformer as T
     from oracle import mgn_oracle as O
@@ -229,10 +230,16 @@ def test_gated_mlp_block_on_the_six_term_launches_vs_oracle(dev, mode):
     act = "silu" if isinstance(gm[1].activation, torch.nn.SiLU) else "gelu"
     ops.set_matrix_precision(mode)
     try:
-        from graph_physics_amd.dense import dense, rms_norm
-        h = rms_norm(x, blk.norm2.scale)
-        p_ = dense(h, gm[1].linear1.weight, gm[1].linear1.bias, W2=gm[1].linear2.weight, b2=gm[1].linear2.bias, norm_scale=gm[0].scale, act=act)
-        y = dense(p_, gm[2].weight, gm[2].bias, resid=x)
+        from graph_physics_amd.dense import ACT_IDS, GatedMlpResidualFn, dense, rms_norm
+        if fused:   # the half as ONE autograd node (what Transformer.forward takes at this size): gated-backward epilogue, residual
+            # gradient accumulated inside the norm backward
+            assert GatedMlpResidualFn.usable(x, gm[1].linear1.weight, gm[2].weight, 1 if mode == "bf16" else 0)
+            y = GatedMlpResidualFn.apply(x, blk.norm2.scale, gm[0].scale, gm[1].linear1.weight, gm[1].linear1.bias, gm[1].linear2.weight,
+                                         gm[1].linear2.bias, gm[2].weight, gm[2].bias, ACT_IDS[act], 1 if mode == "bf16" else 0)
+        else:
+            h = rms_norm(x, blk.norm2.scale)
+            p_ = dense(h, gm[1].linear1.weight, gm[1].linear1.bias, W2=gm[1].linear2.weight, b2=gm[1].linear2.bias, norm_scale=gm[0].scale, act=act)
+            y = dense(p_, gm[2].weight, gm[2].bias, resid=x)
         (y * wgt).sum().backward()
     finally:
         ops.set_matrix_precision("fp32")
