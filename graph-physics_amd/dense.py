@@ -88,7 +88,7 @@ class DenseFn(torch.autograd.Function):
     its input gradient is the CSR segment sum over the same grouping (atomics-free, hub-safe)."""
 
     @staticmethod
-    def forward(ctx, x, x2, x3, W, b, W2, b2, norm_scale, resid, act: int, precision: int, gather):
+    def forward(ctx, x, x2, x3, W, b, W2, b2, norm_scale, resid, act: int, precision: int, gather, pass_x: bool = False):
         ops._require_device(x, x2, x3, W, b, W2, b2, norm_scale, resid)
         xs = [_rows(t) if t is not None else None for t in (x, x2, x3)]
         resid = _rows(resid) if resid is not None else None
@@ -111,12 +111,21 @@ class DenseFn(torch.autograd.Function):
         out = linear_launch(xs[0], W, b, xs[1], W2, b2, norm_scale, act, resid, None, inv, n_out, Z1, Z2, precision, xs[2], idx, M)
         ctx.save_for_backward(xs[0], xs[1], xs[2], W, W2, norm_scale)
         ctx.aux = (act, precision, Z1, Z2, inv, n_out, b is not None, b2 is not None, resid is not None, topo, by, idx, M)
+        ctx.pass_x = bool(pass_x)
+        if pass_x:
+            # (out, x): the SAME rows handed on (autograd makes the second output an alias of x).  A caller that feeds them into a later
+            # residual gets that residual's gradient delivered HERE, where the norm backward adds it in its own pass (acc) -- instead
+            # of autograd summing the two uses of x in a launch of its own.  Needs the norm prologue on an ungathered single phase.
+            if norm_scale is None or x2 is not None or any(g_ is not None for g_ in by):
+                raise ValueError("DenseFn: pass_x needs the norm prologue on one ungathered input phase")
+            return out, x
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_pass=None):
         if ctx.aux is None:
             raise RuntimeError("DenseFn: backward ran twice (the saved activations are released eagerly)")
+        d_pass = ops._f32c(d_pass) if (ctx.pass_x and d_pass is not None) else None
         x, x2, x3, W, W2, norm_scale = ctx.saved_tensors
         act, prec, Z1, Z2, inv, n_out, has_b, has_b2, has_res, topo, by, idx, M = ctx.aux
         if Z1 is None and (act != ACT_NONE or W2 is not None):
@@ -155,6 +164,8 @@ class DenseFn(torch.autograd.Function):
                 for p in range(nph):
                     arr[p].x, arr[p].ldx, arr[p].K, arr[p].idx = xs[p].data_ptr(), int(xs[p].stride(0)), Ks[p], ops._ptr(idx[p])
                     arr[p].dx, arr[p].lddx = rows[p].data_ptr(), Ks[p]
+                if d_pass is not None:   # the gradient of the rows handed on (pass_x): added inside the norm backward
+                    arr[0].acc = d_pass.data_ptr()
                 dscale = torch.empty(K, **f)
                 ws = torch.empty(max(L.mgn_rownorm_bwd_workspace_bytes(K), 16), dtype=torch.uint8, device=dev)
                 with torch.cuda.device(dev):
@@ -219,16 +230,20 @@ class DenseFn(torch.autograd.Function):
         if M > 0:
             ops.wgrad(jobs, dev, prec)
         ctx.aux = None
+        if d_pass is not None and M == 0:
+            dxs[0] = d_pass
         return (dxs[0] if want[0] else None, dxs[1] if want[1] else None, dxs[2] if want[2] else None, dW, db, dW2, db2,
-                dscale, dy if has_res else None, None, None, None)
+                dscale, dy if has_res else None, None, None, None, None)
 
 
-def dense(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act: Optional[str] = None, resid=None, x3=None, gather=None):
+def dense(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act: Optional[str] = None, resid=None, x3=None, gather=None,
+          pass_x: bool = False):
     """fused Linear on the engine (module docstring); ``act``: None / "relu" / "silu" / "gelu"; ``gather`` = (topology,
-    (by_1, by_2, by_3)) with by_p in ("dst", "src", None)."""
+    (by_1, by_2, by_3)) with by_p in ("dst", "src", None).  ``pass_x``: returns (out, x') with x' the input rows again -- use x' for a
+    later residual and its gradient is added inside this node's norm backward (see DenseFn.forward)."""
     ops._call.grad = torch.is_grad_enabled()
     try:
-        return DenseFn.apply(x, x2, x3, W, b, W2, b2, norm_scale, resid, ACT_IDS[act], _prec(), gather)
+        return DenseFn.apply(x, x2, x3, W, b, W2, b2, norm_scale, resid, ACT_IDS[act], _prec(), gather, pass_x)
     finally:
         ops._call.grad = True
 

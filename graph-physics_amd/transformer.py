@@ -282,6 +282,14 @@ class Attention(nn.Module):
             projs = (self.q_proj, self.k_proj, self.v_proj)
             Wc = _StackRows.apply(*(m.weight for m in projs))
             bc = _StackRows.apply(*(m.bias for m in projs)) if self.q_proj.bias is not None else None
+            if _resid is x and _norm_scale is not None and torch.is_grad_enabled() and x.requires_grad:
+                # the block's residual rides through the projection node: its gradient is added inside that node's norm backward
+                # (dense(pass_x=True)) instead of by an autograd add over the two uses of x
+                qkv, xr = dense(x, Wc, bc, norm_scale=_norm_scale, pass_x=True)
+                if self.use_gated_attention and self.gate_proj is not None:
+                    y = SigmoidGateFn.apply(PackedAttentionFn.apply(qkv, topo, self.num_heads, bf16), lin(self.gate_proj))
+                    return dense(y, self.proj.weight, self.proj.bias, resid=_resid)   # (x has a third use: the plain path)
+                return dense(PackedAttentionFn.apply(qkv, topo, self.num_heads, bf16), self.proj.weight, self.proj.bias, resid=xr)
             y = PackedAttentionFn.apply(dense(x, Wc, bc, norm_scale=_norm_scale), topo, self.num_heads, bf16)
             if self.use_gated_attention and self.gate_proj is not None:
                 y = SigmoidGateFn.apply(y, lin(self.gate_proj))
