@@ -298,3 +298,30 @@ def test_round5_host_logic_recompute_size_rollout_modes_and_bench_ceilings():
     assert any('("k_segsum2<8", None)' in ln for ln in src.splitlines())
     assert "k_segsum2<8, false>".startswith("k_segsum2<8") and not "k_segsum2<8, false>".startswith("k_segsum2<8>")
     assert '("k_wgrad_pc", 256)' in src
+
+
+def test_transformer_node_renumbering_switch_and_binding_layout():
+    """[r5] host side of the Transformer path's additions: the renumbering switch (ops.set_node_renumbering governs both model
+    families; positions must be on the device; auto starts at transformer.ATTN_RENUMBER_MIN_NODES), and the ctypes mirrors of the two
+    structs that grew this round end with the new fields in the header's order (a stale binding would shift every later argument)."""
+    from graph_physics_amd import _capi, ops, transformer as T
+
+    pos = torch.zeros(T.ATTN_RENUMBER_MIN_NODES, 3)
+    prev = ops.get_node_renumbering()
+    try:
+        for mode in ("off", "on", "auto"):
+            ops.set_node_renumbering(mode)
+            assert T.want_attn_renumbering(pos.shape[0], pos) is False          # CPU positions: never
+            assert T.want_attn_renumbering(pos.shape[0], None) is False
+    finally:
+        ops.set_node_renumbering(prev)
+    names = [f[0] for f in _capi.LinearArgs._fields_]
+    assert names[-7:] == ["precision", "w_transposed", "gb_z1", "gb_z2", "out2", "norm_scale_outer", "inv_outer_out"]
+    assert [f[0] for f in _capi.RownormPhase._fields_] == ["x", "ldx", "K", "idx", "dx", "lddx", "acc"]
+    import os
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mgn_hip.h")).read()
+    body = hdr[hdr.index("typedef struct {\n  int64_t M;\n  const float* x; int ldx; int K1;"):hdr.index("} mgn_linear_args;")]
+    order = [body.index(k) for k in ("int precision;", "int w_transposed;", "const float* gb_z1;", "const float* gb_z2;", "float* out2;",
+                                     "const float* norm_scale_outer;", "float* inv_outer_out;")]
+    assert order == sorted(order)
+    assert _capi.EXPECTED_VERSION == 135
