@@ -10,6 +10,7 @@ try:
     from graph_physics_amd import ops, _capi
     dev = torch.device("cuda:0")
     nb = int(os.environ.get("TL_BATCH", "16"))  # meshes in the batch (1: the single-tile latency regime)
+    PREC = int(os.environ.get("TL_PREC", "0"))   # 1: the one-term (bf16 matrix mode) instance, 2: with two-byte saves
     g = gp.cylinder_batch(nb, 1885, 0).to(dev)
     topo = ops.Topology(g.edge_index, g.x.shape[0])
     N, E, H = topo.N, topo.E, 128
@@ -47,10 +48,11 @@ try:
     for it in range(3):
         if node:
             ops.mlp_fwd(N, H, [(x, None, H), (agg, None, H)], [Wn0] + Wh, bs, sc, H, x, x_new, None, Hn, Un, Rn,
-                        posts=[(W0.data_ptr() + 4 * H, Pdn), (W0.data_ptr() + 8 * H, Psn)], post_ldw=3 * H, wpk=un)
+                        posts=[(W0.data_ptr() + 4 * H, Pdn), (W0.data_ptr() + 8 * H, Psn)], post_ldw=3 * H, wpk=un, precision=PREC)
         else:
             ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, None, He, Ue, Re, ldw0=3 * H,
-                        adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units, saveM=Me, seg=(topo.dst_s, topo.rowptr_dst, agg, part))
+                        adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units, saveM=Me, seg=(topo.dst_s, topo.rowptr_dst, agg, part),
+                        precision=PREC)
         torch.cuda.synchronize()
         L.mgn_debug_timeline(buf, pos)
     if hasattr(L, "mgn_debug_census"):
