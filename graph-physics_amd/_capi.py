@@ -153,7 +153,7 @@ class LinearArgs(C.Structure):
         ("norm_scale", _f32p), ("eps", C.c_float), ("inv_out", _f32p), ("n_out", _f32p), ("W", _f32p), ("ldw", C.c_int), ("b", _f32p),
         ("W2", _f32p), ("b2", _f32p), ("act", C.c_int), ("N", C.c_int), ("resid", _f32p), ("ldr", C.c_int), ("out", _f32p),
         ("ldo", C.c_int), ("saveZ1", _f32p), ("saveZ2", _f32p), ("precision", C.c_int), ("w_transposed", C.c_int),
-        ("gb_z1", _f32p), ("gb_z2", _f32p), ("out2", _f32p), ("norm_scale_outer", _f32p), ("inv_outer_out", _f32p),
+        ("gb_z1", _f32p), ("gb_z2", _f32p), ("out2", _f32p), ("norm_scale_outer", _f32p), ("inv_outer_out", _f32p), ("z16", C.c_int), ("x16", C.c_int), ("out16", C.c_int),
     ]
 
 
@@ -258,7 +258,7 @@ _lock = threading.Lock()
 
 #: ABI version this binding was written against (mgn_version() of the library must match: the
 #: ctypes structs above mirror exactly that header)
-EXPECTED_VERSION = 135
+EXPECTED_VERSION = 136
 HASH_PATH = os.path.join(_CSRC, "libmgn_hip.srchash")
 LOCK_PATH = os.path.join(_CSRC, ".build.lock")
 

@@ -63,6 +63,13 @@ __device__ __forceinline__ u32x4_d pack_bf16x8(const f32x4& lo, const f32x4& hi)
   o[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2_d));
   return o;
 }
+__device__ __forceinline__ uint2 pack_bf16x4(const f32x4& v) {   // exact for bf16-valued inputs (round to nearest even otherwise)
+  const f32x2_d a = {v[0], v[1]}, b = {v[2], v[3]};
+  return make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_d)), __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_d)));
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(uint2 t) {
+  return f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+}
 __device__ __forceinline__ float bf16r(float v) {
   float a, b;
   bf16r2(v, v, a, b);
@@ -318,7 +325,7 @@ __device__ __forceinline__ void split3_bf16x8(const f32x4& lo, const f32x4& hi, 
 // BF (precision 1, the reference under bf16-mixed): ONE piece = the operands rounded to bf16, bias / result / activation roundings
 // as in k_linear<.., BF = true>; the same 512-thread workgroup and image layout with a third of the bytes.
 // (second launch bound = waves per SIMD: two workgroups per CU -> at most 128 registers up to 192 inputs)
-template <int KB, bool GATE, bool BF>
+template <int KB, bool GATE, bool BF, bool X16 = false>
 __global__ void __launch_bounds__(512, (KB <= 12 ? 4 : 2)) k_linear_x6(const mgn_linear_args a, const int ob0, const int ob1) {
   static_assert(KB % 2 == 0, "K = 32 matrix steps");
   constexpr int S = KB / 2;               // K = 32 slices
@@ -382,8 +389,8 @@ __global__ void __launch_bounds__(512, (KB <= 12 ? 4 : 2)) k_linear_x6(const mgn
     const long m = (tile * 8 + wv) * 16 + c;
     const bool valid = m < a.M;
     const long mm = valid ? m : a.M - 1;
-    f32x4 in[KB];
-    {
+    f32x4 in[X16 ? 1 : KB];
+    if constexpr (!X16) {
       const long r1 = a.idx != nullptr ? (long)a.idx[mm] : mm;
       const long r2 = a.idx2 != nullptr ? (long)a.idx2[mm] : mm;
       const long r3 = a.idx3 != nullptr ? (long)a.idx3[mm] : mm;
@@ -393,6 +400,7 @@ __global__ void __launch_bounds__(512, (KB <= 12 ? 4 : 2)) k_linear_x6(const mgn
                  : (kb < kb2) ? *(const f32x4*)(a.x2 + r2 * a.ldx2 + 16 * (kb - kb1) + 4 * g)
                               : *(const f32x4*)(a.x3 + r3 * a.ldx3 + 16 * (kb - kb2) + 4 * g);
     }
+    if constexpr (!X16) {
     if (a.norm_scale_outer != nullptr) {  // a norm in front of the norm prologue: the same formula on the raw row first
       float ss = 0.f;
 #pragma unroll
@@ -421,11 +429,21 @@ __global__ void __launch_bounds__(512, (KB <= 12 ? 4 : 2)) k_linear_x6(const mgn
         for (int kb = 0; kb < KB; ++kb) *(f32x4*)(a.n_out + mm * K + 16 * kb + 4 * g) = in[kb];
       }
     }
+    }
     u32x4_d x1[S], x2[BF ? 1 : S], x3[BF ? 1 : S];
+    if constexpr (X16) {   // two-byte input rows: the packed operand of a K = 32 slice IS two 8-byte pieces of the row (blocks 2s, 2s + 1)
+      const uint16_t* xr = (const uint16_t*)a.x + mm * a.ldx + 4 * g;
+#pragma unroll
+      for (int s_ = 0; s_ < S; ++s_) {
+        const uint2 lo_ = *(const uint2*)(xr + 32 * s_), hi_ = *(const uint2*)(xr + 32 * s_ + 16);
+        x1[s_] = u32x4_d{lo_.x, lo_.y, hi_.x, hi_.y};
+      }
+    } else {
 #pragma unroll
     for (int s_ = 0; s_ < S; ++s_) {
-      if (BF) x1[s_] = pack_bf16x8(in[2 * s_], in[2 * s_ + 1]);
-      else split3_bf16x8(in[2 * s_], in[2 * s_ + 1], x1[s_], x2[BF ? 0 : s_], x3[BF ? 0 : s_]);
+      if (BF) x1[s_] = pack_bf16x8(in[X16 ? 0 : 2 * s_], in[X16 ? 0 : 2 * s_ + 1]);
+      else split3_bf16x8(in[X16 ? 0 : 2 * s_], in[X16 ? 0 : 2 * s_ + 1], x1[s_], x2[BF ? 0 : s_], x3[BF ? 0 : s_]);
+    }
     }
     for (int ob = ob0; ob < ob1; ++ob) {
       const int n0 = 16 * ob + 4 * g;
@@ -469,11 +487,22 @@ __global__ void __launch_bounds__(512, (KB <= 12 ? 4 : 2)) k_linear_x6(const mgn
       f32x4 acc = hi + lo, acc2 = hi2 + lo2;
       if (BF) acc = bf16r4(acc), acc2 = bf16r4(acc2);   // a bf16 nn.Linear returns bf16
       if (valid) {
-        if (a.saveZ1 != nullptr) *(f32x4*)(a.saveZ1 + mm * a.N + n0) = acc;
-        if (GATE && a.saveZ2 != nullptr) *(f32x4*)(a.saveZ2 + mm * a.N + n0) = acc2;
+        if (BF && a.z16) {   // two-byte rows: the values are bf16 numbers already
+          if (a.saveZ1 != nullptr) *(uint2*)((uint16_t*)a.saveZ1 + mm * a.N + n0) = pack_bf16x4(acc);
+          if (GATE && a.saveZ2 != nullptr) *(uint2*)((uint16_t*)a.saveZ2 + mm * a.N + n0) = pack_bf16x4(acc2);
+        } else {
+          if (a.saveZ1 != nullptr) *(f32x4*)(a.saveZ1 + mm * a.N + n0) = acc;
+          if (GATE && a.saveZ2 != nullptr) *(f32x4*)(a.saveZ2 + mm * a.N + n0) = acc2;
+        }
       }
       if (!GATE && a.gb_z1 != nullptr) {   // the gated product's backward as the epilogue (mgn_act_gate_bwd on the accumulator)
-        const f32x4 z1 = *(const f32x4*)(a.gb_z1 + mm * a.N + n0), z2 = *(const f32x4*)(a.gb_z2 + mm * a.N + n0);
+        f32x4 z1, z2;
+        if (BF && a.z16) {
+          z1 = unpack_bf16x4(*(const uint2*)((const uint16_t*)a.gb_z1 + mm * a.N + n0));
+          z2 = unpack_bf16x4(*(const uint2*)((const uint16_t*)a.gb_z2 + mm * a.N + n0));
+        } else {
+          z1 = *(const f32x4*)(a.gb_z1 + mm * a.N + n0), z2 = *(const f32x4*)(a.gb_z2 + mm * a.N + n0);
+        }
         f32x4 a1, a2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -484,8 +513,13 @@ __global__ void __launch_bounds__(512, (KB <= 12 ? 4 : 2)) k_linear_x6(const mgn
         }
         if (BF) a1 = bf16r4(a1), a2 = bf16r4(a2);
         if (valid) {
-          *(f32x4*)(a.out + mm * a.ldo + n0) = a1;
-          *(f32x4*)(a.out2 + mm * a.ldo + n0) = a2;
+          if (BF && a.out16) {
+            *(uint2*)((uint16_t*)a.out + mm * a.ldo + n0) = pack_bf16x4(a1);
+            *(uint2*)((uint16_t*)a.out2 + mm * a.ldo + n0) = pack_bf16x4(a2);
+          } else {
+            *(f32x4*)(a.out + mm * a.ldo + n0) = a1;
+            *(f32x4*)(a.out2 + mm * a.ldo + n0) = a2;
+          }
         }
         continue;
       }
@@ -498,7 +532,10 @@ __global__ void __launch_bounds__(512, (KB <= 12 ? 4 : 2)) k_linear_x6(const mgn
         if (BF) y = bf16r4(y);
       }
       if (a.resid != nullptr) y = *(const f32x4*)(a.resid + mm * a.ldr + n0) + y;
-      if (valid) *(f32x4*)(a.out + mm * a.ldo + n0) = y;
+      if (valid) {
+        if (BF && a.out16) *(uint2*)((uint16_t*)a.out + mm * a.ldo + n0) = pack_bf16x4(y);   // (a bf16 number: no residual here)
+        else *(f32x4*)(a.out + mm * a.ldo + n0) = y;
+      }
     }
   }
 }
@@ -532,6 +569,14 @@ static int launch_linear_x6(const mgn_linear_args& a, unsigned grid, size_t lds,
     for (int ch = 0; ch < nchunk; ++ch)                                                                                                      \
       hipLaunchKernelGGL((k_linear_x6<KB, GATE_, BF_>), dim3(grid), dim3(512), lds, s, a, ch * nbc, (ch + 1) * nbc);                         \
   } while (0)
+    if (bf && a.x16 && !gate) {   // two-byte input rows: an instance of its own (no fp32 row registers)
+      if (lds > 48 * 1024 &&
+          hipFuncSetAttribute((const void*)k_linear_x6<KB, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return 2;
+      for (int ch = 0; ch < nchunk; ++ch)
+        hipLaunchKernelGGL((k_linear_x6<KB, false, true, true>), dim3(grid), dim3(512), lds, s, a, ch * nbc, (ch + 1) * nbc);
+      return 0;
+    }
     if (gate && bf) LINX_GO(true, true);
     else if (gate) LINX_GO(true, false);
     else if (bf) LINX_GO(false, true);
@@ -585,7 +630,7 @@ static int launch_linear(const mgn_linear_args& a, hipStream_t s) {
       return launch_linear_x6<KB>(a, grid, imgx, nc, s);
     }
   }
-  if (a.w_transposed || a.gb_z1 != nullptr || a.norm_scale_outer != nullptr) return 3;
+  if (a.w_transposed || a.gb_z1 != nullptr || a.norm_scale_outer != nullptr || a.z16 || a.x16 || a.out16) return 3;
   int nchunk = 1;
   while (nchunk < 4 && (full / nchunk > 64 * 1024 || NB % nchunk != 0)) ++nchunk;
   if (nchunk > 1 && getenv("MGN_LINEAR_NO_CHUNK") != nullptr) nchunk = 4;
@@ -615,6 +660,10 @@ extern "C" int mgn_linear_fwd(const mgn_linear_args* args, void* stream) {
   if (a.act < -1 || a.act > MGN_ACT_GELU) return dfail(1, "mgn_linear_fwd: act must be MGN_ACT_NONE, _RELU, _SILU or _GELU");
   if (a.norm_scale_outer != nullptr && (a.norm_scale == nullptr || a.K2 > 0 || a.idx != nullptr))
     return dfail(1, "mgn_linear_fwd: norm_scale_outer needs norm_scale and a single ungathered input phase");
+  if ((a.z16 || a.x16 || a.out16) && a.precision != 1) return dfail(1, "mgn_linear_fwd: two-byte rows (z16 / x16 / out16) need precision 1");
+  if (a.x16 && (a.norm_scale != nullptr || a.K2 > 0 || a.idx != nullptr || a.W2 != nullptr))
+    return dfail(1, "mgn_linear_fwd: x16 takes one ungathered input phase without a norm prologue or a gated product");
+  if (a.out16 && a.resid != nullptr) return dfail(1, "mgn_linear_fwd: out16 has no residual epilogue");
   if (a.gb_z1 != nullptr && (a.gb_z2 == nullptr || a.out2 == nullptr || a.W2 != nullptr || a.b != nullptr || a.resid != nullptr || a.saveZ1 != nullptr ||
                              a.ldo != a.N))
     return dfail(1, "mgn_linear_fwd: the gated-backward epilogue takes gb_z1, gb_z2, out2, dense outputs, no W2 / bias / residual / saves");

@@ -1595,7 +1595,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
 // a lane's four rows (4g + r) are its four K values, the same assignment on both operands -- with the operands rounded to bf16 as
 // the reference's autocast Linear backward sees them: 16 matrix instructions per tile instead of 64 exact-fp32 ones.  (A K = 32 form
 // over pairs of tiles needs a second raw pair in flight to hide the loads: 664 bytes of scratch per lane, or 4 % slower without it.)
-template <bool BF>
+template <bool BF, bool A16 = false, bool B16 = false>
 __global__ void __launch_bounds__(256, 2) k_wgrad_row64(const WgradLaunch L) {
   constexpr int H = 64;
   __shared__ float red[3][H * H + H];
@@ -1618,13 +1618,24 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_row64(const WgradLaunch L) {
   f32x4 cs = {0.f, 0.f, 0.f, 0.f};  // column sums of A over this lane's rows (bias gradient)
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 av[2][4], bv[2][4];
+  // [r5] BF: an operand with a NEGATIVE leading dimension is two-byte bf16 rows of pitch -ld elements (what the bf16 mode's dense
+  // launches write with out16: the values are bf16 numbers, the rows half the bytes)
+  // (compile-time per launch: as run-time selects the two load forms cost 19 registers and 72 bytes of scratch)
+  constexpr bool a16 = BF && A16, b16 = BF && B16;
+  const long plda = A16 ? -(long)J.lda : J.lda, pldb = B16 ? -(long)J.ldb : J.ldb;
+  auto ld16 = [&](const float* X, long off) -> f32x4 {
+    const uint2 t = *(const uint2*)((const uint16_t*)X + off);
+    return f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+  };
   auto load_tile = [&](long tile, f32x4 (&a)[4], f32x4 (&b)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long row = tile * 16 + 4 * g + r;
       const bool ok = row < J.M;
-      a[r] = (ok && a_on) ? ld4(J.A + row * J.lda + 4 * c) : zero;
-      b[r] = (ok && b_on) ? ld4(J.B + row * J.ldb + 4 * c) : zero;
+      if constexpr (a16) a[r] = (ok && a_on) ? ld16(J.A, row * plda + 4 * c) : zero;
+      else a[r] = (ok && a_on) ? ld4(J.A + row * plda + 4 * c) : zero;
+      if constexpr (b16) b[r] = (ok && b_on) ? ld16(J.B, row * pldb + 4 * c) : zero;
+      else b[r] = (ok && b_on) ? ld4(J.B + row * pldb + 4 * c) : zero;
     }
   };
   auto mac_tile = [&](const f32x4 (&a)[4], const f32x4 (&b)[4]) {
@@ -2440,7 +2451,7 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
 
 extern "C" {
 
-int mgn_version(void) { return 135; }
+int mgn_version(void) { return 136; }
 const char* mgn_last_error(void) { return g_err; }
 
 size_t mgn_csr_workspace_bytes(int64_t E, int64_t N) {
@@ -2861,8 +2872,11 @@ int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes,
   if (njobs < 1 || njobs > MGN_MAX_WGRAD_JOBS) return fail(1, "mgn_wgrad: njobs out of range");
   for (int j = 0; j < njobs; ++j) {   // two-byte operands: only what k_wgrad_x6<1> reads
     if (jobs[j].lda < 0 || jobs[j].ldb < 0) {
-      if (precision != 1 || !wgrad_job_full(jobs[j]) || getenv("MGN_FP32_MFMA") != nullptr)
-        return fail(1, "mgn_wgrad: a negative leading dimension (bf16 rows) needs precision 1 and a full 128 x 128 job with ld = -128");
+      // full 128 x 128 jobs (k_wgrad_x6<1>) or, [r5], jobs of the row-vector kernel (k_wgrad_row64<true>: up to 64 x 64)
+      const bool r64 = !wgrad_job_full(jobs[j]) && wgrad_job_row64(jobs[j]) && getenv("MGN_WGRAD_NO_ROW64") == nullptr &&
+                       ((((uintptr_t)jobs[j].A | (uintptr_t)jobs[j].B) & 15) == 0);
+      if (precision != 1 || !(wgrad_job_full(jobs[j]) || r64) || getenv("MGN_FP32_MFMA") != nullptr)
+        return fail(1, "mgn_wgrad: a negative leading dimension (bf16 rows) needs precision 1 and a full 128 x 128 job with ld = -128 or a job of the row-vector kernel");
     }
   }
   hipStream_t s = (hipStream_t)stream;
@@ -2885,6 +2899,9 @@ int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes,
     bool row64 = pass == 1 && HB <= 4 && getenv("MGN_WGRAD_NO_ROW64") == nullptr;
     for (int j = 0; row64 && j < L.njobs; ++j) row64 = wgrad_job_row64(L.job[j]);
     if (row64) HB = 4;
+    if (!row64 && pass == 1)   // (only k_wgrad_x6<1> and k_wgrad_row64<true> read two-byte rows)
+      for (int j = 0; j < L.njobs; ++j)
+        if (L.job[j].lda < 0 || L.job[j].ldb < 0) return fail(1, "mgn_wgrad: bf16-row jobs below 128 x 128 need every job of the launch on the row-vector kernel");
     L.H = 16 * HB;
     // [r5] fp32-row full jobs: the producer / consumer kernel (one 512-thread workgroup per CU); MGN_WGRAD_PC=0: k_wgrad_x6<6>
     bool pc = pass == 0 && precision == 0 && getenv("MGN_FP32_MFMA") == nullptr;
@@ -2930,8 +2947,16 @@ int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes,
         hipLaunchKernelGGL(k_wgrad_lds, dim3(total), dim3(256), smem, s, L);
       }
     } else if (row64) {
-      if (precision == 1)
-        hipLaunchKernelGGL(k_wgrad_row64<true>, dim3(total), dim3(256), 0, s, L);
+      if (precision == 1) {
+        // two-byte operand rows: one pattern per launch (every job's A, every job's B alike)
+        const bool a16 = L.job[0].lda < 0, b16 = L.job[0].ldb < 0;
+        for (int j = 1; j < L.njobs; ++j)
+          if ((L.job[j].lda < 0) != a16 || (L.job[j].ldb < 0) != b16) return fail(1, "mgn_wgrad: the jobs of a row-vector launch must agree on which operand is bf16 rows");
+        if (a16 && b16) hipLaunchKernelGGL((k_wgrad_row64<true, true, true>), dim3(total), dim3(256), 0, s, L);
+        else if (a16) hipLaunchKernelGGL((k_wgrad_row64<true, true, false>), dim3(total), dim3(256), 0, s, L);
+        else if (b16) hipLaunchKernelGGL((k_wgrad_row64<true, false, true>), dim3(total), dim3(256), 0, s, L);
+        else hipLaunchKernelGGL((k_wgrad_row64<true>), dim3(total), dim3(256), 0, s, L);
+      }
       else if (getenv("MGN_FP32_MFMA") == nullptr && getenv("MGN_WGRAD_ROW64_EXACT") == nullptr) {   // [r5] fp32-grade on the split-bf16 matrix path
         bool full = true;
         for (int j = 0; full && j < L.njobs; ++j) full = L.job[j].nja == 4 && L.job[j].kw == 64;

@@ -24,7 +24,7 @@ def _prec() -> int:
 
 def linear_launch(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act: int = ACT_NONE, resid=None, out=None, inv_out=None,
                   n_out=None, saveZ1=None, saveZ2=None, precision: int = 0, x3=None, idx=(None, None, None), M: Optional[int] = None,
-                  w_transposed: bool = False, gate_bwd=None, norm_outer=None):
+                  w_transposed: bool = False, gate_bwd=None, norm_outer=None, z16: bool = False, out16: bool = False):
     """one ``mgn_linear_fwd`` launch (include/mgn_hip.h); x / x2 / x3 / resid may be row-strided views (stride(1) == 1);
     ``idx[p]`` (int32 [M]) gathers the rows of phase p; ``M`` = output rows (default: rows of x); ``w_transposed``: W (and W2) are
     [K, N] -- the launch multiplies by their transpose (see :func:`input_gradient`)."""
@@ -34,7 +34,7 @@ def linear_launch(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act:
     K3 = int(x3.shape[1]) if x3 is not None else 0
     N = int(W.shape[1] if w_transposed else W.shape[0])
     if out is None:
-        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        out = torch.empty(M, N, dtype=torch.bfloat16 if out16 else torch.float32, device=x.device)
     a = _capi.LinearArgs()
     a.M, a.x, a.ldx, a.K1 = M, x.data_ptr(), int(x.stride(0)), K1
     a.x2, a.ldx2, a.K2 = (x2.data_ptr() if x2 is not None else None), (int(x2.stride(0)) if x2 is not None else 0), K2
@@ -49,6 +49,9 @@ def linear_launch(x, W, b=None, x2=None, W2=None, b2=None, norm_scale=None, act:
     a.out, a.ldo = out.data_ptr(), int(out.stride(0))
     a.saveZ1, a.saveZ2, a.precision = ops._ptr(saveZ1), ops._ptr(saveZ2), precision
     a.w_transposed = 1 if w_transposed else 0
+    a.z16 = 1 if z16 else 0
+    a.x16 = 1 if x.dtype == torch.bfloat16 else 0          # two-byte input rows (bf16 mode; written by a launch with out16)
+    a.out16 = 1 if out16 else 0
     if norm_outer is not None:   # (scale, inv_out or None): a second RMSNorm in front of the norm prologue
         a.norm_scale_outer, a.inv_outer_out = norm_outer[0].data_ptr(), ops._ptr(norm_outer[1])
     if gate_bwd is not None:   # (Z1, Z2, out2): the gated product's backward as the epilogue -- out = dZ1, out2 = dZ2
@@ -258,7 +261,10 @@ def _wgrad_jobs(dZ, n, dW, db):
         first = True
         for k0 in range(0, K, slab):
             nk = min(slab, K - k0)
-            job = (dZ[:, j0:j0 + nj], int(dZ.stride(0)), nj // 16, n[:, k0:k0 + nk], int(n.stride(0)), nk // 16, nk, dW, j0 * K + k0, K)
+            # (a bf16 tensor = two-byte rows: the C side takes them as a negative leading dimension, precision 1 only)
+            lda = -int(dZ.stride(0)) if dZ.dtype == torch.bfloat16 else int(dZ.stride(0))
+            ldb = -int(n.stride(0)) if n.dtype == torch.bfloat16 else int(n.stride(0))
+            job = (dZ[:, j0:j0 + nj], lda, nj // 16, n[:, k0:k0 + nk], ldb, nk // 16, nk, dW, j0 * K + k0, K)
             if first and db is not None:
                 job = job + (db[j0:j0 + nj],)
             first = False
@@ -295,14 +301,18 @@ class GatedMlpResidualFn(torch.autograd.Function):
         dev = x.device
         f = dict(dtype=torch.float32, device=dev)
         need = any(ctx.needs_input_grad) and ops._saving()
-        Z1 = torch.empty(M, N, **f) if need else None
-        Z2 = torch.empty(M, N, **f) if need else None
+        # bf16 mode: the pre-activations are bf16 numbers -- kept as two-byte rows (exact; MGN_DENSE_SAVE16=0: fp32 rows)
+        z16 = precision == 1 and _SAVE16[0]
+        zt = dict(dtype=torch.bfloat16 if z16 else torch.float32, device=dev)
+        Z1 = torch.empty(M, N, **zt) if need else None
+        Z2 = torch.empty(M, N, **zt) if need else None
         inv_o = torch.empty(M, **f) if need else None
         inv_i = torch.empty(M, **f) if need else None
         n = torch.empty(M, K, **f) if need else None
         # both norms are the prologue of the gated launch (the outer one's output is never stored)
+        # (bf16 mode: the gated product itself is a bf16 tensor too -- two-byte rows between the two launches and for dW3)
         p_ = linear_launch(x, W1, b1, W2=W2, b2=b2, norm_scale=s_inner, act=act, inv_out=inv_i, n_out=n, saveZ1=Z1, saveZ2=Z2, precision=precision,
-                           norm_outer=(s_outer, inv_o))
+                           norm_outer=(s_outer, inv_o), z16=z16 and need, out16=z16 and need)   # (inference keeps fp32 rows: measured faster there)
         out = linear_launch(p_, W3, b3, resid=x, precision=precision)
         if need:
             ctx.save_for_backward(x, s_outer, s_inner, W1, W2, W3)
@@ -327,8 +337,10 @@ class GatedMlpResidualFn(torch.autograd.Function):
         # W3: weight gradient from (dy, p_); its input gradient goes straight through the gated product's backward
         dW3, db3 = torch.empty(K, N, **f), (torch.empty(K, **f) if has_b3 else None)
         ops.wgrad(_wgrad_jobs(dy, p_, dW3, db3), dev, prec)
-        dZ1, dZ2 = torch.empty(M, N, **f), torch.empty(M, N, **f)
-        linear_launch(dy, W3, out=dZ1, precision=prec, w_transposed=True, act=act, gate_bwd=(Z1, Z2, dZ2))
+        s16 = Z1.dtype == torch.bfloat16     # bf16 mode: dZ1 / dZ2 are bf16 numbers -- two-byte rows for the two dX launches and dW1 / dW2
+        zt = dict(dtype=torch.bfloat16 if s16 else torch.float32, device=dev)
+        dZ1, dZ2 = torch.empty(M, N, **zt), torch.empty(M, N, **zt)
+        linear_launch(dy, W3, out=dZ1, precision=prec, w_transposed=True, act=act, gate_bwd=(Z1, Z2, dZ2), z16=s16, out16=s16)
         dn = input_gradient(dZ1, W1, precision=prec)
         dn = input_gradient(dZ2, W2, resid=dn, precision=prec)
         dW1, db1 = torch.empty(N, K, **f), (torch.empty(N, **f) if has_b1 else None)
@@ -347,6 +359,8 @@ class GatedMlpResidualFn(torch.autograd.Function):
         return dx, ds_outer, ds_inner, dW1, db1, dW2, db2, dW3, db3, None, None
 
 
+#: MGN_DENSE_SAVE16=0: the bf16 mode's saved pre-activations of the gated half stay fp32 rows (A/B)
+_SAVE16 = [os.environ.get("MGN_DENSE_SAVE16", "1") != "0"]
 #: MGN_FUSED_MLP=0: Transformer blocks keep the gated-MLP half on separate autograd nodes (A/B)
 _FUSED_MLP = [os.environ.get("MGN_FUSED_MLP", "1") != "0"]
 

@@ -636,6 +636,11 @@ typedef struct {
    * w_transposed (the LDS-staged form); needs norm_scale. */
   const float* norm_scale_outer;
   float* inv_outer_out;
+  /* [r5] precision 1 only: saveZ1 / saveZ2 (written) and gb_z1 / gb_z2 (read) are TWO-BYTE rows [M, N] of bf16 -- a bf16 Linear's
+   * result is a bf16 number, so the narrowing is exact and the gated half's largest tensors take half the bytes. */
+  int z16;
+  int x16;     /* precision 1: the rows of the (single, ungathered, un-normed) input phase are two-byte bf16 rows, ldx = their pitch in elements */
+  int out16;   /* precision 1: out (and out2) are written as two-byte bf16 rows, ldo = their pitch in elements; no residual */
 } mgn_linear_args;
 int mgn_linear_fwd(const mgn_linear_args* args, void* stream);
 /* 1 when mgn_linear_fwd takes w_transposed for this shape (M rows, K = K1 + K2 + K3 inputs, N outputs, gated product or not) */

@@ -316,12 +316,12 @@ def test_transformer_node_renumbering_switch_and_binding_layout():
     finally:
         ops.set_node_renumbering(prev)
     names = [f[0] for f in _capi.LinearArgs._fields_]
-    assert names[-7:] == ["precision", "w_transposed", "gb_z1", "gb_z2", "out2", "norm_scale_outer", "inv_outer_out"]
+    assert names[-10:] == ["precision", "w_transposed", "gb_z1", "gb_z2", "out2", "norm_scale_outer", "inv_outer_out", "z16", "x16", "out16"]
     assert [f[0] for f in _capi.RownormPhase._fields_] == ["x", "ldx", "K", "idx", "dx", "lddx", "acc"]
     import os
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mgn_hip.h")).read()
     body = hdr[hdr.index("typedef struct {\n  int64_t M;\n  const float* x; int ldx; int K1;"):hdr.index("} mgn_linear_args;")]
     order = [body.index(k) for k in ("int precision;", "int w_transposed;", "const float* gb_z1;", "const float* gb_z2;", "float* out2;",
-                                     "const float* norm_scale_outer;", "float* inv_outer_out;")]
+                                     "const float* norm_scale_outer;", "float* inv_outer_out;", "int z16;", "int x16;", "int out16;")]
     assert order == sorted(order)
-    assert _capi.EXPECTED_VERSION == 135
+    assert _capi.EXPECTED_VERSION == 136

@@ -37,8 +37,9 @@ for rep in range(3):
         ops.set_matrix_precision(mode)
         for wt in ((True, False) if "wt" in sys.argv[1:] else (True,)):
             for fm in ((True, False) if "fused" in sys.argv[1:] else (True,)):
-                _D._WT_ON[0], _D._FUSED_MLP[0] = wt, fm
-                print(mode, f"forward {timed(fwd):.2f} ms  train {timed(train, 8):.2f} ms" + ("" if wt else "   (W^T materialised)")
-                      + ("" if fm else "   (gated-MLP half as separate autograd nodes)"), flush=True)
-_D._WT_ON[0] = _D._FUSED_MLP[0] = True
+                for s16 in ((True, False) if ("save16" in sys.argv[1:] and mode == "bf16") else (True,)):
+                    _D._WT_ON[0], _D._FUSED_MLP[0], _D._SAVE16[0] = wt, fm, s16
+                    print(mode, f"forward {timed(fwd):.2f} ms  train {timed(train, 8):.2f} ms" + ("" if wt else "   (W^T materialised)")
+                          + ("" if fm else "   (gated-MLP half as separate autograd nodes)") + ("" if s16 else "   (fp32 rows for the saved bf16 values)"), flush=True)
+_D._WT_ON[0] = _D._FUSED_MLP[0] = _D._SAVE16[0] = True
 ops.set_matrix_precision("fp32")
