@@ -314,15 +314,18 @@ def test_dense_linear_takes_column_slabs(dev):
 
 
 @pytest.mark.gpu
-def test_transformer_block_bf16_mode_vs_mixed_oracle(dev):
+@pytest.mark.parametrize("N", [3000, 70000])
+def test_transformer_block_bf16_mode_vs_mixed_oracle(dev, N):
     """configs[4]'s bf16 semantic (training.enable_vram_optimizations: Lightning bf16-mixed + the fp32 attention shims,
     layers.py:49-70): one Transformer block at the coarse-aneurysm shape (hidden 64, 4 heads) in the bf16 matrix mode against the
-    oracle's explicit bf16-mixed evaluation -- and not farther from it than that semantic is from fp32."""
+    oracle's explicit bf16-mixed evaluation -- and not farther from it than that semantic is from fp32.  N = 70 000 [r5]: the paths of
+    65 536 rows and more in BOTH modes -- k_linear_x6 (six terms / one piece), the packed attention on fp32 rows of bf16 values, the
+    residual riding through the projection node, the gated-MLP half as one autograd node with two-byte rows in bf16 mode."""
     import graph_physics_amd as gp
     from conftest import rms_err
     from graph_physics_amd import ops
 
-    N, H, nh, seed = 3000, 64, 4, 77
+    H, nh, seed = 64, 4, 77
     pos, ei, _ = R.delaunay_graph(N, seed, dim=3)
     blk = gp.Transformer(H, H, nh).to(dev)
     params = R.variant_params(blk.state_dict(), seed)
