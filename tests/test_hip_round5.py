@@ -196,6 +196,12 @@ def test_six_term_dense_launch_vs_fp64(dev, K, N):
         idx = torch.randint(0, M // 3, (M,), generator=g, dtype=torch.int32).to(dev)
         o = D.linear_launch(xa, W, None, x2=xb, idx=(None, idx, None), M=M)
         assert rel_err(o, xa.to(d) @ W[:, :k1].to(d).t() + xb.to(d)[idx.long()] @ W[:, k1:].to(d).t()) < tol
+        # the same two phases under the norm prologue (the gated-MLP GraphNetBlock's edge update: RMSNorm over the concatenated row)
+        cat = torch.cat([xa.to(d), xb.to(d)[idx.long()]], dim=1)
+        nc = sc.to(d) * cat / (cat.norm(dim=1, keepdim=True) / K ** 0.5 + ops.EPS)
+        n_cat = torch.empty(M, K, **f)
+        o = D.linear_launch(xa, W, b, x2=xb, idx=(None, idx, None), M=M, norm_scale=sc, n_out=n_cat, act=1)
+        assert rel_err(o, F.silu(nc @ W.to(d).t() + b.to(d))) < tol and rel_err(n_cat, nc) < tol
     dz = rn(M, N)
     from graph_physics_amd import _capi
     assert _capi.lib().mgn_linear_accepts_transposed(M, N, K, 0, 0) == (1 if N % 32 == 0 else 0)
