@@ -1350,7 +1350,25 @@ struct WgradLaunch {
   int wg0[MGN_MAX_WGRAD_JOBS + 1];  // first workgroup of each job
   float* partial;                   // [total_wg][H*H + H]: dW partial, then the db partial
   int H;
+  // [r5] row-vector launches whose jobs all walk the same rows (the 64-column slabs of one wide weight gradient: they share an
+  // operand): interleave = workgroups per job (a multiple of 8, the same for every job).  Workgroup b then serves job (b % (8 njobs)) / 8,
+  // share 8 (b / (8 njobs)) + b % 8 -- the workgroups that read the SAME rows of the shared operand are 8 apart in blockIdx, i.e. on the
+  // same XCD and resident together, so two of three (five of six) of those reads are L2 hits.  0: contiguous ranges per job (wg0).
+  int interleave;
 };
+__device__ __forceinline__ void wgrad_where(const WgradLaunch& L, int& j, int& wg, int& nwg) {
+  if (L.interleave > 0) {
+    const int per = 8 * L.njobs, b = (int)blockIdx.x;
+    j = (b % per) >> 3;
+    wg = 8 * (b / per) + (b & 7);
+    nwg = L.interleave;
+    return;
+  }
+  j = 0;
+  while (j + 1 < L.njobs && (int)blockIdx.x >= L.wg0[j + 1]) ++j;
+  nwg = L.wg0[j + 1] - L.wg0[j];
+  wg = blockIdx.x - L.wg0[j];
+}
 
 template <int HB>
 __global__ void __launch_bounds__(256, 2) k_wgrad(const WgradLaunch L) {
@@ -1601,11 +1619,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_row64(const WgradLaunch L) {
   __shared__ float red[3][H * H + H];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
-  int j = 0;
-  while (j + 1 < L.njobs && (int)blockIdx.x >= L.wg0[j + 1]) ++j;
+  int j, wg, nwg;
+  wgrad_where(L, j, wg, nwg);
   const mgn_wgrad_job J = L.job[j];
-  const int nwg = L.wg0[j + 1] - L.wg0[j];
-  const int wg = blockIdx.x - L.wg0[j];
+  const int pidx = L.wg0[j] + wg;   // the partial's slot: contiguous per job whatever the workgroup order
   const long ntiles = (J.M + 15) >> 4;
   const long t0 = ntiles * wg / nwg, t1 = ntiles * (wg + 1) / nwg;
   const bool a_on = 4 * c < 16 * J.nja, b_on = 4 * c < J.kw;
@@ -1710,7 +1727,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_row64(const WgradLaunch L) {
         }
       cs += *(const f32x4*)(red[w] + H * H + 4 * c);
     }
-    float* P = L.partial + (size_t)blockIdx.x * (H * H + H);
+    float* P = L.partial + (size_t)pidx * (H * H + H);
 #pragma unroll
     for (int qa = 0; qa < 4; ++qa)
 #pragma unroll
@@ -1736,11 +1753,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_row64x6(const WgradLaunch L) {
   __shared__ float red[3][H * H + H];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, g = lane >> 4;
-  int j = 0;
-  while (j + 1 < L.njobs && (int)blockIdx.x >= L.wg0[j + 1]) ++j;
+  int j, wg, nwg;
+  wgrad_where(L, j, wg, nwg);
   const mgn_wgrad_job J = L.job[j];
-  const int nwg = L.wg0[j + 1] - L.wg0[j];
-  const int wg = blockIdx.x - L.wg0[j];
+  const int pidx = L.wg0[j] + wg;   // the partial's slot: contiguous per job whatever the workgroup order
   const long ntiles = (J.M + 31) >> 5;
   const long t0 = ntiles * wg / nwg, t1 = ntiles * (wg + 1) / nwg;
   const bool a_on = FULL || 4 * c < 16 * J.nja, b_on = FULL || 4 * c < J.kw;
@@ -1838,7 +1854,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_row64x6(const WgradLaunch L) {
         }
       cs += *(const f32x4*)(red[w] + H * H + 4 * c);
     }
-    float* P = L.partial + (size_t)blockIdx.x * (H * H + H);
+    float* P = L.partial + (size_t)pidx * (H * H + H);
 #pragma unroll
     for (int qa = 0; qa < 4; ++qa)
 #pragma unroll
@@ -2910,7 +2926,20 @@ int mgn_wgrad_p(int njobs, const mgn_wgrad_job* jobs, void* ws, size_t ws_bytes,
       pc = e == nullptr || atoi(e) != 0;
       for (int j = 0; pc && j < L.njobs; ++j) pc = L.job[j].lda == 128 && L.job[j].ldb == 128;
     }
-    const int total = wgrad_plan(L.njobs, L.job, L.wg0, pass == 0, pc ? 256 : 512);
+    int total = wgrad_plan(L.njobs, L.job, L.wg0, pass == 0, pc ? 256 : 512);
+    L.interleave = 0;
+    if (row64 && L.njobs >= 2 && L.njobs <= 8 && getenv("MGN_WGRAD_NO_INTERLEAVE") == nullptr) {
+      bool same = true;
+      for (int j = 1; j < L.njobs; ++j) same = same && L.job[j].M == L.job[0].M;
+      const int64_t tiles = (L.job[0].M + 15) / 16;
+      int per = (512 / L.njobs) & ~7;                       // workgroups per job: a multiple of 8, at most the usual budget together
+      while (per > 8 && (int64_t)per * 4 > tiles) per -= 8;   // (at least ~4 tiles per workgroup)
+      if (same && per >= 8 && tiles >= 4 * per) {
+        for (int j = 0; j <= L.njobs; ++j) L.wg0[j] = j * per;
+        L.interleave = per;
+        total = L.njobs * per;
+      }
+    }
     const size_t need = (size_t)total * (L.H * L.H + L.H) * sizeof(float);
     if (ws_bytes < ws_off + need) return fail(1, "mgn_wgrad: workspace too small");
     L.partial = (float*)((char*)ws + ws_off);
