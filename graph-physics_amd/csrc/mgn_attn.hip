@@ -142,6 +142,19 @@ __device__ __forceinline__ float head_reduce_own(const float (&p)[4], int l) {
   return m;
 }
 
+// [r5] XCD-aware block order: consecutive workgroups go to consecutive XCDs, each with an L2 of its own, so with rows handed out in
+// blockIdx order every L2 saw rows from everywhere.  Block b serves row block (b & 7) * (gridDim / 8) + (b >> 3) instead: an XCD
+// walks ONE contiguous eighth of the (Morton-ordered) rows, and the k / v (q / dy) rows its workgroups gather are mostly rows its own
+// L2 already holds.  -DATTN_NO_XCD_ORDER: blockIdx order.
+__device__ __forceinline__ long attn_block() {
+#ifdef ATTN_NO_XCD_ORDER
+  return (long)blockIdx.x;
+#else
+  const unsigned per = gridDim.x >> 3, b = blockIdx.x;
+  return (b < 8 * per) ? (long)(b & 7) * per + (b >> 3) : (long)b;
+#endif
+}
+
 // The edge loops below are software-pipelined by hand: the column index of edge e + 2 and the gathered rows of edge e + 1 are
 // requested before edge e is processed (a lane walks ONE row's edges serially, and index -> row -> arithmetic is a dependent
 // chain of two memory latencies per edge otherwise; rows of a wave have different degrees, so the compiler does not do it).
@@ -201,7 +214,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ q, c
                                                  const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, long N, int NH,
                                                  float scale, float sd, float* __restrict__ y, float* __restrict__ lse, float* __restrict__ y_raw, AttnLd ld) {
   constexpr int H = 4 * LPR;
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const long i = (attn_block() * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
   if (i >= N) return;
   const float4 qv = *(const float4*)(q + (size_t)i * ld.q + 4 * l);
@@ -284,7 +297,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_row(const float* __restrict__ 
                                                      float* __restrict__ ds_out, AttnLd ld, uint16_t* __restrict__ q16,
                                                      uint16_t* __restrict__ g16) {
   constexpr int H = 4 * LPR;
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const long i = (attn_block() * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
   if (i >= N) return;
   const size_t ro = (size_t)i * H + 4 * l;
@@ -371,7 +384,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_col(const float* __restrict__ 
                                                      float scale, float sd, float* __restrict__ dk, float* __restrict__ dv, AttnLd ld,
                                                      const uint16_t* __restrict__ q16, const uint16_t* __restrict__ g16) {
   constexpr int H = 4 * LPR;
-  const long j = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const long j = (attn_block() * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
   if (j >= N) return;
   float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
@@ -443,7 +456,7 @@ __global__ void __launch_bounds__(256) k_attn_weights(const float* __restrict__ 
                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                      const int32_t* __restrict__ out_pos, long N, int NH, float scale, float* __restrict__ a_out) {
   constexpr int H = 4 * LPR;
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const long i = (attn_block() * 256 + threadIdx.x) / LPR;
   const int l = threadIdx.x % LPR;
   if (i >= N) return;
   const size_t ro = (size_t)i * H + 4 * l;
