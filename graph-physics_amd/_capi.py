@@ -16,7 +16,7 @@ _REPO = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("MGN_LIB") or os.path.join(_CSRC, "libmgn_hip.so")
 SOURCES = [os.path.join(_CSRC, "mgn_kernels.hip"), os.path.join(_CSRC, "mgn_prep.hip"), os.path.join(_CSRC, "mgn_attn.hip"),
            os.path.join(_CSRC, "mgn_dense.hip")]
-DEPS = [os.path.join(_CSRC, "mgn_x6.inc"), os.path.join(_CSRC, "mgn_fused.inc"), os.path.join(_CSRC, "mgn_pp.inc")]  # included by the source
+DEPS = [os.path.join(_CSRC, "mgn_x6.inc"), os.path.join(_CSRC, "mgn_fused.inc"), os.path.join(_CSRC, "mgn_pp.inc"), os.path.join(_CSRC, "mgn_ppr.inc")]  # included by the source
 HEADER = os.path.join(_REPO, "include", "mgn_hip.h")
 # No packed-fp32 VALU (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) in device code: beside a SIMD partner that streams MFMAs
 # one of them takes ~70 cycles instead of ~6 (tools/coissue_probe.hip; plain VALU: 8), and hipcc forms them everywhere --

@@ -1600,6 +1600,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_lds(const WgradLaunch L) {
 
 #include "mgn_x6.inc"
 #include "mgn_pp.inc"
+#include "mgn_ppr.inc"
 #include "mgn_fused.inc"
 
 // Row-vector variant for jobs up to 64 x 64 (the 64 x 64 block jobs dense.py cuts the Transformer's / gated MLP's weight gradients
@@ -2257,6 +2258,24 @@ static bool fwd_pp_ok(const mgn_mlp_fwd_args& a) {
   return (all || none) && a.resid != nullptr && a.scale != nullptr && a.out != a.resid && a.out != a.src[0];
 }
 
+// The register-resident-weights edge update (mgn_ppr.inc) takes a ShEdge launch under the ping-pong kernel's conditions (fp32-grade,
+// units back to back, no message output, saves all there or all absent, outputs alias no input) from 65 536 rows (every CU gets
+// >= 8 groups of 32 rows: below that the two-slot lag of its second half is not amortised).  MGN_PPR: unset = on, both modes;
+// 0 = off; 2 = at any size (tests); MGN_PPR_XCD=0: plain hand-out of the groups instead of XCD by XCD (A/B).
+static bool fwd_ppr_ok(const mgn_mlp_fwd_args& a) {
+  const char* env = getenv("MGN_PPR");
+  const int mode = (env == nullptr) ? 1 : atoi(env);
+  if (mode == 0) return false;
+  const int64_t min_rows = (mode == 2) ? 1 : 65536;
+  if (a.precision != 0 || a.y_out != nullptr || a.M < min_rows || a.M * 512 >= (int64_t)1 << 32) return false;  // (32-bit row offsets)
+  for (int u = 1; u < 4; ++u)
+    if ((const char*)a.wpk[u] != (const char*)a.wpk[0] + (size_t)u * MGN_WPACK_BYTES) return false;
+  const bool all = a.saveU && a.saveR && a.saveH[0] && a.saveH[1] && a.saveH[2] && a.saveM[0] && a.saveM[1] && a.saveM[2];
+  const bool none = !a.saveU && !a.saveR && !a.saveH[0] && !a.saveH[1] && !a.saveH[2] && !a.saveM[0] && !a.saveM[1] && !a.saveM[2];
+  // rows past M are computed as copies of row M - 1 and stored there again: the outputs must alias no input
+  return (all || none) && a.resid != nullptr && a.scale != nullptr && a.out != a.resid && a.out != a.src[0];
+}
+
 template <int HB>
 static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
   const bool ragged = fwd_ragged(a);
@@ -2289,6 +2308,29 @@ static int launch_fwd(const mgn_mlp_fwd_args& a, hipStream_t s) {
       if (atoi(e) > 0 && (unsigned)atoi(e) < grid) grid = (unsigned)atoi(e);
     }
     const int shape = (nw == 4 && !silu) ? fwd_static_shape(a) : 0;
+    if (shape == 1 && !nw6 && fwd_ppr_ok(a)) {
+      static thread_local bool ppr_attr = false;
+      if (!ppr_attr) {
+        if (hipFuncSetAttribute((const void*)k_edge_fwd_ppr<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PPR_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_edge_fwd_ppr<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PPR_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_edge_fwd_ppr<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PPR_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_edge_fwd_ppr<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PPR_LDS_BYTES) != hipSuccess)
+          return 1;
+        ppr_attr = true;
+      }
+      const int64_t ngroups = ((a.M + 15) / 16 + PPR_R - 1) / PPR_R;
+      unsigned gp = (ngroups < 256) ? (unsigned)ngroups : 256u;
+      const char* ex = getenv("MGN_PPR_XCD");
+      const bool xcd = ex == nullptr || atoi(ex) != 0;
+      if (a.saveU != nullptr) {
+        if (xcd) hipLaunchKernelGGL((k_edge_fwd_ppr<true, true>), dim3(gp), dim3(512), PPR_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((k_edge_fwd_ppr<true, false>), dim3(gp), dim3(512), PPR_LDS_BYTES, s, a);
+      } else {
+        if (xcd) hipLaunchKernelGGL((k_edge_fwd_ppr<false, true>), dim3(gp), dim3(512), PPR_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((k_edge_fwd_ppr<false, false>), dim3(gp), dim3(512), PPR_LDS_BYTES, s, a);
+      }
+      return 0;
+    }
     if (shape == 1 && !nw6 && fwd_pp_ok(a)) {
       static thread_local bool pp_attr = false;
       if (!pp_attr) {

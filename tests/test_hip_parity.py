@@ -836,7 +836,8 @@ def test_static_shape_kernels_equal_the_dynamic_kernels_bit_for_bit(dev, prec):
     params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), 91)
     x_in, e_in = R.randn((g.x.shape[0], 11), 5).to(dev), R.randn((g.edge_index.shape[1], 3), 6).to(dev)
     res = {}
-    old, old_pp = os.environ.get("MGN_X6_STATIC"), os.environ.get("MGN_PP")
+    old, old_pp, old_ppr = os.environ.get("MGN_X6_STATIC"), os.environ.get("MGN_PP"), os.environ.get("MGN_PPR")
+    os.environ["MGN_PPR"] = "0"  # (likewise the register-resident-weights kernels: tests/test_hip_ppr.py)
     os.environ["MGN_PP"] = "0"   # the x6 generation on both sides (the ping-pong kernel of the inference-mode launches agrees to 2e-6,
     ops.set_matrix_precision(prec)   # not bit for bit: tests/test_hip_pp.py)
     try:
@@ -851,7 +852,7 @@ def test_static_shape_kernels_equal_the_dynamic_kernels_bit_for_bit(dev, prec):
             res[mode] = {"out": out.detach().clone(), "inf": inf.clone(), **{k: p.grad.clone() for k, p in net.named_parameters()}}
     finally:
         ops.set_matrix_precision("fp32")
-        for k_, v_ in (("MGN_X6_STATIC", old), ("MGN_PP", old_pp)):
+        for k_, v_ in (("MGN_X6_STATIC", old), ("MGN_PP", old_pp), ("MGN_PPR", old_ppr)):
             if v_ is None:
                 os.environ.pop(k_, None)
             else:

@@ -1,7 +1,8 @@
-"""GPU: the ping-pong generation of the edge update (csrc/mgn_pp.inc; MGN_PP: default = inference-mode launches from 65 536 rows) through the C ABI (mgn_mlp_fwd):
+"""GPU: the register-resident-weights generation of the edge update (csrc/mgn_ppr.inc; MGN_PPR: default = launches from 65 536 rows, both modes) through the C ABI (mgn_mlp_fwd):
 every output of the launch -- e', the fused aggregation, the saved activations with their sign bits, U, rms -- against an fp64
 evaluation of the reference's edge update (layers.py:1044-1060, 163-210, 104-129) on ragged row counts (tile tails, one row,
-rows past the last tile) in inference and training mode, and against the x6 static-shape kernel it replaces."""
+rows past the last tile) in inference and training mode, and against the x6 static-shape kernel it replaces: saved activations and sign bits BIT-identical (same MFMA terms in the same
+order on the same packed weights), u / e' / aggregate to rounding (the row norm adds its squares in another order)."""
 import os
 
 import pytest
@@ -48,10 +49,9 @@ def case():
 def _run(c, M, save, pp):
     dev, topo = c["dev"], c["topo"]
     f = dict(dtype=torch.float32, device=dev)
-    old = os.environ.get("MGN_PP")
-    old_r = os.environ.get("MGN_PPR")
-    os.environ["MGN_PP"] = "2" if pp else "0"
-    os.environ["MGN_PPR"] = "0"   # (the register-resident-weights kernel would take these launches first: tests/test_hip_ppr.py)
+    old = os.environ.get("MGN_PP"), os.environ.get("MGN_PPR")
+    os.environ["MGN_PP"] = "0"
+    os.environ["MGN_PPR"] = "2" if pp else "0"
     try:
         sl = slice(0, M)
         nn = int(topo.dst_s[M - 1]) + 1
@@ -68,7 +68,7 @@ def _run(c, M, save, pp):
         ops.seg_fix(rowptr, part, agg)
         torch.cuda.synchronize()
     finally:
-        for k, v in (("MGN_PP", old), ("MGN_PPR", old_r)):
+        for k, v in zip(("MGN_PP", "MGN_PPR"), old):
             if v is None:
                 os.environ.pop(k, None)
             else:
@@ -81,8 +81,8 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("save", [False, True])
-@pytest.mark.parametrize("M", [0, -10, 40000, 257, 129, 128, 17, 1])
-def test_ping_pong_edge_update_vs_fp64(case, M, save):
+@pytest.mark.parametrize("M", [0, -10, -23, 40000, 8193, 257, 129, 128, 33, 32, 31, 17, 16, 1])
+def test_ppr_edge_update_vs_fp64_and_x6(case, M, save):
     """M <= 0: all rows of the 6-mesh batch (E ~ 67 500: several tiles per workgroup), minus |M|"""
     topo, ref = case["topo"], case["ref"]
     M = topo.E + M if M <= 0 else M
@@ -100,4 +100,5 @@ def test_ping_pong_edge_update_vs_fp64(case, M, save):
             bits = (got["H"][l].view(M, 8, 4, 4) > 0).permute(0, 2, 1, 3).reshape(M, 4, 32).long()   # [row][g][4 ib + r]
             want = (bits << torch.arange(32, device=case["dev"])).sum(-1)
             assert torch.equal(got["M"][l].long() & 0xffffffff, want), f"sign bits of layer {l + 1}"
+            assert torch.equal(got["H"][l], base["H"][l]) and torch.equal(got["M"][l], base["M"][l]), f"layer {l + 1} differs from the x6 kernel"
         assert _rel(got["U"], ref["U"][:M]) < tol and _rel(got["R"], ref["R"][:M]) < tol
