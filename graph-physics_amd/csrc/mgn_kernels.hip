@@ -2429,6 +2429,30 @@ static bool bwd_x6(const mgn_mlp_bwd_args& a) {
   return true;
 }
 
+// The register-resident-weights edge backward chain (mgn_ppr.inc) takes an SbEdge launch when it is fp32-grade, its four units lie
+// back to back, only dscale is asked for as a column sum, every dZ is written as fp32 rows and the outputs alias no input (rows past
+// M are computed as copies of row M - 1 and stored there again), from 65 536 rows.  MGN_PPR as for the forward kernel; MGN_PPR_BWD=0
+// keeps the x6 chain (A/B).
+static bool bwd_ppr_ok(const mgn_mlp_bwd_args& a) {
+  const char* env = getenv("MGN_PPR");
+  const int mode = (env == nullptr) ? 1 : atoi(env);
+  const char* eb = getenv("MGN_PPR_BWD");
+  if (mode == 0 || (eb != nullptr && atoi(eb) == 0)) return false;
+  const int64_t min_rows = (mode == 2) ? 1 : 65536;
+  if (a.precision != 0 || a.M < min_rows || a.M * 512 >= (int64_t)1 << 32 || a.dscale == nullptr) return false;
+  for (int u = 1; u < 4; ++u)
+    if ((const char*)a.wpk[u] != (const char*)a.wpk[0] + (size_t)u * MGN_WPACK_BYTES) return false;
+  for (int l = 0; l < 4; ++l)
+    if (a.db[l] != nullptr || a.dZ[l] == nullptr) return false;
+  if (a.dIn[0] == nullptr || a.Ms[0] == nullptr || a.Ms[1] == nullptr || a.Ms[2] == nullptr) return false;
+  const void* ins[4] = {a.dOut, a.U, a.din_resid[0], a.dOut2};
+  const void* outs[5] = {a.dZ[0], a.dZ[1], a.dZ[2], a.dZ[3], a.dIn[0]};
+  for (const void* o : outs)
+    for (const void* i : ins)
+      if (o == i) return false;
+  return true;
+}
+
 template <int HB>
 static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
   MlpPlan p = plan_mlp(a.M, a.H, a.NL, a.out_w != a.H || a.n_din > 1, true, a.act);
@@ -2458,7 +2482,23 @@ static int launch_bwd(const mgn_mlp_bwd_args& a, hipStream_t s) {
     const bool sb_edge = !static_off && !front && a.seg_out == nullptr && a.act == MGN_ACT_RELU && a.NL == 4 &&
                          a.n_din == 1 && a.din_resid[0] != nullptr && a.scale != nullptr && a.R != nullptr && a.U != nullptr &&
                          a.dOut2 != nullptr && a.idx2 != nullptr;
-    if (sb_edge) {
+    if (sb_edge && bwd_ppr_ok(a)) {
+      static thread_local bool ppr_attr = false;
+      if (!ppr_attr) {
+        if (hipFuncSetAttribute((const void*)k_edge_bwd_ppr<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PPB_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_edge_bwd_ppr<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PPB_LDS_BYTES) != hipSuccess)
+          return 1;
+        ppr_attr = true;
+      }
+      const int64_t ngroups = ((a.M + 15) / 16 + PPR_R - 1) / PPR_R;
+      unsigned gp = (ngroups < 256) ? (unsigned)ngroups : 256u;
+      if (gp > p.grid) gp = p.grid;  // (the column reduction reads p.grid partials: never more workgroups than that)
+      const char* ex = getenv("MGN_PPR_XCD");
+      if (ex == nullptr || atoi(ex) != 0)
+        hipLaunchKernelGGL((k_edge_bwd_ppr<true>), dim3(gp), dim3(512), PPB_LDS_BYTES, s, a, (int)p.grid);
+      else
+        hipLaunchKernelGGL((k_edge_bwd_ppr<false>), dim3(gp), dim3(512), PPB_LDS_BYTES, s, a, (int)p.grid);
+    } else if (sb_edge) {
       if (a.precision >= 1)
         hipLaunchKernelGGL((k_mlp_bwd_x6<1, false, 0, false, SbEdge>), dim3(p.grid), dim3(256), lds, s, a);
       else

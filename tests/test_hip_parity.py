@@ -873,7 +873,8 @@ def test_static_node_shape_equals_the_dynamic_kernel_on_a_multi_tile_launch(dev)
     params = R.make_params(R.epd_param_shapes(L, H, 11, 3, 2), 92)
     x_in, e_in = R.randn((g.x.shape[0], 11), 7).to(dev), R.randn((g.edge_index.shape[1], 3), 8).to(dev)
     res = {}
-    old = os.environ.get("MGN_X6_STATIC")
+    old, old_ppr = os.environ.get("MGN_X6_STATIC"), os.environ.get("MGN_PPR")
+    os.environ["MGN_PPR"] = "0"  # the x6 generation on both sides (the register-resident-weights edge kernels agree to rounding only: tests/test_hip_ppr.py)
     try:
         for mode in ("0", "1"):
             os.environ["MGN_X6_STATIC"] = mode
@@ -883,9 +884,10 @@ def test_static_node_shape_equals_the_dynamic_kernel_on_a_multi_tile_launch(dev)
             out.square().sum().backward()
             res[mode] = {"out": out.detach().clone(), **{k: p.grad.clone() for k, p in net.named_parameters()}}
     finally:
-        if old is None:
-            os.environ.pop("MGN_X6_STATIC", None)
-        else:
-            os.environ["MGN_X6_STATIC"] = old
+        for k_, v_ in (("MGN_X6_STATIC", old), ("MGN_PPR", old_ppr)):
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
     for k in res["0"]:
         assert torch.equal(res["0"][k], res["1"][k]), (k, float((res["0"][k] - res["1"][k]).abs().max()))

@@ -102,3 +102,69 @@ def test_ppr_edge_update_vs_fp64_and_x6(case, M, save):
             assert torch.equal(got["M"][l].long() & 0xffffffff, want), f"sign bits of layer {l + 1}"
             assert torch.equal(got["H"][l], base["H"][l]) and torch.equal(got["M"][l], base["M"][l]), f"layer {l + 1} differs from the x6 kernel"
         assert _rel(got["U"], ref["U"][:M]) < tol and _rel(got["R"], ref["R"][:M]) < tol
+
+
+# ------------------------------------------------------------------ the backward chain (k_edge_bwd_ppr)
+@pytest.fixture(scope="module")
+def bcase(case):
+    """forward saves of the whole batch (x6 kernel) + an fp64 backward FROM THOSE saves (both kernels read the same mask bits)"""
+    c = case
+    dev, topo = c["dev"], c["topo"]
+    f = dict(dtype=torch.float32, device=dev)
+    E = topo.E
+    fwd = _run(c, E, True, False)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    dOut = torch.randn(E, H, generator=gen, **f)
+    dAgg = torch.randn(topo.N, H, generator=gen, **f)
+    pk = torch.empty(4 * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+    bu = [pk.data_ptr() + u * _capi.WPACK_BYTES for u in range(4)]
+    Wh, W0 = c["Wh"], c["W0"]
+    ops.wpack([(Wh[2].data_ptr(), H, True, bu[0]), (Wh[1].data_ptr(), H, True, bu[1]), (Wh[0].data_ptr(), H, True, bu[2]), (W0.data_ptr(), 3 * H, True, bu[3])], dev)
+    d = torch.float64
+    dY = dOut.to(d) + dAgg.to(d)[topo.dst_s.long()]
+    U64, R64 = fwd["U"].to(d), fwd["R"].to(d)
+    gg = c["sc"].to(d) * dY
+    dz3 = gg / (R64[:, None] + 1e-8) - U64 * ((gg * U64).sum(1, keepdim=True) / (H * R64[:, None]))
+    dz2 = (dz3 @ Wh[2].to(d)) * (fwd["H"][2] > 0)
+    dz1 = (dz2 @ Wh[1].to(d)) * (fwd["H"][1] > 0)
+    dz0 = (dz1 @ Wh[0].to(d)) * (fwd["H"][0] > 0)
+    dE = dOut.to(d) + dz0 @ W0[:, :H].to(d)
+    return dict(fwd=fwd, dOut=dOut, dAgg=dAgg, bu=bu, pk=pk, ref=dict(dZ=[dz0, dz1, dz2, dz3], dE=dE, dYU=dY * U64))
+
+
+def _run_bwd(c, b, M, ppr):
+    dev, topo = c["dev"], c["topo"]
+    f = dict(dtype=torch.float32, device=dev)
+    old = os.environ.get("MGN_PPR")
+    os.environ["MGN_PPR"] = "2" if ppr else "0"
+    try:
+        sl = slice(0, M)
+        dZ = [torch.full((M, H), float("nan"), **f) for _ in range(4)]
+        dE = torch.full((M, H), float("nan"), **f)
+        dsc = torch.full((H,), float("nan"), **f)
+        fw = b["fwd"]
+        ops.mlp_bwd(M, H, 4, b["dOut"][sl], b["dAgg"], topo.dst_s[sl].contiguous(), H, fw["U"][sl], fw["R"][sl], c["sc"], [t[sl] for t in fw["H"]],
+                    [None] * 4, dZ, [(None, b["dOut"][sl], dE)], [None] * 4, dsc, wpk=b["bu"], Ms=[t[sl] for t in fw["M"]])
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            os.environ.pop("MGN_PPR", None)
+        else:
+            os.environ["MGN_PPR"] = old
+    return dict(dZ=dZ, dE=dE, dscale=dsc)
+
+
+@pytest.mark.parametrize("M", [0, -10, -23, 40000, 8193, 257, 129, 128, 33, 32, 31, 17, 16, 1])
+def test_ppr_edge_backward_chain_vs_fp64_and_x6(case, bcase, M):
+    """every output of the launch -- dZ[3..0], dE, dscale -- against the fp64 backward of the reference's edge update (RMSNorm
+    layers.py:104-129, build_mlp :163-210, edge_update :1044-1060) and against the x6 static-shape chain it replaces"""
+    topo, ref = case["topo"], bcase["ref"]
+    M = topo.E + M if M <= 0 else M
+    got = _run_bwd(case, bcase, M, True)
+    base = _run_bwd(case, bcase, M, False)
+    tol = 2e-6
+    for l in range(4):
+        assert _rel(got["dZ"][l], ref["dZ"][l][:M]) < tol and not bool(torch.isnan(got["dZ"][l]).any()), f"dZ[{l}]"
+        assert _rel(got["dZ"][l], base["dZ"][l].double()) < tol
+    assert _rel(got["dE"], ref["dE"][:M]) < tol and not bool(torch.isnan(got["dE"]).any())
+    assert _rel(got["dscale"], ref["dYU"][:M].sum(0)) < tol and _rel(got["dscale"], base["dscale"].double()) < 2 * tol

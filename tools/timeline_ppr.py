@@ -23,7 +23,8 @@ bs = [torch.zeros(H, **f) for _ in range(4)]
 sc = torch.ones(H, **f)
 Pd, Ps = x @ W0[:, H:2 * H].t(), x @ W0[:, 2 * H:].t()
 e_new = torch.empty(E, H, **f)
-save = len(sys.argv) > 1 and sys.argv[1] == "save"
+save = len(sys.argv) > 1 and sys.argv[1] in ("save", "bwd")
+bwd = len(sys.argv) > 1 and sys.argv[1] == "bwd"
 He = [torch.empty(E, H, **f) for _ in range(3)] if save else None
 Ue, Re = (torch.empty(E, H, **f), torch.empty(E, **f)) if save else (None, None)
 Me = [torch.empty(E, 4, dtype=torch.int32, device=dev) for _ in range(3)] if save else None
@@ -33,22 +34,35 @@ units = [pk.data_ptr() + u * _capi.WPACK_BYTES for u in range(4)]
 ops.wpack([(W0.data_ptr(), 3 * H, False, units[0])] + [(Wh[l].data_ptr(), H, False, units[l + 1]) for l in range(3)], dev)
 L = _capi.lib()
 L.mgn_debug_ppr_timeline.restype = C.c_int
-buf = (C.c_ulonglong * (2 * 1024))()
+buf = (C.c_ulonglong * (2 * 512))()
 n = (C.c_int * 2)()
+if bwd:
+    bu = [pk.data_ptr() for _ in range(4)]
+    pkb = torch.empty(4 * _capi.WPACK_BYTES, dtype=torch.uint8, device=dev)
+    bu = [pkb.data_ptr() + u * _capi.WPACK_BYTES for u in range(4)]
+    ops.wpack([(Wh[2].data_ptr(), H, True, bu[0]), (Wh[1].data_ptr(), H, True, bu[1]), (Wh[0].data_ptr(), H, True, bu[2]), (W0.data_ptr(), 3 * H, True, bu[3])], dev)
+    ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, None, He, Ue, Re, ldw0=3 * H,
+                adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units, saveM=Me, seg=(topo.dst_s, topo.rowptr_dst, agg, part))
+    dOut, dAgg = torch.randn(E, H, **f), torch.randn(N, H, **f)
+    dZ = [torch.empty(E, H, **f) for _ in range(4)]
+    dE_o, dsc = torch.empty(E, H, **f), torch.empty(H, **f)
 reps = int(os.environ.get("TL_REPS", "3"))
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(reps):
     if it == reps - 1:
         ev0.record()
-    ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, None, He, Ue, Re, ldw0=3 * H,
-                adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units, saveM=Me, seg=(topo.dst_s, topo.rowptr_dst, agg, part))
+    if bwd:
+        ops.mlp_bwd(E, H, 4, dOut, dAgg, topo.dst_s, H, Ue, Re, sc, He, [None] * 4, dZ, [(None, dOut, dE_o)], [None] * 4, dsc, wpk=bu, Ms=Me)
+    else:
+        ops.mlp_fwd(E, H, [(e, None, H)], [W0] + Wh, bs, sc, H, e, e_new, None, He, Ue, Re, ldw0=3 * H,
+                    adds=[(Pd, topo.dst_s), (Ps, topo.src_s)], wpk=units, saveM=Me, seg=(topo.dst_s, topo.rowptr_dst, agg, part))
 ev1.record()
 torch.cuda.synchronize()
 L.mgn_debug_ppr_timeline(buf, n)
-print(f"E = {E}, save = {save}, last launch {ev0.elapsed_time(ev1) * 1e3:.1f} us (with the timeline stamps)")
+print(f"E = {E}, save = {save}, bwd = {bwd}, last launch {ev0.elapsed_time(ev1) * 1e3:.1f} us (with the timeline stamps)")
 names = ["bar->M0", "M0", "bar->B0", "B0", "bar->M1", "M1", "bar->B1", "B1"]
 for hh in range(2):
-    st = [(buf[hh * 1024 + i] >> 8, int(buf[hh * 1024 + i] & 255)) for i in range(n[hh])]
+    st = [(buf[hh * 512 + i] >> 8, int(buf[hh * 512 + i] & 255)) for i in range(n[hh])]
     ngrp = sum(1 for _, t in st if t == 0)
     tot = st[-1][0] - st[0][0]
     print(f"half h={hh}: {n[hh]} stamps = {ngrp} groups; loop {tot} cycles, {tot / max(ngrp, 1):.0f} per group (2 tiles x 4 units: floor 2 x 96 x 16 x 2 = 6144)")
