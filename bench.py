@@ -286,7 +286,12 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
         return (traffic.get(key + "_read_bytes"), traffic.get(key + "_write_bytes"))
     t = "x6" if x6 else "lds<1>"
     per_step = lambda tag: tm.count(tag) // steps  # noqa: E731
-    roof = hbm_obj(f"k_mlp_fwd_{t} (edge update, training mode: W_e.e + gathered node projections, 3 Linear, RMSNorm, "
+    # the register-resident-weights generation (csrc/mgn_ppr.inc) takes fp32-grade edge launches from 65 536 rows unless MGN_PPR=0
+    # (mgn_kernels.hip: fwd_ppr_ok / bwd_ppr_ok)
+    ppr = x6 and nterm == 6 and E >= 65536 and os.environ.get("MGN_PPR", "") != "0"
+    ppr_bwd = ppr and os.environ.get("MGN_PPR_BWD", "") != "0"
+    roof = hbm_obj((f"k_edge_fwd_ppr<true> [traffic: {tnote}]" if ppr else f"k_mlp_fwd_{t} [traffic: {tnote}]") +
+                   " (edge update, training mode: W_e.e + gathered node projections, 3 Linear, RMSNorm, "
                    "residual, saves, fused aggregation)", tm.ms("edge_fwd"), b_fwd, traffic.get("edge_fwd_bytes"),
                    dict(mfma(tm.ms("edge_fwd"), nterm if x6 else 1), launches_per_step=per_step("edge_fwd"), traffic_source=tnote),
                    write_bytes=w_fwd, traffic_rw=rw("edge_fwd"))
@@ -304,7 +309,7 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
                               traffic.get("edge_bwd_fused_bytes"), dict(mf, launches_per_step=per_step("edge_bwd_fused"))))
         b_wg = row * (12 * N)                            # the node-row jobs that remain in the weight-gradient launch
     if tm.ms("edge_bwd"):
-        others.append(hbm_obj(f"k_mlp_bwd_{t} (edge backward chain: RMSNorm bwd, 3 masked dgrad GEMMs, input grad)", tm.ms("edge_bwd"), b_bwd,
+        others.append(hbm_obj(("k_edge_bwd_ppr" if ppr_bwd else f"k_mlp_bwd_{t}") + " (edge backward chain: RMSNorm bwd, 3 masked dgrad GEMMs, input grad)", tm.ms("edge_bwd"), b_bwd,
                               traffic.get("edge_bwd_bytes"), dict(mfma(tm.ms("edge_bwd"), nterm if x6 else 1), launches_per_step=per_step("edge_bwd")),
                               write_bytes=w_bwd, traffic_rw=rw("edge_bwd")))
     if tm.ms("wgrad"):
@@ -317,7 +322,7 @@ def kernel_rooflines(gp, ops, capi, eng, batch, dev, steps=3):
     if tm.ms("edge_inf"):
         # the ping-pong instance takes fp32-grade inference-mode launches from 65 536 rows unless MGN_PP=0 (mgn_kernels.hip: fwd_pp_ok)
         pp = x6 and nterm == 6 and E >= 65536 and os.environ.get("MGN_PP", "") != "0"
-        others.append(hbm_obj(("k_edge_fwd_pp<false>" if pp else f"k_mlp_fwd_{t}") + " (edge update, inference mode = the rollout's "
+        others.append(hbm_obj(("k_edge_fwd_ppr<false>" if ppr else "k_edge_fwd_pp<false>" if pp else f"k_mlp_fwd_{t}") + " (edge update, inference mode = the rollout's "
                               "dominant kernel: nothing saved, aggregation fused)", tm.ms("edge_inf"), b_inf, None,
                               dict(mfma(tm.ms("edge_inf"), nterm if x6 else 1), launches_per_rollout_step=tm.count("edge_inf") // 2),
                               write_bytes=w_inf))
@@ -614,12 +619,16 @@ def c5_record(args, gp, ops, harness, dev):
         return e0.elapsed_time(e1) / reps
 
     t_f = ev(lambda: T.SparseAttentionFn.apply(q, k, v, topo, nh))
-    b_f = 2 * 4.0 * H * E + 3 * 4.0 * H * n + 4.0 * E + 4.0 * (n + 1)      # k, v rows per edge | q read, y + lse written per node | col, rowptr
-    cache_note = {"resident": f"L2 / Infinity Cache: the gathered rows come out of three {4 * H * n / 1e6:.0f} MB matrices (q, k, v) that fit the 256 MiB "
-                              "Infinity Cache, so `achieved` is CACHE bandwidth (it may exceed what HBM delivers); the HBM-side traffic of a launch is "
-                              "the three matrices once, not two rows per edge"}
-    rec["roofline_attention"] = hbm_obj("k_attn_fwd<16> (edge-masked QK^T -> online softmax -> AV over the CSR of the mesh adjacency: two gathered "
-                                        "256-byte rows per edge; no matrix cores)", t_f, b_f, None, cache_note)
+    # COMPULSORY bytes: every matrix once (q, k, v read; y + lse written) + the adjacency -- the two gathered rows per edge come out of
+    # L2 / the Infinity Cache (three matrices of 4 H n bytes fit it) and are reported beside it as `gathered_bytes_per_launch`
+    b_f = 4 * 4.0 * H * n + 4.0 * nh * n + 4.0 * E + 4.0 * (n + 1)
+    g_f = 2 * 4.0 * H * E
+    cache_note = {"gathered_bytes_per_launch": int(g_f), "gathered_rate_gbps": round(g_f / (t_f * 1e-3) / 1e9, 1),
+                  "resident": f"the gathered k / v rows (two {4 * H}-byte rows per edge) come out of L2 / the Infinity Cache: the matrices are "
+                              f"{4 * H * n / 1e6:.0f} MB each; `achieved` prices the COMPULSORY bytes only, so frac <= 1; the kernel is bound by "
+                              "vector-instruction issue (DESIGN 4.5), not by either figure"}
+    rec["roofline_attention"] = hbm_obj("k_attn_fwd<16> (edge-masked QK^T -> online softmax -> AV over the CSR of the mesh adjacency; no matrix "
+                                        "cores)", t_f, b_f, None, cache_note, write_bytes=4.0 * H * n + 4.0 * nh * n)
     # the two backward kernels on their own: the C entry point timed directly (through autograd the interval also held the
     # zero-fills / allocations around them: 0.70 ms in situ against 0.54 ms of kernel time under rocprofv3 in round 3)
     from graph_physics_amd import _capi as capi_
@@ -636,9 +645,14 @@ def c5_record(args, gp, ops, harness, dev):
         capi_.check(rc, "mgn_sparse_attn_bwd", attn=True)
 
     t_b = ev(bwd)
-    b_b = 4.0 * H * (5 * E) + 4.0 * H * 7 * n + 4.0 * nh * 4 * E       # rows of k, v (pass A), q, dy (pass B) + a / ds per edge and head written + read
+    # compulsory: q, k, v, y, dy, lse read + dq, dk, dv written once, the per-edge weights / score gradients written by the row pass and
+    # read by the column pass, the two adjacencies; gathered rows (5 per edge) reported beside it
+    b_b = 4.0 * H * 8 * n + 4.0 * nh * n + 4.0 * nh * 4 * E + 2 * (4.0 * E + 4.0 * (n + 1)) + 8.0 * E
+    g_b = 4.0 * H * 5 * E
+    note_b = dict(cache_note, gathered_bytes_per_launch=int(g_b), gathered_rate_gbps=round(g_b / (t_b * 1e-3) / 1e9, 1))
     rec["roofline_attention_backward"] = hbm_obj("k_attn_bwd_row + k_attn_bwd_col (two passes: by row dq + per-edge attn / dscore, by column dk, dv); "
-                                                 "the two launches timed directly (mgn_sparse_attn_bwd)", t_b, b_b, None, cache_note)
+                                                 "the two launches timed directly (mgn_sparse_attn_bwd)", t_b, b_b, None, note_b,
+                                                 write_bytes=4.0 * H * 3 * n + 4.0 * nh * 2 * E)
     return rec
 
 
@@ -855,6 +869,11 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
                               f"{int(plan.send_idx.numel())} rows of {4 * args.hidden} B sent per exchange by this rank")
             r["allreduce_ms_per_step"] = round(1e3 * timed(lambda: sync(net.parameters()), 3), 3)
             r["allreduce_what"] = "flat all-reduce of every parameter gradient (11.5 MB), on its own"
+            # one forward exchange on its own (event-timed on the device), for the top-level `collective` object
+            r["halo_one_exchange_ms"] = round(1e3 * timed(lambda: halo.finish_forward(halo.start_forward(buf)), 5), 4)
+            r["halo_one_exchange_bytes_sent"] = int(plan.send_idx.numel()) * 4 * args.hidden
+            r["halo_one_exchange_bytes_received"] = int(plan.n_ghost) * 4 * args.hidden
+            r["allreduce_bytes"] = int(sum(p_.numel() for p_ in net.parameters())) * 4
         return r
 
     if world > 1:
@@ -919,8 +938,9 @@ def c4_record(args, gp, D, ops, harness, rank, world, dev):
     t_seg = ev_time(lambda: ops.segsum(m, topo.rowptr_dst, None, agg))
     b_seg = 4.0 * H * (E + n) + 4.0 * (n + 1)  # 4EH + 4NH + 4(N+1)
     from graph_physics_amd import _capi as _capi_mod
-    rec["roofline_scatter"] = hbm_obj("k_segsum<8> (forward scatter-add agg[i] = sum of the messages of node i's incoming edges, CSR order, "
-                                      "atomics-free; 3.6 GB per launch, past the 256 MiB Infinity Cache)", t_seg, b_seg,
+    rec["roofline_scatter"] = hbm_obj("k_segsum<8> AS A STAND-ALONE LAUNCH (forward scatter-add agg[i] = sum of the messages of node i's incoming "
+                                      "edges, CSR order, atomics-free; 3.6 GB per launch, past the 256 MiB Infinity Cache; inside a step the forward "
+                                      "aggregation is the edge kernel's fused epilogue and the backward scatters are roofline_scatter_backward)", t_seg, b_seg,
                                       _c4_scatter_traffic(_capi_mod), write_bytes=4.0 * H * n, traffic_rw=_c4_scatter_traffic(_capi_mod, rw=True))
     t_seg2 = ev_time(lambda: ops.segsum2(m, topo.rowptr_dst, None, agg, topo.rowptr_src, topo.perm_src, agg2))
     b_seg2 = 2 * 4.0 * H * (E + n) + 4.0 * E + 8.0 * (n + 1)
@@ -1097,9 +1117,8 @@ def main():
             "matrix_path": ("bf16 operands (one term), fp32 accumulate / RMSNorm / residuals" if args.precision == "bf16" else
                             "bf16x3 split operands, 6-term products on v_mfma_f32_16x16x32_bf16, fp32 accumulate "
                             "(fp32-grade accuracy: forward parity 1e-5 vs the CPU oracle)" if ops.X6_ENABLED else "fp32 MFMA"),
-            "config": {"workload": f"CylinderFlow-like Delaunay meshes, {args.batch} x {args.nodes} nodes per GPU batch "
-                       f"(N={N}, E={E}), {args.rounds} MP rounds, latent {args.hidden}, fp32, random-init weights; "
-                       "BASELINE.json configs[1]", "global_batch_meshes": args.batch * world, "launch": graph_note,
+            "config": {"workload": f"BASELINE.json configs[1], {'fp32' if args.precision == 'fp32' else 'bf16'}: {args.batch} x {args.nodes}-node CylinderFlow-like meshes "
+                       f"per GPU (N={N}, E={E}), {args.rounds} rounds, latent {args.hidden}, random init", "global_batch_meshes": args.batch * world, "launch": graph_note,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "rollout_node_steps_per_s": round(rollout_nps, 1),
             "rollout_ms_per_step": round(1e3 * dt_r / args.rollout_steps, 3), "rollout_launch": rollout_note,
@@ -1157,10 +1176,15 @@ def main():
             wd_done = threading.Event()
 
             def bail(why):
+                # a plain process exit (never a re-exec: this process has touched the GPU).  Rank 0 prints the headline it has measured
+                # and leaves with 0; every other rank leaves NON-ZERO -- the launcher's return code then shows that the partitioned
+                # record failed -- and ten seconds later, so that the launcher's clean-up of its peers cannot cut off rank 0's line
                 if rank == 0:
                     out["c4"] = {"error": why}
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                    os._exit(0)
+                time.sleep(10.0)
+                os._exit(3)
 
             def watchdog():
                 if not wd_done.wait(float(os.environ.get("MGN_BENCH_C4_DEADLINE_S", "480"))):
@@ -1185,10 +1209,28 @@ def main():
             wd_done.set()
         if rank == 0:
             out["c4"] = c4
+            if world > 1 and isinstance(c4, dict):
+                import torch.distributed as dist_
+                try:
+                    rccl_v = ".".join(str(v_) for v_ in torch.cuda.nccl.version())
+                except Exception:  # noqa: BLE001
+                    rccl_v = None
+                out["collective"] = {
+                    "backend": dist_.get_backend(), "world_size_seen_by_process_group": dist_.get_world_size(), "rccl_version": rccl_v,
+                    "halo_exchange": {"what": "ONE forward exchange of ghost-node latents of the partitioned 1M-node mesh (pack, all_to_all_single, "
+                                              "unpack), rank 0, on its own, HIP events",
+                                      "bytes_sent_rank0": c4.get("halo_one_exchange_bytes_sent"), "bytes_received_rank0": c4.get("halo_one_exchange_bytes_received"),
+                                      "ms": c4.get("halo_one_exchange_ms"), "exchanges_per_training_step": 2 * args.rounds},
+                    "gradient_all_reduce": {"what": "flat all-reduce of every parameter gradient, on its own, HIP events",
+                                            "bytes": c4.get("allreduce_bytes"), "ms": c4.get("allreduce_ms_per_step")},
+                    "headline_gradient_sync": "bucketed all-reduce inside the backward pass (OverlappedGradAllReduce: three collectives of 3-4 MB per step on "
+                                              "a side stream)"}
             # the north-star scatter-add figure (>= 40 % of the HBM roofline past the Infinity Cache) as a top-level key: a reader of
             # the parsed line need not open the nested record
             if isinstance(c4, dict) and "roofline_scatter" in c4:
                 out["roofline_scatter_c4"] = c4["roofline_scatter"]
+                if "roofline_scatter_backward" in c4:   # ... and the launch a training step really runs at this size (k_segsum2)
+                    out["roofline_scatter_c4_in_step"] = c4["roofline_scatter_backward"]
             if c5dp is not None:
                 out["c5"] = c5dp
     if rank == 0:

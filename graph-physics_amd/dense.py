@@ -301,8 +301,10 @@ class GatedMlpResidualFn(torch.autograd.Function):
         dev = x.device
         f = dict(dtype=torch.float32, device=dev)
         need = any(ctx.needs_input_grad) and ops._saving()
-        # bf16 mode: the pre-activations are bf16 numbers -- kept as two-byte rows (exact; MGN_DENSE_SAVE16=0: fp32 rows)
-        z16 = precision == 1 and _SAVE16[0]
+        # bf16 mode: the pre-activations are bf16 numbers -- kept as two-byte rows (exact; MGN_DENSE_SAVE16=0: fp32 rows).  Only where every
+        # weight-gradient job of the backward lands on the row-vector kernel (mgn_wgrad_p takes two-byte rows in 64-wide slabs or as
+        # packed full 128 x 128 jobs with ld = -128, not the -384-strided 128-column slabs _wgrad_jobs cuts at hidden 128)
+        z16 = precision == 1 and _SAVE16[0] and min(int(W1.shape[0]), int(x.shape[1])) <= 64
         zt = dict(dtype=torch.bfloat16 if z16 else torch.float32, device=dev)
         Z1 = torch.empty(M, N, **zt) if need else None
         Z2 = torch.empty(M, N, **zt) if need else None

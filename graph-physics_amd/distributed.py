@@ -335,6 +335,7 @@ class PartitionedEPD(torch.nn.Module):
         # argument and never inferred from the tensor a rank happens to pass.  Owned rows always come from the current pos_own.
         self.cache_positions = bool(cache_positions)
         self._pos_full = None
+        self._pos_ghost = None
         # what the un-partitioned forward would apply and this path does not: refuse instead of silently
         # computing another function (processors.py:203-209: the temporal block attends over ALL nodes' previous latents)
         if getattr(model, "use_temporal_block", False) or getattr(model, "temporal_block", None) is not None:
@@ -344,6 +345,7 @@ class PartitionedEPD(torch.nn.Module):
         """drop the cached ghost positions (``cache_positions=True``): the next forward exchanges them again -- call it on
         EVERY rank (the exchange is a collective)"""
         self._pos_full = None
+        self._pos_ghost = None
 
     def forward(self, x_in_own: torch.Tensor, edge_attr_loc: torch.Tensor, phi_own: Optional[torch.Tensor] = None,
                 pos_own: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -362,11 +364,13 @@ class PartitionedEPD(torch.nn.Module):
             if pos_own.shape[0] != plan.n_own:
                 raise ValueError("pos_own must hold one row per owned node")
             p_own = pos_own.detach().to(dev, torch.float32).contiguous()
-            if (not self.cache_positions or self._pos_full is None or self._pos_full.device != dev
-                    or self._pos_full.shape[1] != p_own.shape[1]):
-                self._pos_full = torch.cat([p_own, HaloExchange.apply(p_own, plan, self.group)], dim=0)
-            else:
-                self._pos_full[: plan.n_own].copy_(p_own)
+            # cache_positions: only the GHOST rows are cached; every forward builds a fresh tensor (a tensor written in place would trip
+            # autograd's version check -- or silently show newer positions to a RoPE node that kept the raw pointer -- when two
+            # forwards precede one backward: gradient accumulation)
+            if (not self.cache_positions or self._pos_ghost is None or self._pos_ghost.device != dev
+                    or self._pos_ghost.shape[1] != p_own.shape[1]):
+                self._pos_ghost = HaloExchange.apply(p_own, plan, self.group)
+            self._pos_full = torch.cat([p_own, self._pos_ghost], dim=0)
         if self._ctx is None:
             self._ctx = be.prepare(plan.edge_index.to(dev), plan.n_own + plan.n_ghost)
         x_own = be.mlp(m.nodes_encoder, x_in_own)
@@ -423,12 +427,14 @@ class PartitionedETD(torch.nn.Module):
         self.backend = backend    # None: the HIP engine (the model's own Transformer modules)
         self.cache_positions = bool(cache_positions)
         self._pos_full = None
+        self._pos_ghost = None
         self._topo = None
         if getattr(model, "use_temporal_block", False) or getattr(model, "temporal_block", None) is not None:
             raise NotImplementedError("PartitionedETD: use_temporal_block is not supported on a partitioned mesh")
 
     def invalidate_positions(self) -> None:
         self._pos_full = None
+        self._pos_ghost = None
 
     def local_edge_index(self) -> torch.Tensor:
         """the rank's edges as (row, column) of the attention in local numbering: rows are owned nodes"""
@@ -445,11 +451,13 @@ class PartitionedETD(torch.nn.Module):
             if pos_own.shape[0] != plan.n_own:
                 raise ValueError("pos_own must hold one row per owned node")
             p_own = pos_own.detach().to(dev, torch.float32).contiguous()
-            if (not self.cache_positions or self._pos_full is None or self._pos_full.device != dev
-                    or self._pos_full.shape[1] != p_own.shape[1]):
-                self._pos_full = torch.cat([p_own, HaloExchange.apply(p_own, plan, self.group)], dim=0)
-            else:
-                self._pos_full[: plan.n_own].copy_(p_own)
+            # cache_positions: only the GHOST rows are cached; every forward builds a fresh tensor (a tensor written in place would trip
+            # autograd's version check -- or silently show newer positions to a RoPE node that kept the raw pointer -- when two
+            # forwards precede one backward: gradient accumulation)
+            if (not self.cache_positions or self._pos_ghost is None or self._pos_ghost.device != dev
+                    or self._pos_ghost.shape[1] != p_own.shape[1]):
+                self._pos_ghost = HaloExchange.apply(p_own, plan, self.group)
+            self._pos_full = torch.cat([p_own, self._pos_ghost], dim=0)
             pos_full = self._pos_full
         ei = self.local_edge_index().to(dev)
         n_loc = plan.n_own + plan.n_ghost

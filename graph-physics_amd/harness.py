@@ -378,22 +378,28 @@ class Engine:
         if seen is None:
             seen = self._r_seen = {}
 
-        def put(name, dst, src):
+        def put(name, dst, src, may_skip):
+            # (the skip is for the MESH's fields only -- edge features, positions: tensors nobody refills in place; x / y are copied
+            # every frame: the engine's own kernels write through raw pointers without bumping _version)
             last = seen.get(name)
-            if src is dst or (last is not None and last[0] is src and last[1] == src._version):
+            if src is dst or (may_skip and last is not None and last[0] is src and last[1] == src._version):
                 return
             dst.copy_(src, non_blocking=True)
             seen[name] = (src, src._version)
 
         for k, fr in enumerate(frames):
             if fr is not st:
-                put("x", st.x, fr.x)
-                put("y", st.y, fr.y)
-                put("edge_attr", st.edge_attr, fr.edge_attr)
+                put("x", st.x, fr.x, False)
+                put("y", st.y, fr.y, False)
+                put("edge_attr", st.edge_attr, fr.edge_attr, True)
+                # a deforming mesh: positions are per frame (relative RoPE reads them inside the captured step)
+                if st.pos is not None and getattr(fr, "pos", None) is not None:
+                    put("pos", st.pos, fr.pos, True)
             if k == 0:
                 self._r_last.copy_(fr.x[:, i0:i1])
             self._r_graph.replay()
             out.append(self._r_pred.clone())
+        self._r_seen = {}   # (no frame tensor stays referenced by the engine after the call)
         return out
 
     #: ``rollout(..., graph="auto")`` replays a captured step when the trajectory has at least this many frames on ONE mesh of at
@@ -413,7 +419,13 @@ class Engine:
                 return None
             if fr.x.shape != f0.x.shape or fr.edge_attr.shape != f0.edge_attr.shape or fr.y.shape != f0.y.shape:
                 return None
-        return (ei.data_ptr(), ei._version, tuple(ei.shape), tuple(f0.x.shape), tuple(f0.edge_attr.shape), tuple(f0.y.shape))
+        from . import ops
+        has_pos = getattr(f0, "pos", None) is not None
+        for fr in frames:   # positions present for all frames or for none (the captured step is built for one of the two)
+            if (getattr(fr, "pos", None) is not None) != has_pos:
+                return None
+        return (ei.data_ptr(), ei._version, tuple(ei.shape), tuple(f0.x.shape), tuple(f0.edge_attr.shape), tuple(f0.y.shape), has_pos,
+                ops.get_matrix_precision())
 
     @torch.no_grad()
     def rollout(self, frames: Sequence[Graph], graph: str = "auto") -> List[torch.Tensor]:
@@ -432,9 +444,13 @@ class Engine:
             if graph == "on" and key is None:
                 raise ValueError("rollout(graph='on') needs frames of one shape on one edge_index tensor")
             if key is not None and (graph == "on" or small):
-                if getattr(self, "_r_key", None) != key or getattr(self, "_r_graph", None) is None:
+                # the keyed edge_index is kept REFERENCED and compared by identity: an address alone may be recycled by the allocator
+                # for another trajectory's topology of the same size
+                if (getattr(self, "_r_key", None) != key or getattr(self, "_r_graph", None) is None
+                        or getattr(self, "_r_ei", None) is not frames[0].edge_index):
                     self.capture_rollout_step(frames[0])
                     self._r_key = key
+                    self._r_ei = frames[0].edge_index
                 return self.rollout_graphed(frames)
         last, out = None, []
         for fr in frames:

@@ -213,18 +213,21 @@ def test_six_term_dense_launch_vs_fp64(dev, K, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H", [64, 128])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_gated_mlp_block_on_the_six_term_launches_vs_oracle(dev, mode, fused):
+def test_gated_mlp_block_on_the_six_term_launches_vs_oracle(dev, mode, fused, H):
     """x + gated_mlp(norm2(x)) of a Transformer block (layers.py:256-278, 700-819) at 70 001 rows -- every Linear on k_linear_x6
     (six terms in fp32 mode, its one-piece form in bf16 mode), the input gradients through the transposed staging -- forward and
     every gradient against the oracle's restatement (oracle.gated_mlp / rms_norm; bf16 mode: under oracle.bf16_mixed, judged like the
-    other bf16-mode tests on the tensor's scale).  ``fused``: dense.GatedMlpResidualFn instead of the separate autograd nodes."""
+    other bf16-mode tests on the tensor's scale).  ``fused``: dense.GatedMlpResidualFn instead of the separate autograd nodes.
+    H = 128 (the reference's default hidden size): the fused node's bf16 mode keeps fp32 saves there (its weight-gradient slabs are
+    128 wide: no two-byte form) -- the shape that raised in the backward pass before round 6."""
     import graph_physics_amd as gp
     from graph_physics_amd import ops, transformer as T
     from oracle import mgn_oracle as O
     torch.manual_seed(5)
-    M, H = 70001, 64
+    M = 70001
     blk = T.Transformer(H, H, 4, activation_layer=torch.nn.GELU).to(dev)
     with torch.no_grad():
         for p_ in blk.parameters():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # device assembly of csrc/mgn_kernels.hip -> /tmp/mgn_kernels.s (+ resource usage remarks in /tmp/mgn_kernels.rep); $1 = a kernel's mangled-name
 # substring: its body is extracted to /tmp/k.s
-cd /root/repo/graph-physics_amd/csrc
+cd "$(dirname "$0")/../graph-physics_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops -I../../include -S --cuda-device-only -o /tmp/mgn_kernels.s mgn_kernels.hip -Rpass-analysis=kernel-resource-usage "${@:2}" > /tmp/mgn_kernels.rep 2>&1
 grep -i "error" /tmp/mgn_kernels.rep | head
 if [ -n "$1" ]; then

@@ -10,6 +10,7 @@ fd, wd, tag = sys.argv[1:4]
 # (kernel-name prefix, workgroups or None) -> key.  Prefixes stop before the closing '>' (k_segsum2<8, false> since round 4: the old
 # "k_segsum2<8>" key matched nothing and the bench line carried traffic 0 for the scatter)
 KEYS = {("k_mlp_fwd_x6<6, 4, 0", 512): "edge_fwd", ("k_mlp_bwd_x6<6, false, 0", 512): "edge_bwd", ("k_wgrad_x6", 512): "wgrad",
+        ("k_edge_fwd_ppr<true", 256): "edge_fwd", ("k_edge_bwd_ppr", 256): "edge_bwd",   # [r6] the register-resident-weights generation
         ("k_wgrad_pc", 256): "wgrad", ("k_segsum2<8", None): "segsum", ("__amd_rocclr_copyBuffer", None): "calibration_copy"}
 def collect(d, counter):
     acc = defaultdict(list)
