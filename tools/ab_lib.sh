@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/.."
 for rep in $(seq 1 ${REPS:-2}); do
   for v in "$@"; do
-    MGN_LIB=tools/libexp_$v.so python bench.py --no-cpu-baseline --no-c4 2>/dev/null | tail -1 | python -c "
+    MGN_LIB=tools/libexp_$v.so python bench.py --no-cpu-baseline --no-c4 ${AB_EXTRA:---no-extras} 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 o=d['roofline_other_kernels']

@@ -112,6 +112,18 @@ for M in sizes:
         print(line, flush=True)
 print("ACCURACY vs fp64 (ppr, x6 in brackets):", "OK" if ok else "FAILED")
 
+def rotating(save, pp, K=6):
+    """K sets of output tensors used in turn: every launch writes memory no earlier launch of the loop has left in a cache -- what a
+    training step does (15 rounds, fresh saves each); the same buffers over and over flatter the write path by ~20 %"""
+    fns = [run(E, save, pp)[1] for _ in range(K)]
+    state = [0]
+
+    def fn():
+        fns[state[0] % K]()
+        state[0] += 1
+    return fn
+
+
 for save in (False, True):
     for rep in range(2):
         for pp in (0, 1, 2):
@@ -119,4 +131,11 @@ for save in (False, True):
                 continue
             _, fn = run(E, save, pp)
             t = timeit(fn)
+            if save:
+                os.environ["MGN_PP"] = "2" if pp == 1 else "0"
+                os.environ["MGN_PPR"] = "2" if pp == 2 else "0"
+                tr = timeit(rotating(save, pp), iters=18)
+                print(f"{('x6 static', 'ping-pong', 'ppr')[pp]:10s} save={int(save)} {tr*1e3:8.1f} us  with 6 rotating sets of outputs", flush=True)
+                os.environ["MGN_PP"] = "2" if pp == 1 else "0"
+                os.environ["MGN_PPR"] = "2" if pp == 2 else "0"
             print(f"{('x6 static', 'ping-pong', 'ppr')[pp]:10s} save={int(save)} {t*1e3:8.1f} us  {6 * 8.0*E*H*H/t/1e9:7.1f} TFLOP/s bf16", flush=True)

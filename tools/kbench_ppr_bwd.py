@@ -88,8 +88,21 @@ for M in sizes:
         ok = ok and good
     print(line, flush=True)
 print("ACCURACY vs fp64 (ppr, x6 in brackets):", "OK" if ok else "FAILED")
+def rotating(ppr, K=6):
+    fns = [run(E, ppr)[1] for _ in range(K)]
+    state = [0]
+
+    def fn():
+        fns[state[0] % K]()
+        state[0] += 1
+    return fn
+
+
 for rep in range(2):
     for ppr in (False, True):
+        os.environ["MGN_PPR"] = "2" if ppr else "0"
+        tr = timeit(rotating(ppr), iters=18)
+        print(f"{'ppr' if ppr else 'x6 static':10s} bwd chain {tr*1e3:8.1f} us  with 6 rotating sets of outputs", flush=True)
         _, fn = run(E, ppr)
         t = timeit(fn)
         print(f"{'ppr' if ppr else 'x6 static':10s} bwd chain {t*1e3:8.1f} us  {6 * 8.0*E*H*H/t/1e9:7.1f} TFLOP/s bf16", flush=True)
