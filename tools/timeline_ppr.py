@@ -34,7 +34,7 @@ units = [pk.data_ptr() + u * _capi.WPACK_BYTES for u in range(4)]
 ops.wpack([(W0.data_ptr(), 3 * H, False, units[0])] + [(Wh[l].data_ptr(), H, False, units[l + 1]) for l in range(3)], dev)
 L = _capi.lib()
 L.mgn_debug_ppr_timeline.restype = C.c_int
-buf = (C.c_ulonglong * (2 * 512))()
+buf = (C.c_ulonglong * (2 * 160))()
 n = (C.c_int * 2)()
 if bwd:
     bu = [pk.data_ptr() for _ in range(4)]
@@ -62,7 +62,7 @@ L.mgn_debug_ppr_timeline(buf, n)
 print(f"E = {E}, save = {save}, bwd = {bwd}, last launch {ev0.elapsed_time(ev1) * 1e3:.1f} us (with the timeline stamps)")
 names = ["bar->M0", "M0", "bar->B0", "B0", "bar->M1", "M1", "bar->B1", "B1"]
 for hh in range(2):
-    st = [(buf[hh * 512 + i] >> 8, int(buf[hh * 512 + i] & 255)) for i in range(n[hh])]
+    st = [(buf[hh * 160 + i] >> 8, int(buf[hh * 160 + i] & 255)) for i in range(n[hh])]
     ngrp = sum(1 for _, t in st if t == 0)
     tot = st[-1][0] - st[0][0]
     print(f"half h={hh}: {n[hh]} stamps = {ngrp} groups; loop {tot} cycles, {tot / max(ngrp, 1):.0f} per group (2 tiles x 4 units: floor 2 x 96 x 16 x 2 = 6144)")
