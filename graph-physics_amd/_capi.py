@@ -240,6 +240,8 @@ SYMBOLS = {
     "mgn_sparse_attn_bwd_s": (C.c_int, [C.c_void_p, C.c_int64] * 3 + [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int64, C.c_int, C.c_int]
                               + [C.c_void_p, C.c_int64] * 3 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "mgn_sparse_attn_weights": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mgn_head_axis_attn_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3),
+    "mgn_head_axis_attn_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 4),
     "mgn_attn_last_error": (C.c_char_p, []),
     "mgn_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "mgn_linear_accepts_transposed": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),

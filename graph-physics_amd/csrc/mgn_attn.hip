@@ -640,3 +640,192 @@ extern "C" int mgn_sparse_attn_weights(const float* q, const float* k, const flo
   ATTN_DISPATCH(k_attn_weights, 0, q, k, lse, rowptr, col, out_pos, (long)N, num_heads, scale, attn);
   return acheck("mgn_sparse_attn_weights");
 }
+
+// =====================================================================================================================
+// [r6] Attention over the HEAD axis of one node: what the reference's scaled_dot_product_attention computes when it is
+// handed no adjacency (layers.py:493-559 with att_mask = None: attn = softmax(q k^T / sqrt(d)) over the LAST axis of
+// [N, d, d], y = attn v) -- the TemporalAttention of an installation without DGL (processors.py:203-209,376-377 pass
+// adj = None).  q / k / v rows are [d, NH] (feature f = i * NH + h): S[i][j] = sum_h q[i][h] k[j][h] / sqrt(d), softmax
+// over j, y[i][h] = sum_j P[i][j] v[j][h]; no node reads another node's rows.  A few hundred flops per output value on
+// rows that are read once: one thread per (node, i), the node's k / v rows broadcast out of LDS, fixed summation order
+// (forward and backward are bit-reproducible; the backward's column pass recomputes the weights instead of adding
+// atomically).
+// =====================================================================================================================
+#define HAX_THREADS 128
+
+template <int NH>
+__global__ __launch_bounds__(HAX_THREADS) void k_head_axis_attn_fwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                                    const float* __restrict__ v, long N, int d, float sd,
+                                                                    float* __restrict__ y, float* __restrict__ lse) {
+  extern __shared__ float hax_lds[];
+  const int H = d * NH, nb = HAX_THREADS / d;
+  const long n0 = (long)blockIdx.x * nb;
+  const int nn = (int)min((long)nb, N - n0);
+  float* K = hax_lds;
+  float* V = hax_lds + nb * H;
+  for (int t = threadIdx.x; t < nn * H; t += HAX_THREADS) {
+    K[t] = k[n0 * H + t];
+    V[t] = v[n0 * H + t];
+  }
+  __syncthreads();
+  const int ln = threadIdx.x / d, i = threadIdx.x - ln * d;
+  if (ln >= nn) return;
+  const long n = n0 + ln;
+  float qi[NH], acc[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    qi[h] = q[n * H + i * NH + h] / sd;   // layers.py:509-510: the query is divided first
+    acc[h] = 0.f;
+  }
+  const float* Kn = K + ln * H;
+  const float* Vn = V + ln * H;
+  float m = -INFINITY, l = 0.f;
+  for (int j = 0; j < d; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) s = fmaf(qi[h], Kn[j * NH + h], s);
+    const float mn = fmaxf(m, s), c = expf(m - mn), p = expf(s - mn);
+    l = l * c + p;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) acc[h] = fmaf(p, Vn[j * NH + h], acc[h] * c);
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int h = 0; h < NH; ++h) y[n * H + i * NH + h] = acc[h] * inv;
+  lse[n * d + i] = m + logf(l);
+}
+
+template <int NH>
+__global__ __launch_bounds__(HAX_THREADS) void k_head_axis_attn_bwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                                    const float* __restrict__ v, const float* __restrict__ y,
+                                                                    const float* __restrict__ lse, const float* __restrict__ dy, long N,
+                                                                    int d, float sd, float* __restrict__ dq, float* __restrict__ dk,
+                                                                    float* __restrict__ dv) {
+  extern __shared__ float hax_lds[];
+  const int H = d * NH, nb = HAX_THREADS / d;
+  const long n0 = (long)blockIdx.x * nb;
+  const int nn = (int)min((long)nb, N - n0);
+  float* Q = hax_lds;                 // the SCALED queries
+  float* K = Q + nb * H;
+  float* V = K + nb * H;
+  float* G = V + nb * H;              // dy
+  float* L = G + nb * H;              // lse  [nb][d]
+  float* D = L + nb * d;              // sum_h dy[i][h] y[i][h]  [nb][d]
+  for (int t = threadIdx.x; t < nn * H; t += HAX_THREADS) {
+    Q[t] = q[n0 * H + t] / sd;
+    K[t] = k[n0 * H + t];
+    V[t] = v[n0 * H + t];
+    G[t] = dy[n0 * H + t];
+  }
+  const int ln = threadIdx.x / d, i = threadIdx.x - ln * d;
+  const bool live = ln < nn;
+  const long n = n0 + ln;
+  if (live) {
+    float dsum = 0.f;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) dsum = fmaf(dy[n * H + i * NH + h], y[n * H + i * NH + h], dsum);
+    D[ln * d + i] = dsum;
+    L[ln * d + i] = lse[n * d + i];
+  }
+  __syncthreads();
+  if (!live) return;
+  const float* Qn = Q + ln * H;
+  const float* Kn = K + ln * H;
+  const float* Vn = V + ln * H;
+  const float* Gn = G + ln * H;
+  {  // row pass: dq[i] = sum_j dS[i][j] k[j] / sqrt(d)
+    float qi[NH], gi[NH], a[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      qi[h] = Qn[i * NH + h];
+      gi[h] = Gn[i * NH + h];
+      a[h] = 0.f;
+    }
+    const float li = L[ln * d + i], di = D[ln * d + i];
+    for (int j = 0; j < d; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        s = fmaf(qi[h], Kn[j * NH + h], s);
+        dp = fmaf(gi[h], Vn[j * NH + h], dp);
+      }
+      const float ds = expf(s - li) * (dp - di);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) a[h] = fmaf(ds, Kn[j * NH + h], a[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) dq[n * H + i * NH + h] = a[h] / sd;
+  }
+  {  // column pass (this thread is column j = i): dk[j] = sum_i dS[i][j] q_scaled[i], dv[j] = sum_i P[i][j] dy[i]
+    const int j = i;
+    float kj[NH], vj[NH], ak[NH], av[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      kj[h] = Kn[j * NH + h];
+      vj[h] = Vn[j * NH + h];
+      ak[h] = 0.f;
+      av[h] = 0.f;
+    }
+    for (int r = 0; r < d; ++r) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        s = fmaf(Qn[r * NH + h], kj[h], s);
+        dp = fmaf(Gn[r * NH + h], vj[h], dp);
+      }
+      const float p = expf(s - L[ln * d + r]), ds = p * (dp - D[ln * d + r]);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        ak[h] = fmaf(ds, Qn[r * NH + h], ak[h]);
+        av[h] = fmaf(p, Gn[r * NH + h], av[h]);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      dk[n * H + j * NH + h] = ak[h];   // Q holds q / sqrt(d) already
+      dv[n * H + j * NH + h] = av[h];
+    }
+  }
+}
+
+static int hax_args_ok(int64_t N, int H, int NH) {
+  if (N < 0 || H <= 0 || H > 1024) return 0;
+  if (!(NH == 1 || NH == 2 || NH == 4 || NH == 8 || NH == 16) || H % NH != 0) return 0;
+  return H / NH <= HAX_THREADS;
+}
+
+#define HAX_LAUNCH(KERNEL, LDS, ...)                                                                            \
+  switch (num_heads) {                                                                                          \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(HAX_THREADS), LDS, s, __VA_ARGS__); break;         \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(HAX_THREADS), LDS, s, __VA_ARGS__); break;         \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(HAX_THREADS), LDS, s, __VA_ARGS__); break;         \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(grid), dim3(HAX_THREADS), LDS, s, __VA_ARGS__); break;         \
+    default: hipLaunchKernelGGL((KERNEL<16>), dim3(grid), dim3(HAX_THREADS), LDS, s, __VA_ARGS__); break;       \
+  }
+
+extern "C" int mgn_head_axis_attn_fwd(const float* q, const float* k, const float* v, int64_t N, int H, int num_heads, float* y,
+                                      float* lse, void* stream) {
+  if (!hax_args_ok(N, H, num_heads) || (N > 0 && (!q || !k || !v || !y || !lse)))
+    return afail(1, "mgn_head_axis_attn_fwd: num_heads must be 1/2/4/8/16 and divide hidden, hidden / num_heads <= 128");
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int d = H / num_heads, nb = HAX_THREADS / d;
+  const unsigned grid = (unsigned)((N + nb - 1) / nb);
+  const size_t lds = (size_t)2 * nb * H * sizeof(float);
+  HAX_LAUNCH(k_head_axis_attn_fwd, lds, q, k, v, (long)N, d, sqrtf((float)d), y, lse);
+  return acheck("mgn_head_axis_attn_fwd");
+}
+
+extern "C" int mgn_head_axis_attn_bwd(const float* q, const float* k, const float* v, const float* y, const float* lse, const float* dy,
+                                      int64_t N, int H, int num_heads, float* dq, float* dk, float* dv, void* stream) {
+  if (!hax_args_ok(N, H, num_heads) || (N > 0 && (!q || !k || !v || !y || !lse || !dy || !dq || !dk || !dv)))
+    return afail(1, "mgn_head_axis_attn_bwd: num_heads must be 1/2/4/8/16 and divide hidden, hidden / num_heads <= 128");
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int d = H / num_heads, nb = HAX_THREADS / d;
+  const unsigned grid = (unsigned)((N + nb - 1) / nb);
+  const size_t lds = ((size_t)4 * nb * H + 2 * nb * d) * sizeof(float);
+  HAX_LAUNCH(k_head_axis_attn_bwd, lds, q, k, v, y, lse, dy, (long)N, d, sqrtf((float)d), dq, dk, dv);
+  return acheck("mgn_head_axis_attn_bwd");
+}

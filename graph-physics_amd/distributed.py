@@ -322,10 +322,12 @@ class PartitionedEPD(torch.nn.Module):
     forward(x_in_own[n_own,F_n], edge_attr_loc[E_loc,F_e]) -> out_own[n_own,O]
     """
 
-    def __init__(self, model, plan, group=None, backend=None, cache_positions: bool = False):
+    def __init__(self, model, plan, group=None, backend=None, cache_positions: bool = False, temporal_plan=None):
         super().__init__()
         self.model, self.plan, self.group = model, plan, group
         self.backend = backend if backend is not None else HipBackend()
+        self.temporal_plan = temporal_plan
+        self._ttopo, self._t_of, self._t_inv = None, None, None
         self._ctx = None
         self._halo = None
         # [n_own + n_ghost, D]: owned positions + the ghosts'.  The ghosts' rows are exchanged on EVERY forward (one small
@@ -336,10 +338,28 @@ class PartitionedEPD(torch.nn.Module):
         self.cache_positions = bool(cache_positions)
         self._pos_full = None
         self._pos_ghost = None
-        # what the un-partitioned forward would apply and this path does not: refuse instead of silently
-        # computing another function (processors.py:203-209: the temporal block attends over ALL nodes' previous latents)
-        if getattr(model, "use_temporal_block", False) or getattr(model, "temporal_block", None) is not None:
-            raise NotImplementedError("PartitionedEPD: use_temporal_block is not supported on a partitioned mesh")
+        # the temporal block (processors.py:183-184, :203-209) attends along ROWS of spmatrix(indices=edge_index): row i = the edges
+        # whose SOURCE is i, columns = their destinations -- the other end of the edges this rank holds (it holds the edges whose
+        # DESTINATION it owns).  So it needs a second plan, built on the flipped edge list with the same partition vector:
+        #     temporal_plan = partition.build_rank_plan(edge_index.flip(0), part, rank, world)
+        # (its "destination" is the attention row, its ghosts the columns this rank does not own; on a mesh whose edge list holds both
+        # directions of every edge the two plans have the same ghosts).  Without DGL the reference hands the block no adjacency and
+        # it is row-wise (attention_backend == "pyg"): no plan needed.
+        self._temporal = bool(getattr(model, "use_temporal_block", False)) and getattr(model, "temporal_block", None) is not None
+        if self._temporal and getattr(model, "attention_backend", "dgl") == "dgl":
+            if temporal_plan is None:
+                raise ValueError("PartitionedEPD: a model with use_temporal_block needs temporal_plan = "
+                                 "build_rank_plan(edge_index.flip(0), part, rank, world)")
+            o1, o2 = plan.owned.cpu(), temporal_plan.owned.cpu()
+            s1, s2 = torch.argsort(o1), torch.argsort(o2)
+            if o1.numel() != o2.numel() or not torch.equal(o1[s1], o2[s2]):
+                raise ValueError("PartitionedEPD: temporal_plan must be built with the same partition vector as plan")
+            # both plans list the owned nodes interior-first, and "interior" depends on the direction: position of each of
+            # temporal_plan's owned nodes in plan's numbering (None: the same order, every mesh with both directions of each edge)
+            t_of = torch.empty_like(s1)
+            t_of[s2] = s1
+            self._t_of = None if torch.equal(t_of, torch.arange(t_of.numel())) else t_of
+            self._t_inv = None if self._t_of is None else torch.argsort(t_of)
 
     def invalidate_positions(self) -> None:
         """drop the cached ghost positions (``cache_positions=True``): the next forward exchanges them again -- call it on
@@ -377,16 +397,21 @@ class PartitionedEPD(torch.nn.Module):
         e = be.mlp(m.edges_encoder, be.order_edges(edge_attr_loc, self._ctx))
         blocks = list(m.processor_list)
         fused = getattr(be, "fused", False) and blocks and m.hidden_size == 128 and not m.use_rope and not m.use_gated_mlp
+        prev_own = x_own
         if fused:
             from . import ops
             from .layers import _block_params
             if self._halo is None:
                 self._halo = HaloState(plan, dev, self.group)
-            params = []
-            for blk in blocks:
-                params += _block_params(blk)
-            x_own, _ = ops.processor_apply(x_own, e, self._ctx, len(blocks), *params, spec=blocks[0].spec, halo=self._halo,
-                                           phi=phi_own)
+            # the temporal block needs the node latents BEFORE the last round too (processors.py:193-209): two autograd nodes then
+            groups = [blocks] if not (self._temporal and len(blocks) > 1) else [blocks[:-1], blocks[-1:]]
+            for grp in groups:
+                prev_own = x_own
+                params = []
+                for blk in grp:
+                    params += _block_params(blk)
+                x_own, e = ops.processor_apply(x_own, e, self._ctx, len(grp), *params, spec=grp[0].spec, halo=self._halo,
+                                               phi=phi_own)
         else:
             # per-block path (RoPE, gated-MLP blocks, widths off the packed kernels): the ghost LATENTS are exchanged before
             # every block (HaloExchange: differentiable, fixed-order backward), the block runs on owned + ghost rows and the
@@ -396,11 +421,40 @@ class PartitionedEPD(torch.nn.Module):
             if phi_own is not None:
                 phi_full = torch.cat([phi_own.reshape(-1).to(dev, torch.float32), torch.zeros(plan.n_ghost, device=dev)])
             for blk in blocks:
+                prev_own = x_own
                 x_gh = HaloExchange.apply(x_own, plan, self.group)
                 x_full = torch.cat([x_own, x_gh], dim=0)
                 x_full, e = be.block(blk, x_full, e, self._ctx, pos=self._pos_full if use_rope else None, phi=phi_full)
                 x_own = x_full[: plan.n_own]
+        if self._temporal:
+            x_own = self._temporal_tail(prev_own, x_own, dev)
         return be.mlp(m.decode_module, x_own)
+
+    def _temporal_tail(self, prev_own: torch.Tensor, last_own: torch.Tensor, dev) -> torch.Tensor:
+        """processors.py:203-209: x = temporal_block(prev_x, last_x, adj) on the owned rows.  Row i attends over the edges whose
+        source is i (``temporal_plan``: the flipped edge list); k comes from prev_x, q / v from last_x, so the ghosts of BOTH
+        travel -- as one exchange of [prev | last] rows; the ghosts' own output rows are dropped."""
+        m, be, tb = self.model, self.backend, self.model.temporal_block
+        if getattr(m, "attention_backend", "dgl") != "dgl":      # no DGL: no adjacency, the block is row-wise
+            return tb(prev_own, last_own, None) if isinstance(be, HipBackend) else be.temporal_block(tb, prev_own, last_own, None)
+        tp = self.temporal_plan
+        if self._t_of is not None:
+            idx = self._t_of.to(dev)
+            prev_own, last_own = prev_own.index_select(0, idx), last_own.index_select(0, idx)
+        h = prev_own.shape[1]
+        both = torch.cat([prev_own, last_own], dim=1)
+        both = torch.cat([both, HaloExchange.apply(both, tp, self.group)], dim=0)
+        prev_full, last_full = both[:, :h].contiguous(), both[:, h:].contiguous()
+        ei = tp.edge_index.flip(0).contiguous().to(dev)          # (row = owned source, column)
+        if isinstance(be, HipBackend):
+            from .transformer import get_attn_topology
+            if self._ttopo is None:
+                self._ttopo = get_attn_topology(ei, tp.n_own + tp.n_ghost)
+            y = tb(prev_full, last_full, self._ttopo)
+        else:
+            y = be.temporal_block(tb, prev_full, last_full, ei)
+        y = y[: tp.n_own]
+        return y if self._t_of is None else y.index_select(0, self._t_inv.to(dev))
 
 
 class PartitionedETD(torch.nn.Module):
@@ -417,7 +471,7 @@ class PartitionedETD(torch.nn.Module):
     exchanged latents, their own outputs (rows without their edges here) are dropped.  RoPE: the ghosts' positions travel as in
     ``PartitionedEPD`` (every call unless ``cache_positions``).  Results on the owned rows equal the un-partitioned forward /
     backward (tests: gloo world 4 against the oracle on the CPU, the HIP engine with all ranks on one device).
-    The temporal block (attends over every node's previous latents, processors.py:203-209) is refused.
+    The temporal block (processors.py:376-377) runs the same way after the last block: one more exchange for the ghosts of ``last_x``.
 
     forward(x_in_own[n_own, F_n], pos_own=None) -> out_own[n_own, O]"""
 
@@ -429,8 +483,8 @@ class PartitionedETD(torch.nn.Module):
         self._pos_full = None
         self._pos_ghost = None
         self._topo = None
-        if getattr(model, "use_temporal_block", False) or getattr(model, "temporal_block", None) is not None:
-            raise NotImplementedError("PartitionedETD: use_temporal_block is not supported on a partitioned mesh")
+        if getattr(model, "attention_backend", "dgl") != "dgl":
+            raise NotImplementedError("PartitionedETD: only the sparse-attention branch (attention_backend='dgl') is partitioned")
 
     def invalidate_positions(self) -> None:
         self._pos_full = None
@@ -469,9 +523,19 @@ class PartitionedETD(torch.nn.Module):
             x_own = x_in_own if m.only_processor else m.nodes_encoder(x_in_own)
         else:
             x_own = x_in_own if m.only_processor else be.mlp(m.nodes_encoder, x_in_own)
+        x_full = None
         for blk in m.processor_list:
             x_full = torch.cat([x_own, HaloExchange.apply(x_own, plan, self.group)], dim=0)
             y = blk(x_full, self._topo, pos=pos_full) if be is None else be.transformer_block(blk, x_full, ei, pos_full)
+            x_own = y[: plan.n_own]
+        if getattr(m, "use_temporal_block", False) and m.temporal_block is not None:
+            # processors.py:376-377: temporal_block(prev_x, last_x, adj) -- row i reads q_i from last_x and k_j (of prev_x), v_j (of
+            # last_x) over the same adjacency as the blocks.  prev_x with its ghost rows is the last block's input (already
+            # exchanged); the ghosts of last_x travel in ONE more neighbour exchange; the ghosts' own output rows are dropped.
+            last_full = torch.cat([x_own, HaloExchange.apply(x_own, plan, self.group)], dim=0)
+            prev_full = x_full if x_full is not None else last_full          # no block: prev_x = last_x = the encoder's output
+            tb = m.temporal_block
+            y = tb(prev_full, last_full, self._topo) if be is None else be.temporal_block(tb, prev_full, last_full, ei)
             x_own = y[: plan.n_own]
         if m.only_processor:
             return x_own

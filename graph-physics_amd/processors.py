@@ -5,6 +5,8 @@ one autograd node (``ops.ProcessorFunction``) that keeps edge latents in the
 dst-sorted order for all rounds."""
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 import torch.nn as nn
 
@@ -16,8 +18,14 @@ class EncodeProcessDecode(nn.Module):
     def __init__(self, message_passing_num: int, node_input_size: int, edge_input_size: int, output_size: int,
                  hidden_size: int = 128, only_processor: bool = False, use_rope_embeddings: bool = False,
                  use_gated_attention: bool = False, use_gated_mlp: bool = False, rope_pos_dimension: int = 3,
-                 rope_base: float = 10000.0, use_temporal_block: bool = False):
+                 rope_base: float = 10000.0, use_temporal_block: bool = False, attention_backend: Optional[str] = None):
         super().__init__()
+        # only read by the temporal block: "dgl" = attention over the mesh adjacency, "pyg" (or MGN_ATTENTION_BACKEND=pyg) = what an
+        # installation without DGL computes, processors.py:203-209: adj = None -> attention over each node's head axis
+        from .transformer import default_attention_backend
+        self.attention_backend = attention_backend if attention_backend is not None else default_attention_backend()
+        if self.attention_backend not in ("dgl", "pyg"):
+            raise ValueError("attention_backend must be 'dgl' or 'pyg'")
         self.only_processor = only_processor
         self.hidden_size = hidden_size
         self.d = output_size
@@ -86,10 +94,13 @@ class EncodeProcessDecode(nn.Module):
                 x, e = ops.processor_apply(x, e, topo, len(grp), *params, spec=b0.spec, pos=pos, phi=phi,
                                            rope_inv_freq=b0._rope_inv_freq if self.use_rope else None)
         if self.use_temporal_block and self.temporal_block is not None:
-            from .transformer import get_attn_topology
-            if rank is not None:  # the attention topology is in the caller's numbering
-                x, prev_x, rank = x.index_select(0, rank), prev_x.index_select(0, rank), None
-            x = self.temporal_block(prev_x, x, get_attn_topology(edge_index, n))
+            if self.attention_backend == "pyg":   # row-wise without an adjacency: any numbering
+                x = self.temporal_block(prev_x, x, None)
+            else:
+                from .transformer import get_attn_topology
+                if rank is not None:  # the attention topology is in the caller's numbering
+                    x, prev_x, rank = x.index_select(0, rank), prev_x.index_select(0, rank), None
+                x = self.temporal_block(prev_x, x, get_attn_topology(edge_index, n))
         out = x if self.only_processor else self.decode_module(x)
         if rank is not None:  # back to the caller's numbering (the decoder is row-wise: permute its narrow output)
             out = out.index_select(0, rank)

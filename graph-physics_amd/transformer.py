@@ -188,6 +188,43 @@ class PackedAttentionFn(torch.autograd.Function):
         return d, None, None, None
 
 
+class HeadAxisAttentionFn(torch.autograd.Function):
+    """``scaled_dot_product_attention(q, k, v, att_mask=None)`` on [N, d, num_heads] operands (layers.py:493-559 without an adjacency):
+    per node, softmax(q k^T / sqrt(d)) over the last axis of [d, d], then @ v -- mgn_head_axis_attn_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, num_heads: int):
+        ops._require_device(q, k, v)
+        q, k, v = (t.float().contiguous() for t in (q, k, v))
+        N, H = q.shape
+        y = torch.empty_like(q)
+        lse = torch.empty(N, H // num_heads, dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            rc = _capi.lib().mgn_head_axis_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), N, H, num_heads, y.data_ptr(), lse.data_ptr(),
+                                                    ops._stream(q.device))
+        _capi.check(rc, "mgn_head_axis_attn_fwd", attn=True)
+        ctx.save_for_backward(q, k, v, y, lse)
+        ctx.num_heads = num_heads
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        q, k, v, y, lse = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        N, H = q.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        with torch.cuda.device(q.device):
+            rc = _capi.lib().mgn_head_axis_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(), lse.data_ptr(), dy.data_ptr(),
+                                                    N, H, ctx.num_heads, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ops._stream(q.device))
+        _capi.check(rc, "mgn_head_axis_attn_bwd", attn=True)
+        return dq, dk, dv, None
+
+
+def head_axis_attention(q, k, v, num_heads: int):
+    """the reference's attention when no adjacency is handed over: [N, H] rows viewed as [N, H / num_heads, num_heads]"""
+    return HeadAxisAttentionFn.apply(q, k, v, num_heads)
+
+
 def sparse_attention(q, k, v, topo: AttnTopology, num_heads: int, return_attention: bool = False, b16: bool = False):
     """``return_attention``: also the per-edge attention weights [E, num_heads] in the order of the caller's edge_index
     (the values of the reference's softmax-ed sparse matrix, layers.py:543-559); no gradient flows through them."""
@@ -379,13 +416,16 @@ class TemporalAttention(nn.Module):
 
     def forward(self, h_prev: torch.Tensor, h_pred: torch.Tensor, adj=None) -> torch.Tensor:
         ops._require_device(h_prev, h_pred)
-        if adj is None:
-            raise NotImplementedError("TemporalAttention runs over the mesh adjacency (the reference's DGL branch)")
-        topo = adj if isinstance(adj, AttnTopology) else get_attn_topology(adj, h_prev.size(0))
         q = dense(h_pred, self.q_proj.weight, self.q_proj.bias)
         k = dense(h_prev, self.k_proj.weight, self.k_proj.bias)
         v = dense(h_pred, self.v_proj.weight, self.v_proj.bias)
-        y = sparse_attention(q, k, v, topo, self.H)
+        if adj is None:
+            # an installation without DGL hands the block no adjacency (processors.py:203-209, :376-377) and
+            # scaled_dot_product_attention (layers.py:493-559) then attends over the head axis of each node
+            y = head_axis_attention(q, k, v, self.H)
+        else:
+            topo = adj if isinstance(adj, AttnTopology) else get_attn_topology(adj, h_prev.size(0))
+            y = sparse_attention(q, k, v, topo, self.H)
         out = dense(y, self.out_proj.weight, self.out_proj.bias)
         if self.use_gate:   # sigmoid(Linear(SiLU(Linear(cat[h_pred, h_prev])))) * out: the concatenation is two input phases
             g1 = dense(h_pred, self.gate[0].weight, self.gate[0].bias, x2=h_prev, act="silu")
@@ -477,8 +517,6 @@ class EncodeTransformDecode(nn.Module):
         # (the reference drops RoPE / the gate without DGL, with a warning: processors.py:267,317-326)
         self.use_rope_embeddings, self.use_gated_attention = use_rope_embeddings and not pyg, use_gated_attention
         self._requested_rope, self.use_temporal_block = use_rope_embeddings, use_temporal_block
-        if pyg and use_temporal_block:
-            raise NotImplementedError("EncodeTransformDecode: the temporal block without a sparse adjacency (non-DGL branch) is not implemented")
         if not self.only_processor:
             self.nodes_encoder = build_mlp(node_input_size, hidden_size, hidden_size)
             self.decode_module = build_mlp(hidden_size, hidden_size, output_size, layer_norm=False)
@@ -509,9 +547,14 @@ class EncodeTransformDecode(nn.Module):
         if order is not None and pos is not None:
             pos = pos.index_select(0, order)
         x = x_in if self.only_processor else self.nodes_encoder(x_in)
-        if pyg:   # processors.py:372-375: x = block(x, edge_index), nothing around it
+        if pyg:   # processors.py:372-377: x = block(x, edge_index); the temporal block is handed adj = None (no DGL: no adjacency)
+            prev_x = last_x = x
             for block in self.processor_list:
-                x = block(x, topo)
+                prev_x = x
+                last_x = block(prev_x, topo)
+                x = last_x
+            if self.use_temporal_block and self.temporal_block is not None:
+                x = self.temporal_block(prev_x, last_x, None)
         else:
             prev_x = last_x = x
             for block in self.processor_list:

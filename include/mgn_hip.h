@@ -581,6 +581,16 @@ int mgn_sparse_attn_bwd_s(const float* q, int64_t ldq, const void* k, int64_t ld
  * with edge_index.  lse from mgn_sparse_attn_fwd. */
 int mgn_sparse_attn_weights(const float* q, const float* k, const float* lse, const int32_t* rowptr, const int32_t* col,
                             const int32_t* out_pos, int64_t N, int H, int num_heads, float* attn, void* stream);
+/* [r6] Attention over the HEAD axis of each node -- scaled_dot_product_attention(q, k, v, att_mask=None) on [N, d, num_heads]
+ * operands (/root/reference/graphphysics/models/layers.py:493-559 with no adjacency: softmax(q k^T / sqrt(d)) over the last
+ * axis of [N, d, d], then @ v), what TemporalAttention.forward (layers.py:858-887) runs when the installation has no DGL
+ * (processors.py:203-209 and :376-377 hand it adj = None).  q / k / v / y / dy / dq / dk / dv: [N, H] fp32 rows, feature
+ * i * num_heads + h = (i, h) of the [d, num_heads] view, d = H / num_heads <= 128; lse: [N, d] (written by _fwd, read by
+ * _bwd).  No node reads another node's rows.  Returns 0, 1 (bad arguments), 2 (HIP error: mgn_attn_last_error()). */
+int mgn_head_axis_attn_fwd(const float* q, const float* k, const float* v, int64_t N, int H, int num_heads, float* y, float* lse,
+                           void* stream);
+int mgn_head_axis_attn_bwd(const float* q, const float* k, const float* v, const float* y, const float* lse, const float* dy,
+                           int64_t N, int H, int num_heads, float* dq, float* dk, float* dv, void* stream);
 const char* mgn_attn_last_error(void);
 
 /* ================================================================================

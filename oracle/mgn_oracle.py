@@ -629,15 +629,27 @@ def transformer_block(x, p, prefix, edge_index, num_heads, act="relu", **kw):
     return x + gated_mlp(rms_norm(x, p[prefix + "norm2.scale"]), p, prefix + "gated_mlp.", act)
 
 
-def temporal_attention(h_prev, h_pred, p, prefix, edge_index, num_heads=4):
-    """TemporalAttention.forward, layers.py:858-887 (use_gate=True, the constructor default)."""
+def head_axis_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """scaled_dot_product_attention WITHOUT an adjacency, layers.py:493-559 (att_mask = None: the ``else`` arms of :518-522 and
+    :555-556): on [N, D, Hh] operands the matrix products run over the last two axes, so every node attends over its own D rows --
+    attn = softmax(q k^T / sqrt(D)) of shape [N, D, D], y = attn @ v.  Pinned by tests/golden/temporal_dense.npz (the unmodified
+    reference TemporalAttention called with adj = None)."""
+    q = q / math.sqrt(k.size(1))
+    return torch.softmax(q @ k.transpose(-2, -1), dim=-1) @ v
+
+
+def temporal_attention(h_prev, h_pred, p, prefix, edge_index, num_heads=4, use_gate=True):
+    """TemporalAttention.forward, layers.py:858-887 (use_gate=True, the constructor default).  ``edge_index=None``: what an
+    installation without DGL computes (processors.py:203-209, :376-377 pass adj = None)."""
     N, h = h_prev.shape
     lin = lambda name, t: torch.nn.functional.linear(t, p[f"{prefix}{name}.weight"], p[f"{prefix}{name}.bias"])  # noqa: E731
     d = h // num_heads
     q, k, v = lin("q_proj", h_pred).reshape(N, d, num_heads), lin("k_proj", h_prev).reshape(N, d, num_heads), lin("v_proj", h_pred).reshape(N, d, num_heads)
-    out = lin("out_proj", sparse_attention(q, k, v, edge_index).reshape(N, h))
-    g = torch.sigmoid(lin("gate.2", torch.nn.functional.silu(lin("gate.0", torch.cat([h_pred, h_prev], dim=-1)))))
-    h_corr = h_prev + g * out
+    y = head_axis_attention(q, k, v) if edge_index is None else sparse_attention(q, k, v, edge_index)
+    out = lin("out_proj", y.reshape(N, h))
+    if use_gate:   # layers.py:880-882
+        out = torch.sigmoid(lin("gate.2", torch.nn.functional.silu(lin("gate.0", torch.cat([h_pred, h_prev], dim=-1))))) * out
+    h_corr = h_prev + out
     return h_corr + lin("mixer.2", torch.nn.functional.silu(lin("mixer.0", torch.cat([h_corr, h_prev], dim=-1))))
 
 
@@ -675,7 +687,10 @@ def etd_forward(x_in, edge_index, p, message_passing_num, num_heads, act="relu",
     prev_x = last_x = x
     if conv == "pyg":
         for i in range(message_passing_num):
-            x = transformer_conv(x, p, f"processor_list.{i}.", edge_index, num_heads)
+            prev_x = x
+            x = last_x = transformer_conv(prev_x, p, f"processor_list.{i}.", edge_index, num_heads)
+        if use_temporal_block:   # :376-377 with adj = None
+            x = temporal_attention(prev_x, last_x, p, "temporal_block.", None, num_heads)
         return mlp(x, p, "decode_module.", act)
     for i in range(message_passing_num):
         prev_x = x

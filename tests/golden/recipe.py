@@ -179,3 +179,13 @@ TRANSFORMER_CASES = {
     # node_input_size 14 (+ 9 one-hot = 23 inputs), output_size 3, on a 3-D tetrahedral mesh
     "etd_aneurysm": dict(model="etd", hidden=64, heads=4, L=10, N=500, seed=506, f_in=23, out=3, pos_dim=3),
 }
+
+
+# ------------------------------------------------ TemporalAttention WITHOUT an adjacency (an installation without DGL: adj = None)
+TEMPORAL_DENSE_CASES = {
+    "tmp_h128_heads4": dict(hidden=128, heads=4, N=90, seed=601),     # EncodeProcessDecode's temporal block (num_heads default)
+    "tmp_h32_heads8": dict(hidden=32, heads=8, N=50, seed=602),
+    "tmp_h64_heads1": dict(hidden=64, heads=1, N=40, seed=603),
+    "tmp_h48_heads2_nogate": dict(hidden=48, heads=2, N=33, seed=604, gate=False),
+}
+EPD_TEMPORAL_NODGL = dict(hidden=128, L=3, N=120, seed=605)           # EncodeProcessDecode(use_temporal_block=True), HAS_DGL_SPARSE False

@@ -171,15 +171,25 @@ def test_bench_refuses_a_gpus_flag_that_contradicts_the_launch():
 
 # ---------------------------------------------------------------- round 3: host logic of the new options
 def test_partitioned_model_refuses_what_it_would_silently_drop():
-    """PartitionedEPD does not apply the temporal block: a model that has it must not construct (the un-partitioned forward would
-    compute another function); RoPE constructs [r4] and asks for the owned positions like the reference asks for graph.pos."""
+    """[r6] a model with the temporal block needs the plan of the flipped edge list (attention rows = sources) built with the same
+    partition vector -- without it, or with another partition, the constructor refuses instead of computing another function; RoPE
+    constructs [r4] and asks for the owned positions like the reference asks for graph.pos."""
     from graph_physics_amd import distributed as D
     from graph_physics_amd import partition as P
 
     pos, ei, _ = R.delaunay_graph(60, 3)
     plan = P.build_rank_plan(ei, P.partition_nodes(pos.numpy(), ei, 2), 0, 2)
-    with pytest.raises(NotImplementedError, match="temporal"):
-        D.PartitionedEPD(gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_temporal_block=True), plan)
+    part = P.partition_nodes(pos.numpy(), ei, 2)
+    tnet = gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_temporal_block=True, attention_backend="dgl")
+    with pytest.raises(ValueError, match="temporal_plan"):
+        D.PartitionedEPD(tnet, plan)
+    with pytest.raises(ValueError, match="same partition"):
+        D.PartitionedEPD(tnet, plan, temporal_plan=P.build_rank_plan(ei.flip(0), 1 - part, 0, 2))
+    D.PartitionedEPD(tnet, plan, temporal_plan=P.build_rank_plan(ei.flip(0), part, 0, 2))
+    # an installation without DGL: the block gets no adjacency and is row-wise -- no second plan
+    D.PartitionedEPD(gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_temporal_block=True, attention_backend="pyg"), plan)
+    with pytest.raises(NotImplementedError, match="sparse-attention"):
+        D.PartitionedETD(gp.EncodeTransformDecode(1, 11, 2, hidden_size=32, attention_backend="pyg"), plan)
     D.PartitionedEPD(gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_rope_embeddings=True, rope_pos_dimension=2), plan)
     pm = D.PartitionedEPD(gp.EncodeProcessDecode(2, 11, 3, 2, hidden_size=32, use_gated_attention=True), plan)
     with pytest.raises(ValueError, match="phi_own"):

@@ -435,6 +435,123 @@ def test_partitioned_transformer_hip_world4_equals_unpartitioned_oracle(rope):
     assert float((full - ref.detach()).abs().max() / ref.detach().abs().max()) < 1e-5
 
 
+# ------------------------------------------------------------------ [r6] the temporal block on a partitioned mesh
+def _directed(ei):
+    """drop the reverse of a third of the edges: attention rows (sources) and message-passing destinations then have different
+    ghosts and another interior / boundary split -- the two plans of PartitionedEPD number the owned nodes differently"""
+    keep = torch.from_numpy(np.random.default_rng(SEED + 40).random(ei.shape[1]) > 0.33) | (ei[0] < ei[1])
+    return ei[:, keep].contiguous()
+
+
+def _temporal_net(gp, model):
+    from graph_physics_amd import layers
+    if model == "etd":
+        return gp.EncodeTransformDecode(3, 11, 2, hidden_size=64, num_heads=4, use_temporal_block=True)
+    layers.set_use_silu_activation(True)     # (see _worker: keeps ReLU branch flips out of a test of the partition logic)
+    try:
+        return gp.EncodeProcessDecode(L, 11, 3, 2, hidden_size=H, use_temporal_block=True, attention_backend="dgl")
+    finally:
+        layers.set_use_silu_activation(False)
+
+
+def _worker_temporal(rank, world, port, q, model):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import graph_physics_amd as gp
+    from graph_physics_amd import distributed as D
+    from graph_physics_amd import partition as P
+
+    dev = torch.device("cuda:0")
+    pos, ei, part = _case(world)
+    N = pos.shape[0]
+    net = _temporal_net(gp, model)
+    net.load_state_dict(R.variant_params(net.state_dict(), SEED + 50))
+    net = net.to(dev)
+    if model == "etd":
+        x_in, _, tgt, nt = _inputs(N, ei.shape[1])
+        plan = P.build_rank_plan(ei.flip(0), part, rank, world, pos=pos.numpy())
+        pm = D.PartitionedETD(net, plan)
+        run = lambda: pm(x_in[plan.owned].to(dev))   # noqa: E731
+        renumbered = False
+    else:
+        ei = _directed(ei)
+        x_in, e_in, tgt, nt = _inputs(N, ei.shape[1])
+        plan = P.build_rank_plan(ei, part, rank, world, pos=pos.numpy())
+        tplan = P.build_rank_plan(ei.flip(0), part, rank, world, pos=pos.numpy())
+        pm = D.PartitionedEPD(net, plan, temporal_plan=tplan)   # H = 128: the fused processor node, split before the last round
+        run = lambda: pm(x_in[plan.owned].to(dev), e_in[plan.edge_ids].to(dev))   # noqa: E731
+        renumbered = pm._t_of is not None
+    runs = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        out = run()
+        loss = D.partitioned_loss(out, tgt[plan.owned].to(dev), nt[plan.owned].to(dev))
+        loss.backward()
+        runs.append({k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None})
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k      # bit-reproducible
+    D.GradAllReduce(average=False)(net.parameters())
+    grads = {k: v.grad.cpu().numpy().copy() for k, v in net.named_parameters() if v.grad is not None}
+    q.put((rank, plan.owned.numpy().copy(), out.detach().cpu().numpy().copy(), float(loss.detach()), grads, renumbered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["epd", "etd"])
+def test_partitioned_temporal_block_hip_world4_equals_unpartitioned_oracle(model):
+    """TemporalAttention (layers.py:822-887) after the last round / block of a PARTITIONED model, on the HIP
+    engine, world 4 on one device (a rank without any boundary among them): forward, loss and every parameter gradient against
+    the un-partitioned oracle.  epd: message passing on the plan of the edge list, the temporal rows (= sources,
+    processors.py:183-184) on the plan of the flipped list, a directed mesh so that the two number their owned nodes differently."""
+    world = 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_temporal, args=(r, world, port, q, model)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(q, procs, world, 900)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    import graph_physics_amd as gp
+
+    pos, ei, part = _case(world)
+    N = pos.shape[0]
+    net = _temporal_net(gp, model)
+    params = {k: v.clone().requires_grad_(True) for k, v in R.variant_params(net.state_dict(), SEED + 50).items()}
+    if model == "etd":
+        x_in, _, tgt, nt = _inputs(N, ei.shape[1])
+        ref = O.etd_forward(x_in, ei, params, 3, 4, use_temporal_block=True)
+    else:
+        ei = _directed(ei)
+        x_in, e_in, tgt, nt = _inputs(N, ei.shape[1])
+        x, e = O.mlp(x_in, params, "nodes_encoder.", "silu"), O.mlp(e_in, params, "edges_encoder.", "silu")
+        prev = x
+        for i in range(L):
+            prev = x
+            x, e = O.graph_net_block(x, e, ei, params, f"processor_list.{i}.", act="silu")
+        ref = O.mlp(O.temporal_attention(prev, x, params, "temporal_block.", ei, 4), params, "decode_module.", "silu")
+    ref_loss = O.l2_loss(ref, tgt, nt)
+    ref_loss.backward()
+    gmax = max(float(v.grad.abs().max()) for v in params.values() if v.grad is not None)
+    full, total = torch.zeros_like(ref), 0.0
+    for rank, owned, out, loss, grads, renumbered in res:
+        full[torch.from_numpy(owned)] = torch.from_numpy(out)
+        total += loss
+        for k, g in grads.items():
+            gref = params[k].grad
+            if gref is None:
+                continue
+            scale = max(float(gref.abs().max()), 1e-3 * gmax)     # (softmax-invariant key biases: see the Transformer test above)
+            err = float((torch.from_numpy(g) - gref).abs().max()) / scale
+            assert err < 3e-4, (rank, k, err)
+    if model == "epd":
+        assert any(r[5] for r in res)
+    assert abs(total - float(ref_loss.detach())) < 1e-5 * abs(float(ref_loss.detach()))
+    assert float((full - ref.detach()).abs().max() / ref.detach().abs().max()) < 1e-5
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -74,6 +74,59 @@ def test_oracle_vs_reference_golden(name):
             assert abs(float(p[k].grad.norm()) - gn) < 2e-3 * gn + 1e-8, k
 
 
+def temporal_dense_fixture():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "temporal_dense.npz"))
+    return {k: (str(z[k]) if z[k].dtype.kind == "U" else torch.from_numpy(z[k])) for k in z.files}
+
+
+@pytest.mark.parametrize("name", list(R.TEMPORAL_DENSE_CASES))
+def test_oracle_temporal_block_without_adjacency_vs_reference_golden(name):
+    """[r6] TemporalAttention(h_prev, h_pred, adj=None) -- what an installation without DGL runs (processors.py:203-209, :376-377):
+    scaled_dot_product_attention without a mask attends over the head axis of each node (layers.py:518-522, :555-556).  Golden: the
+    unmodified reference module (tests/golden/make_golden_temporal_dense.py)."""
+    import graph_physics_amd as gp
+
+    fx = temporal_dense_fixture()
+    c = R.TEMPORAL_DENSE_CASES[name]
+    H, nh, N, seed = c["hidden"], c["heads"], c["N"], c["seed"]
+    mod = gp.TemporalAttention(H, nh, use_gate=c.get("gate", True))
+    keys = fx[name + ".keys"].split("|")
+    assert list(mod.state_dict().keys()) == keys
+    p = {k: t.clone().requires_grad_(True) for k, t in R.variant_params(mod.state_dict(), seed, keys).items()}
+    h_prev, h_pred, cot = (R.randn((N, H), seed + i).requires_grad_(i < 3) for i in (1, 2, 3))
+    out = O.temporal_attention(h_prev, h_pred, p, "", None, nh, use_gate=c.get("gate", True))
+    assert rel_err(out, fx[name + ".out"]) < 2e-6
+    (out * cot).sum().backward()
+    assert rel_err(h_prev.grad, fx[name + ".d_prev"]) < 1e-5 and rel_err(h_pred.grad, fx[name + ".d_pred"]) < 1e-5
+    for k in keys:
+        assert abs(float(p[k].grad.norm()) - float(fx[f"{name}.gnorm.{k}"])) < 1e-4 * float(fx[f"{name}.gnorm.{k}"]) + 1e-8, k
+
+
+def test_oracle_epd_temporal_tail_without_dgl_vs_reference_golden():
+    """[r6] the reference's EncodeProcessDecode(use_temporal_block=True) as THIS image runs it (no DGL: adj = None)"""
+    import graph_physics_amd as gp
+
+    fx = temporal_dense_fixture()
+    c, name = R.EPD_TEMPORAL_NODGL, "epd_temporal_nodgl"
+    _, ei, ea = R.delaunay_graph(c["N"], c["seed"], dim=2)
+    net = gp.EncodeProcessDecode(c["L"], 11, 3, 2, hidden_size=c["hidden"], use_temporal_block=True, attention_backend="pyg")
+    keys = fx[name + ".keys"].split("|")
+    assert list(net.state_dict().keys()) == keys
+    p = {k: t.clone().requires_grad_(True) for k, t in R.variant_params(net.state_dict(), c["seed"], keys).items()}
+    x_in, e_in, cot = R.randn((c["N"], 11), c["seed"] + 1), R.randn((ea.shape[0], 3), c["seed"] + 2), R.randn((c["N"], 2), c["seed"] + 3)
+    x, e = O.mlp(x_in, p, "nodes_encoder."), O.mlp(e_in, p, "edges_encoder.")
+    prev = x
+    for i in range(c["L"]):
+        prev = x
+        x, e = O.graph_net_block(x, e, ei, p, f"processor_list.{i}.")
+    out = O.mlp(O.temporal_attention(prev, x, p, "temporal_block.", None, 4), p, "decode_module.")
+    assert rel_err(out, fx[name + ".out"]) < 2e-6
+    (out * cot).sum().backward()
+    for k in keys:
+        gn = float(fx[f"{name}.gnorm.{k}"])
+        assert abs(float(p[k].grad.norm()) - gn) < 2e-3 * gn + 1e-8, k
+
+
 # ----------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("H,nh", [(128, 4), (64, 4), (64, 2), (32, 8), (16, 16), (128, 1), (128, 16), (16, 1)])
@@ -567,8 +620,9 @@ def test_transformer_conv_branch_surface_and_oracle_restatement(monkeypatch):
     monkeypatch.setenv("MGN_ATTENTION_BACKEND", "pyg")
     assert T.default_attention_backend() == "pyg"
     assert isinstance(gp.EncodeTransformDecode(1, 11, 2, hidden_size=H, num_heads=nh).processor_list[0], T.TransformerConv)
-    with pytest.raises(NotImplementedError):
-        gp.EncodeTransformDecode(1, 11, 2, hidden_size=H, num_heads=nh, use_temporal_block=True)
+    # [r6] the temporal block constructs on this branch too (processors.py:327-336: "Temporal attention will run without sparse adjacency")
+    tnet = gp.EncodeTransformDecode(1, 11, 2, hidden_size=H, num_heads=nh, use_temporal_block=True)
+    assert tnet.temporal_block is not None and "temporal_block.mixer.2.bias" in tnet.state_dict()
     # oracle (edge list) against a dense masked evaluation, duplicates-free graph with an isolated node
     _, ei, _ = R.delaunay_graph(N - 1, 7)
     p = {k: v.double() for k, v in R.variant_params({k[len("processor_list.0."):]: v for k, v in sd.items() if k.startswith("processor_list.0.")}, 9).items()}
@@ -613,4 +667,104 @@ def test_transformer_conv_branch_on_the_engine_vs_oracle(H, nh):
     gmax = max(float(t.grad.abs().max()) for t in p.values())
     for k, t in net.named_parameters():
         scale = max(float(p[k].grad.abs().max()), 1e-3 * gmax)   # (the key bias' gradient is zero up to rounding: the softmax does not see it)
+        assert float((t.grad.cpu() - p[k].grad).abs().max()) / scale < GRAD_TOL, k
+
+
+# ------------------------------------------------------------------ [r6] the temporal block without an adjacency (no-DGL installations)
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,nh", [(128, 4), (32, 8), (64, 1), (48, 2), (128, 16), (16, 16), (256, 2)])
+def test_head_axis_attention_kernels_vs_oracle(dev, H, nh):
+    """mgn_head_axis_attn_fwd / _bwd against the oracle's restatement of the unmasked scaled_dot_product_attention (layers.py:493-559):
+    forward 1e-5 in three readings, dq / dk / dv 2e-5, bit-reproducible, ragged node counts (the last workgroup is partial)"""
+    from graph_physics_amd import transformer as T
+
+    for N in (1, 7, 301):
+        seed = 900 + H + nh + N
+        q, k, v, cot = (R.randn((N, H), seed + i) for i in range(1, 5))
+        D = H // nh
+        qo, ko, vo = (t.clone().requires_grad_(True) for t in (q, k, v))
+        ref = O.head_axis_attention(qo.reshape(N, D, nh), ko.reshape(N, D, nh), vo.reshape(N, D, nh)).reshape(N, H)
+        (ref * cot).sum().backward()
+        qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+        y = T.head_axis_attention(qd, kd, vd, nh)
+        (y * cot.to(dev)).sum().backward()
+        assert_close3(y, ref, FWD_TOL, f"head-axis attention H={H} heads={nh} N={N}")
+        for a, b, what in ((qd.grad, qo.grad, "dq"), (kd.grad, ko.grad, "dk"), (vd.grad, vo.grad, "dv")):
+            assert rel_err(a, b) < 2e-5, (what, N)
+        g1 = [t.grad.clone() for t in (qd, kd, vd)]
+        qd.grad = kd.grad = vd.grad = None
+        y2 = T.head_axis_attention(qd, kd, vd, nh)
+        (y2 * cot.to(dev)).sum().backward()
+        assert torch.equal(y, y2) and all(torch.equal(a, t.grad) for a, t in zip(g1, (qd, kd, vd)))
+    with pytest.raises(RuntimeError, match="num_heads"):
+        T.head_axis_attention(torch.zeros(4, 30, device=dev), torch.zeros(4, 30, device=dev), torch.zeros(4, 30, device=dev), 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(R.TEMPORAL_DENSE_CASES))
+def test_temporal_block_without_adjacency_on_the_engine_vs_reference_golden(dev, name):
+    """gp.TemporalAttention(h_prev, h_pred, None) on the engine against the golden of the unmodified reference module: output 1e-5,
+    input gradients 1e-4, every parameter-gradient norm"""
+    import graph_physics_amd as gp
+
+    fx = temporal_dense_fixture()
+    c = R.TEMPORAL_DENSE_CASES[name]
+    H, nh, N, seed = c["hidden"], c["heads"], c["N"], c["seed"]
+    mod = gp.TemporalAttention(H, nh, use_gate=c.get("gate", True))
+    mod.load_state_dict(R.variant_params(mod.state_dict(), seed, fx[name + ".keys"].split("|")))
+    mod = mod.to(dev)
+    h_prev, h_pred, cot = (R.randn((N, H), seed + i).to(dev).requires_grad_(i < 3) for i in (1, 2, 3))
+    out = mod(h_prev, h_pred, None)
+    assert_close3(out, fx[name + ".out"], FWD_TOL, name)
+    (out * cot).sum().backward()
+    assert rel_err(h_prev.grad, fx[name + ".d_prev"]) < GRAD_TOL and rel_err(h_pred.grad, fx[name + ".d_pred"]) < GRAD_TOL
+    for k, t in mod.named_parameters():
+        gn = float(fx[f"{name}.gnorm.{k}"])
+        assert abs(float(t.grad.norm()) - gn) < 2e-4 * gn + 1e-7, k
+        if f"{name}.g.{k}" in fx:
+            assert rel_err(t.grad, fx[f"{name}.g.{k}"]) < 2e-4, k
+
+
+@pytest.mark.gpu
+def test_epd_and_etd_temporal_tail_without_dgl_on_the_engine(dev):
+    """the whole models on the no-DGL branch: EncodeProcessDecode(use_temporal_block=True, attention_backend="pyg") against the golden of
+    the unmodified reference (as this image runs it), EncodeTransformDecode(attention_backend="pyg", use_temporal_block=True) against
+    the oracle (its TransformerConv blocks are parity-unpinned: PyG is not installable here)"""
+    import graph_physics_amd as gp
+
+    fx = temporal_dense_fixture()
+    c, name = R.EPD_TEMPORAL_NODGL, "epd_temporal_nodgl"
+    _, ei, ea = R.delaunay_graph(c["N"], c["seed"], dim=2)
+    net = gp.EncodeProcessDecode(c["L"], 11, 3, 2, hidden_size=c["hidden"], use_temporal_block=True, attention_backend="pyg")
+    net.load_state_dict(R.variant_params(net.state_dict(), c["seed"], fx[name + ".keys"].split("|")))
+    net = net.to(dev)
+    x_in, e_in, cot = R.randn((c["N"], 11), c["seed"] + 1), R.randn((ea.shape[0], 3), c["seed"] + 2), R.randn((c["N"], 2), c["seed"] + 3)
+    out = net(gp.Graph(x=x_in.to(dev), edge_attr=e_in.to(dev), edge_index=ei.to(dev)))
+    assert_close3(out, fx[name + ".out"], FWD_TOL, name)
+    (out * cot.to(dev)).sum().backward()
+    for k, t in net.named_parameters():
+        gn = float(fx[f"{name}.gnorm.{k}"])
+        assert abs(float(t.grad.norm()) - gn) < 2e-3 * gn + 1e-7, k
+    # EncodeTransformDecode, non-DGL branch with the temporal tail
+    H, nh, L, N, seed = 32, 4, 2, 300, 611
+    pos, ei, _ = R.delaunay_graph(N, seed)
+    from graph_physics_amd import layers
+    layers.set_use_silu_activation(True)   # SiLU encoders / decoder: no ReLU branch flips between the CPU oracle and the engine
+    try:
+        etd = gp.EncodeTransformDecode(L, 11, 2, hidden_size=H, num_heads=nh, attention_backend="pyg", use_temporal_block=True)
+    finally:
+        layers.set_use_silu_activation(False)
+    params = R.variant_params(etd.state_dict(), seed)
+    etd.load_state_dict(params)
+    etd = etd.to(dev)
+    x_in, cot = R.randn((N, 11), seed + 1), R.randn((N, 2), seed + 3)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.etd_forward(x_in, ei, p, L, nh, act="silu", use_temporal_block=True, conv="pyg")
+    (ref * cot).sum().backward()
+    out = etd(gp.Graph(x=x_in.to(dev), edge_index=ei.to(dev)))
+    assert_close3(out, ref.detach(), FWD_TOL, "ETD pyg branch + temporal tail")
+    (out * cot.to(dev)).sum().backward()
+    gmax = max(float(t.grad.abs().max()) for t in p.values())
+    for k, t in etd.named_parameters():
+        scale = max(float(p[k].grad.abs().max()), 1e-3 * gmax)
         assert float((t.grad.cpu() - p[k].grad).abs().max()) / scale < GRAD_TOL, k
