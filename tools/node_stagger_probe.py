@@ -54,4 +54,6 @@ for t in [int(v) for v in sys.argv[1:]] or [0, 100, 200, 400]:
         e1.record()
         torch.cuda.synchronize()
         best.append(e0.elapsed_time(e1) * 10)
-    print("stagger %4d ticks (save=%d, N=%d): %.1f us per launch (min of 5 x 100), median %.1f" % (t, save, N, min(best), sorted(best)[2]), flush=True)
+    chk = [float(sets[0][k].double().abs().sum()) for k in ("x_new", "Pd", "Ps")] + ([float(sets[0]["Un"].double().abs().sum())] if save else [])
+    print("stagger %4d ticks (save=%d, N=%d, MGN_NW_SMALL=%s): %.1f us per launch (min of 5 x 100), median %.1f   checksums %s" % (
+        t, save, N, os.environ.get("MGN_NW_SMALL", "-"), min(best), sorted(best)[2], " ".join("%.9e" % v for v in chk)), flush=True)
