@@ -46,7 +46,15 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(dev: torch.device) -> int:
+    """the hipStream_t of torch's current stream on ``dev`` (what every launch of the engine is queued on).  The raw query is one C call;
+    building a ``torch.cuda.Stream`` object for it costs ~5 us, 60-90 times per training step"""
+    if _raw_stream is not None:
+        idx = dev.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(dev).cuda_stream
 
 

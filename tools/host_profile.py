@@ -53,3 +53,60 @@ torch.cuda.synchronize()
 st = pstats.Stats(pr_)
 st.sort_stats("cumulative").print_stats(45)
 st.sort_stats("tottime").print_stats(25)
+
+# ---- the backward pass runs on autograd's device thread (cProfile does not see it): wall time inside the engine's launch functions
+# against the whole of ProcessorFunction.backward
+import collections
+from graph_physics_amd import ops as _ops
+acc = collections.defaultdict(lambda: [0, 0.0])
+
+
+def _wrap(name):
+    fn = getattr(_ops, name)
+
+    def w(*a, **k):
+        t = time.perf_counter()
+        r = fn(*a, **k)
+        v = acc[name]
+        v[0] += 1
+        v[1] += time.perf_counter() - t
+        return r
+    setattr(_ops, name, w)
+
+
+for n_ in ("mlp_fwd", "mlp_bwd", "wgrad", "segsum2", "segsum_topo", "seg_fix", "colred_batch", "wpack", "_split_block", "gather_rows"):
+    _wrap(n_)
+_bw = _ops.ProcessorFunction.backward
+
+
+def _bw_t(ctx, *g):
+    t = time.perf_counter()
+    r = _bw(ctx, *g)
+    v = acc["ProcessorFunction.backward (total)"]
+    v[0] += 1
+    v[1] += time.perf_counter() - t
+    return r
+
+
+_ops.ProcessorFunction.backward = staticmethod(_bw_t)
+_emp = torch.empty
+_el = torch.empty_like
+
+
+def _empty(*a, **k):
+    t = time.perf_counter()
+    r = _emp(*a, **k)
+    v = acc["torch.empty"]
+    v[0] += 1
+    v[1] += time.perf_counter() - t
+    return r
+
+
+torch.empty = _empty
+for _ in range(K):
+    step()
+torch.cuda.synchronize()
+torch.empty = _emp
+print("per step (host wall time inside, %d steps):" % K)
+for k_, (n_, t_) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+    print("  %-40s %6.1f calls  %7.3f ms" % (k_, n_ / K, 1e3 * t_ / K))
